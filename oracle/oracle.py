@@ -1,0 +1,212 @@
+"""ctypes binding of the CPU oracle (liburf_oracle.so) -- TEST INFRASTRUCTURE.
+
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Builds the library on first use if it is missing (gcc is in the image).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liburf_oracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c",
+                                              "urf_oracle.h", "oracle_math.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liburf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class SPConfig(C.Structure):
+    _fields_ = [("max_keypoints", C.c_int), ("keypoint_threshold", C.c_double), ("remove_borders", C.c_int)]
+
+
+class SGConfig(C.Structure):
+    _fields_ = [("image_width", C.c_int), ("image_height", C.c_int),
+                ("matching_threshold", C.c_double), ("sinkhorn_iterations", C.c_int)]
+
+
+class RansacConfig(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("sigma", C.c_float), ("seed", C.c_uint32)]
+
+
+class DMatch(C.Structure):
+    _fields_ = [("queryIdx", C.c_int), ("trainIdx", C.c_int), ("distance", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.o_exp.restype = C.c_float
+        _lib.o_exp.argtypes = [C.c_float]
+        _lib.o_log.restype = C.c_float
+        _lib.o_log.argtypes = [C.c_float]
+        _lib.o_wave_sum.restype = C.c_float
+        _lib.oransac_find_F.restype = C.c_float
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+SP_CHANNELS = [64, 64, 64, 64, 128, 128, 128, 128, 256, 65, 256, 256]
+SP_SCALE = [1, 2, 2, 4, 4, 8, 8, 8, 8, 8, 8, 8]  # output is H/scale x W/scale
+
+
+def sp_dense(blob, img, want_layers=False):
+    """returns dict(scores, heat, desc[, layers]) for a u8 HxW image."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    Hc, Wc = H // 8, W // 8
+    scores = np.zeros((Hc * 8, Wc * 8), np.float32)
+    heat = np.zeros((Hc * 8, Wc * 8), np.float32)
+    desc = np.zeros((Hc, Wc, 256), np.float32)
+    layers = None
+    lp = None
+    if want_layers:
+        layers = []
+        h, w = H, W
+        dims = []
+        for i in range(12):
+            if i in (1, 3, 5):
+                h, w = h // 2, w // 2
+            dims.append((h, w))
+            layers.append(np.zeros((h, w, SP_CHANNELS[i]), np.float32))
+        arr = (C.c_void_p * 12)(*[l.ctypes.data for l in layers])
+        lp = arr
+    rc = lib().osp_dense(_p(blob), _p(img), H, W, C.c_size_t(img.strides[0]), _p(scores), _p(heat), _p(desc), lp)
+    assert rc == 0, rc
+    out = dict(scores=scores, heat=heat, desc=desc)
+    if want_layers:
+        out["layers"] = layers
+    return out
+
+
+def sp_nms(heat):
+    heat = np.ascontiguousarray(heat, np.float32)
+    out = np.zeros_like(heat)
+    lib().osp_simple_nms(_p(heat), heat.shape[0], heat.shape[1], _p(out))
+    return out
+
+
+def sp_postprocess(scores, desc, cfg, mask=None, cap=None):
+    Hs, Ws = scores.shape
+    Hc, Wc = desc.shape[:2]
+    cap = cap or Hs * Ws
+    feat = np.zeros((cap, 259), np.float64)  # column-major 259 x cap
+    K = C.c_int(0)
+    idx = np.zeros(cap, np.int32)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+    rc = lib().osp_postprocess(_p(scores), Hs, Ws, _p(desc), Hc, Wc, _p(mask),
+                               C.c_size_t(mask.strides[0] if mask is not None else 0),
+                               C.byref(cfg), _p(feat), cap, C.byref(K), _p(idx))
+    assert rc == 0, rc
+    return feat[:K.value].copy(), idx[:K.value].copy()
+
+
+def sp_infer(blob, cfg, img, mask=None, cap=4096):
+    """SuperPoint::infer.  Returns feat [K][259] (row j = column j of the 259xK matrix)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    cap = max(cap, 1)
+    if cfg.max_keypoints < 0:
+        cap = (H // 8) * (W // 8) * 64
+    feat = np.zeros((cap, 259), np.float64)
+    K = C.c_int(0)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+    rc = lib().osp_infer(_p(blob), C.byref(cfg), _p(img), H, W, C.c_size_t(img.strides[0]), _p(mask),
+                         C.c_size_t(mask.strides[0] if mask is not None else 0), _p(feat), cap, C.byref(K))
+    assert rc == 0, rc
+    return feat[:K.value].copy()
+
+
+def sg_normalize(feat, width, height):
+    feat = np.ascontiguousarray(feat, np.float64)
+    out = np.zeros_like(feat)
+    lib().osg_normalize_keypoints(_p(feat), feat.shape[0], width, height, _p(out))
+    return out
+
+
+def sg_graph(blob, iters, f0, f1, want_final=False):
+    f0 = np.ascontiguousarray(f0, np.float64)
+    f1 = np.ascontiguousarray(f1, np.float64)
+    n0, n1 = f0.shape[0], f1.shape[0]
+    Z = np.zeros((n0 + 1, n1 + 1), np.float32)
+    m0 = np.zeros((n0, 256), np.float32) if want_final else None
+    m1 = np.zeros((n1, 256), np.float32) if want_final else None
+    rc = lib().osg_graph(_p(blob), iters, _p(f0), n0, _p(f1), n1, _p(Z), _p(m0), _p(m1))
+    assert rc == 0, rc
+    return (Z, m0, m1) if want_final else Z
+
+
+def sg_decode(Z, thresh):
+    Z = np.ascontiguousarray(Z, np.float32)
+    h, w = Z.shape
+    i0 = np.zeros(h - 1, np.int32)
+    i1 = np.zeros(w - 1, np.int32)
+    m0 = np.zeros(h - 1, np.float64)
+    m1 = np.zeros(w - 1, np.float64)
+    lib().osg_decode(_p(Z), h, w, C.c_double(thresh), _p(i0), _p(i1), _p(m0), _p(m1))
+    return i0, i1, m0, m1
+
+
+def sg_infer(blob, cfg, f0, f1):
+    f0 = np.ascontiguousarray(f0, np.float64)
+    f1 = np.ascontiguousarray(f1, np.float64)
+    n0, n1 = f0.shape[0], f1.shape[0]
+    i0 = np.zeros(n0, np.int32)
+    i1 = np.zeros(n1, np.int32)
+    m0 = np.zeros(n0, np.float64)
+    m1 = np.zeros(n1, np.float64)
+    Z = np.zeros((n0 + 1, n1 + 1), np.float32)
+    rc = lib().osg_infer(_p(blob), C.byref(cfg), _p(f0), n0, _p(f1), n1, _p(i0), _p(i1), _p(m0), _p(m1), _p(Z))
+    assert rc == 0, rc
+    return i0, i1, m0, m1, Z
+
+
+def ransac_find_F(p0, p1, cfg):
+    p0 = np.ascontiguousarray(p0, np.float32)
+    p1 = np.ascontiguousarray(p1, np.float32)
+    n = p0.shape[0]
+    inl = np.zeros(n, np.uint8)
+    F = np.zeros(9, np.float32)
+    s = lib().oransac_find_F(_p(p0), _p(p1), n, C.byref(cfg), _p(inl), _p(F))
+    return float(s), inl, F.reshape(3, 3)
+
+
+def match_points(sg_blob, cfg, rcfg, f0, f1, outlier_rejection=True):
+    f0 = np.ascontiguousarray(f0, np.float64)
+    f1 = np.ascontiguousarray(f1, np.float64)
+    n0, n1 = f0.shape[0], f1.shape[0]
+    cap = max(n0, 1)
+    out = (DMatch * cap)()
+    n = lib().omatch_points(_p(sg_blob), C.byref(cfg), C.byref(rcfg), _p(f0), n0, _p(f1), n1,
+                            int(bool(outlier_rejection)), out, cap)
+    return [(out[i].queryIdx, out[i].trainIdx, out[i].distance) for i in range(n)]
+
+
+def fma_gemm(A, B, C0=None):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    M, K = A.shape
+    N = B.shape[1]
+    out = np.zeros((M, N), np.float32)
+    if C0 is not None:
+        C0 = np.ascontiguousarray(C0, np.float32)
+    lib().o_fma_gemm(_p(A), _p(B), _p(C0), M, N, K, _p(out))
+    return out

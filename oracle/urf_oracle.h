@@ -1,0 +1,124 @@
+/* urf_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement (the parity oracle) of
+ * the UR-MVO learned front-end: SuperPoint -> SuperGlue -> epipolar RANSAC.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (ur-mvo_amd/) never includes, links or calls
+ * anything in oracle/.
+ *
+ * Every function cites the reference file:line (relative to the UR-MVO tree)
+ * whose behaviour it restates.  Pinning: see oracle/README.md and DESIGN.md.
+ */
+#ifndef URF_ORACLE_H_
+#define URF_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- weight containers (same written layout as the product) ---- */
+#define OSP_NUM_CONV 12
+#define OSP_BLOB_FLOATS 1300865
+#define OSG_BLOB_FLOATS 12003905
+#define OSG_LAYERS 18
+
+/* ---------------- SuperPoint ---------------- */
+typedef struct {
+  int max_keypoints;          /* include/read_configs.h:10 */
+  double keypoint_threshold;  /* :11 */
+  int remove_borders;         /* :12 */
+} osp_config;
+
+/* Dense network, superpoint/SP/model.py:55-86 (+ simple_nms :15-26) fed by
+ * SuperPoint::process_input src/super_point.cpp:158-176.
+ * img: u8 H x W with row stride `step`.  Outputs (any may be NULL):
+ *   scores_nms : [Hs][Ws] f32 post-NMS heat map, Hs=(H/8)*8, Ws=(W/8)*8
+ *   heat       : [Hs][Ws] f32 pre-NMS heat map (softmax + depth-to-space)
+ *   desc       : [Hc][Wc][256] f32 L2-normalised dense descriptors (NHWC)
+ *   layers[i]  : optional per-conv post-activation dumps (NHWC), i in [0,12)
+ */
+int osp_dense(const float *blob, const uint8_t *img, int H, int W, size_t step,
+              float *scores_nms, float *heat, float *desc, float **layers);
+
+/* SuperPoint::process_output src/super_point.cpp:338-386 (host post-process).
+ * scores: [Hs][Ws]; desc: [Hc][Wc][256]; mask: NULL or u8 [Hs][Ws] stride mstep.
+ * feat: column-major 259 x cap doubles.  Returns 0; *K = columns written.
+ * kp_index (optional, cap ints): raster index y*Ws+x of each keypoint. */
+int osp_postprocess(const float *scores, int Hs, int Ws, const float *desc,
+                    int Hc, int Wc, const uint8_t *mask, size_t mstep,
+                    const osp_config *cfg, double *feat, int cap, int *K,
+                    int *kp_index);
+
+/* SuperPoint::infer src/super_point.cpp:121-156 = dense + postprocess. */
+int osp_infer(const float *blob, const osp_config *cfg, const uint8_t *img,
+              int H, int W, size_t step, const uint8_t *mask, size_t mstep,
+              double *feat, int cap, int *K);
+
+/* simple_nms alone (superpoint/SP/model.py:15-26), radius 4. */
+void osp_simple_nms(const float *heat, int Hs, int Ws, float *out);
+
+/* ---------------- SuperGlue + matching ---------------- */
+typedef struct {
+  int image_width;            /* include/read_configs.h:21 */
+  int image_height;           /* :22 */
+  double matching_threshold;  /* :24 */
+  int sinkhorn_iterations;    /* src/super_glue.cpp:463 (default 100) */
+} osg_config;
+
+/* PointMatching::NormalizeKeypoints src/point_matching.cc:63-76 */
+void osg_normalize_keypoints(const double *feat, int n, int width, int height,
+                             double *out);
+
+/* SuperGlue graph (I/O contract src/super_glue.cpp:63-98,
+ * 198-215, Sinkhorn recurrence :432-498).  f0/f1: column-major 259 x n with
+ * ALREADY normalised keypoints (as SuperGlue::infer receives them).
+ * Z: (n0+1) x (n1+1) row-major log-assignment (may be NULL).
+ * final0/final1: optional [n][256] projected descriptors. */
+int osg_graph(const float *blob, int iters, const double *f0, int n0,
+              const double *f1, int n1, float *Z, float *final0, float *final1);
+
+/* decode() src/super_glue.cpp:401-430 on a (h x w) log-assignment. */
+void osg_decode(const float *Z, int h, int w, double thresh, int *idx0,
+                int *idx1, double *ms0, double *ms1);
+
+/* SuperGlue::infer src/super_glue.cpp:166-241 = graph + decode. */
+int osg_infer(const float *blob, const osg_config *cfg, const double *f0,
+              int n0, const double *f1, int n1, int *idx0, int *idx1,
+              double *ms0, double *ms1, float *Z);
+
+typedef struct { int queryIdx, trainIdx; float distance; } o_dmatch;
+
+typedef struct {
+  int iterations;   /* EpipolarGeometry(K, sigma, iterations): src/tracking.cc:52-55 -> 200 */
+  float sigma;      /* 1.0 */
+  uint32_t seed;    /* explicit, replaces process-global srand(0) (src/epipolar_geometry.cc:100-112) */
+} oransac_config;
+
+/* EpipolarGeometry::_find_F (+_normalize,_compute_F21,_check_F)
+ * src/epipolar_geometry.cc:161-205,247-283,372-449,735-780 on n matched pixel
+ * pairs.  inliers: n bytes.  F21: 9 floats row-major.  Returns best score. */
+float oransac_find_F(const float *pts0, const float *pts1, int n,
+                     const oransac_config *cfg, uint8_t *inliers, float *F21);
+
+/* PointMatching::MatchingPoints src/point_matching.cc:14-61; the
+ * cv::findFundamentalMat call (:50) is replaced by oransac_find_F.
+ * Returns number of matches written (<= cap). */
+int omatch_points(const float *sg_blob, const osg_config *cfg,
+                  const oransac_config *rcfg, const double *f0, int n0,
+                  const double *f1, int n1, int outlier_rejection,
+                  o_dmatch *out, int cap);
+
+/* canonical math probes (tests) */
+float o_exp(float x);
+float o_log(float x);
+float o_wave_sum(const float *x, int n);
+/* fmaf-chain GEMM probe: C[m][n] = chain_k fma(A[m][k], B[k][n], C0[m][n]) */
+void o_fma_gemm(const float *A, const float *B, const float *C0, int M, int N,
+                int K, float *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
