@@ -1,0 +1,161 @@
+/* urf.h -- C ABI of liburf_front.so, the MI355X-native front-end that replaces
+ * UR-MVO's TensorRT path (SuperPoint -> SuperGlue -> epipolar RANSAC).
+ *
+ * Plain pointers and sizes only; no torch / Eigen / OpenCV types.  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * UR-MVO tree).  The C++ shim headers include/super_point.h, super_glue.h and
+ * point_matching.h rebuild the reference's classes on top of this ABI
+ * (INTEGRATION.md shows the binding a maintainer adds).
+ *
+ * Return value: 0 = ok, <0 = error (urf_last_error() has the text).  No
+ * exceptions cross this boundary; on error outputs are left untouched
+ * (reference contract: bool returns, src/tracking.cc:328-331,346-350).
+ * Threading: a handle may be used from any host thread, one call at a time per
+ * handle (the reference serialises with _gpu_mutex, src/tracking.cc:325,345);
+ * each call binds the handle's HIP device on entry, no thread-local state.
+ */
+#ifndef URF_H_
+#define URF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URF_FEAT_ROWS 259        /* score, x, y, 256-d descriptor (src/super_point.cpp:364-384) */
+#define URF_MAX_KEYPOINTS 1024   /* TensorRT profile cap, src/super_glue.cpp:67-68,97-98 */
+#define URF_SP_BLOB_FLOATS 1300865
+#define URF_SG_BLOB_FLOATS 12003905
+
+const char *urf_last_error(void);
+int urf_device_count(void);
+
+/* ------------------------------------------------------------ SuperPoint -- */
+/* SuperPointConfig, include/read_configs.h:9-18 (tensor names, dla_core and
+ * file names live in the C++ shim; they carry no meaning for this back-end). */
+typedef struct {
+  int max_keypoints;          /* <= URF_MAX_KEYPOINTS, or -1 (= cap) */
+  double keypoint_threshold;
+  int remove_borders;
+  int max_height, max_width;  /* arena is sized for these at build(); 0 -> 1500 (profile max, src/super_point.cpp:55-60) */
+  int max_batch;              /* frames per urf_sp_infer_batch call; 0 -> 1 */
+  int device;                 /* HIP device ordinal */
+} urf_sp_config;
+
+typedef struct urf_sp urf_sp;
+
+/* SuperPoint::SuperPoint + build(), src/super_point.cpp:13-102.  `blob` is the
+ * SP weight container: URF_SP_BLOB_FLOATS f32, host memory. */
+int urf_sp_create(const urf_sp_config *cfg, urf_sp **out);
+int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats);
+/* engine_file analogue (save_engine/deserialize_engine, :402-438): a packed
+ * weight file "URFW" + kind + count + f32 payload. */
+int urf_sp_build_file(urf_sp *h, const char *path);
+int urf_weights_save(const char *path, int kind /*1=SP,2=SG*/, const float *blob, size_t n_floats);
+void urf_sp_destroy(urf_sp *h);
+
+/* SuperPoint::infer(image, mask, features), src/super_point.cpp:121-156.
+ * img: u8 rows x cols, row stride `step` bytes (cv::Mat::step).  mask: NULL
+ * (cv::Mat::empty()) or u8 rows x cols, non-zero = keep, stride mstep.
+ * feat: caller buffer for a column-major 259 x cap f64 matrix
+ * (Eigen::Matrix<double,259,Dynamic> storage); *K = columns written. */
+int urf_sp_infer(urf_sp *h, const uint8_t *img, int rows, int cols, size_t step,
+                 const uint8_t *mask, size_t mstep, double *feat, int cap, int *K);
+
+/* Batch of B same-sized frames (host pointers).  feat: B matrices of 259 x cap,
+ * Kout: B counts.  One upload, one pipeline, one download. */
+int urf_sp_infer_batch(urf_sp *h, int B, const uint8_t *const *imgs, int rows, int cols,
+                       size_t step, double *feat, int cap, int *Kout);
+
+/* Device-resident variant: d_imgs = device pointer to B contiguous u8 frames
+ * (rows*cols each).  Results stay on the GPU as feature slots
+ * (urf_slot_bytes() each, layout in DESIGN.md): the SuperGlue stage and the
+ * RCCL all-gather consume them without touching the host.  Asynchronous on the
+ * handle's stream; urf_sp_sync() waits. */
+size_t urf_slot_bytes(void);
+int urf_sp_infer_device(urf_sp *h, int B, const uint8_t *d_imgs, int rows, int cols,
+                        void *d_slots);
+int urf_sp_sync(urf_sp *h);
+/* copy one slot (device) to a host 259 x cap f64 matrix (exact widening). */
+int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K);
+
+/* debug / parity taps (tests): dense tensors of the LAST single-frame call.
+ * which: 0 = post-NMS scores [Hs][Ws], 1 = pre-NMS heat map [Hs][Ws],
+ * 2 = dense descriptors [Hc][Wc][256], 100+i = conv i output (NHWC). */
+int urf_sp_debug_tensor(urf_sp *h, int which, float *out, size_t n_floats);
+
+/* ---------------------------------------------- SuperGlue / PointMatching -- */
+/* SuperGlueConfig, include/read_configs.h:20-29 */
+typedef struct {
+  int image_width, image_height;
+  double matching_threshold;
+  int sinkhorn_iterations;    /* 0 -> 100 (src/super_glue.cpp:463) */
+  int max_pairs;              /* pairs per batched call; 0 -> 1 */
+  int device;
+  /* outlier stage: EpipolarGeometry(K, sigma=1.0, iterations=200), src/tracking.cc:52-55 */
+  int ransac_iterations;      /* 0 -> 200 */
+  float ransac_sigma;         /* 0 -> 1.0 */
+  uint32_t ransac_seed;
+} urf_sg_config;
+
+typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
+
+typedef struct urf_pm urf_pm;
+
+/* PointMatching::PointMatching -> SuperGlue::build, src/point_matching.cc:6-12,
+ * src/super_glue.cpp:21-147.  blob: SG weight container, host memory. */
+int urf_pm_create(const urf_sg_config *cfg, urf_pm **out);
+int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats);
+int urf_pm_build_file(urf_pm *h, const char *path);
+void urf_pm_destroy(urf_pm *h);
+
+/* PointMatching::NormalizeKeypoints, src/point_matching.cc:63-76 (host, f64). */
+void urf_normalize_keypoints(const double *feat, int n, int width, int height, double *out);
+
+/* SuperGlue::infer(features0, features1, indices0, indices1, mscores0,
+ * mscores1), src/super_glue.cpp:166-241.  f0/f1: column-major 259 x n f64 with
+ * ALREADY normalised keypoints.  Zout: optional (n0+1)x(n1+1) f32
+ * log-assignment (the TensorRT output tensor). */
+int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f1, int n1,
+                 int *idx0, int *idx1, double *ms0, double *ms1, float *Zout);
+
+/* PointMatching::MatchingPoints(features0, features1, matches,
+ * outlier_rejection), src/point_matching.cc:14-61.  Returns the match count
+ * (>=0) or <0 on error.  The cv::findFundamentalMat call (:50) is replaced by
+ * the in-tree 8-point RANSAC of src/epipolar_geometry.cc:161-205. */
+int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, int n1,
+              int outlier_rejection, urf_dmatch *out, int cap);
+
+/* Device-resident batch: pair p matches slot a[p] against slot b[p] (device
+ * slot pointers).  out: P x cap matches, nout: P counts (host). */
+int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1,
+                     int outlier_rejection, urf_dmatch *out, int cap, int *nout);
+/* same, asynchronous: results stay in the handle until urf_pm_fetch(). */
+int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0,
+                           const void *const *d_slots1, int outlier_rejection);
+int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
+int urf_pm_sync(urf_pm *h);
+
+/* EpipolarGeometry::_find_F, src/epipolar_geometry.cc:161-205: 8-point RANSAC
+ * on n pixel correspondences (host arrays of x,y pairs).  Returns 0;
+ * *score = best score, inliers n bytes, F21 9 floats row-major. */
+int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n,
+                      uint8_t *inliers, float *F21, float *score);
+
+/* ------------------------------------------------ kernel timing (bench) ---- */
+/* HIP-event timing of the pipeline stages on the handle's own stream. */
+int urf_sp_stage_ms(urf_sp *h, float *ms, int n);   /* ms[i]: last call's stage times */
+int urf_pm_stage_ms(urf_pm *h, float *ms, int n);
+int urf_set_profiling(int enable);
+
+/* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
+int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
+int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);
+int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

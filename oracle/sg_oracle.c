@@ -88,16 +88,21 @@ static void linear(const float *X, int n, int cin, const float *W, const float *
 
 /* multi-head attention message, canonical order:
  *   s_ij = (chain_d fma(q_id,k_jd,0)) * 0.125 ; m_i = max_j ; p_ij = exp_c(s_ij-m_i)
- *   l_i = sequential sum_j p_ij ; o_id = (chain_j fma(p_ij, v_jd, 0)) / l_i      */
+ *   keys are visited in 16-blocks; inside a block in the order 4j+r for r=0..3,
+ *   j=0..3 (0,4,8,12,1,5,...): the order in which an MFMA accumulator tile is
+ *   consumed as the next MFMA's operand.
+ *   l_i = (P0+P1)+(P2+P3), P_g = seq_{t,r} p[16t+4g+r]
+ *   o_id = (chain_{t,r,j} fma(p[16t+4j+r], v[16t+4j+r][d], 0)) / l_i             */
 static void attention(const float *q, int nq, const float *k, const float *v, int ns,
                       float *o) {
+  const int nblk = (ns + 15) / 16;
   for (int h = 0; h < HEADS; ++h) {
     float *kt = (float *)malloc((size_t)DH * ns * sizeof(float));
     for (int j = 0; j < ns; ++j)
       for (int d = 0; d < DH; ++d) kt[(size_t)d * ns + j] = k[(size_t)j * D + h * DH + d];
 #pragma omp parallel
     {
-      float *s = (float *)malloc((size_t)ns * sizeof(float));
+      float *s = (float *)malloc((size_t)nblk * 16 * sizeof(float));
 #pragma omp for schedule(static)
       for (int i = 0; i < nq; ++i) {
         const float *qi = q + (size_t)i * D + h * DH;
@@ -110,16 +115,25 @@ static void attention(const float *q, int nq, const float *k, const float *v, in
         }
         float m = -FLT_MAX;
         for (int j = 0; j < ns; ++j) { s[j] = s[j] * 0.125f; m = s[j] > m ? s[j] : m; }
-        float l = 0.0f;
+        for (int j = 0; j < ns; ++j) s[j] = om_exp(s[j] - m);
+        for (int j = ns; j < nblk * 16; ++j) s[j] = 0.0f;
+        float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < nblk; ++t)
+          for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) P[g] = P[g] + s[16 * t + 4 * g + r];
+        const float l = (P[0] + P[1]) + (P[2] + P[3]);
         float acc[DH];
         for (int d = 0; d < DH; ++d) acc[d] = 0.0f;
-        for (int j = 0; j < ns; ++j) {
-          const float p = om_exp(s[j] - m);
-          l = l + p;
-          const float *vr = v + (size_t)j * D + h * DH;
+        for (int t = 0; t < nblk; ++t)
+          for (int r = 0; r < 4; ++r)
+            for (int j4 = 0; j4 < 4; ++j4) {
+              const int key = 16 * t + 4 * j4 + r;
+              if (key >= ns) continue;
+              const float p = s[key];
+              const float *vr = v + (size_t)key * D + h * DH;
 #pragma omp simd
-          for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(p, vr[d], acc[d]);
-        }
+              for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(p, vr[d], acc[d]);
+            }
         for (int d = 0; d < DH; ++d) o[(size_t)i * D + h * DH + d] = acc[d] / l;
       }
       free(s);

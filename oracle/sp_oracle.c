@@ -2,8 +2,9 @@
  * Follows superpoint/SP/model.py:15-26,55-86 (network + in-graph NMS) and
  * src/super_point.cpp:158-386 (input conversion + host post-processing) of the
  * UR-MVO reference.  Arithmetic order is the canonical order of DESIGN.md:
- * every convolution output is ONE fp32 fma chain  acc=bias; for tap(ky,kx);
- * for c: acc=fma(in,w,acc)  (zero padding feeds exact zeros).
+ * every convolution output is ONE fp32 fma chain  acc=bias; for 64-channel
+ * chunk; for tap(ky,kx); for c in chunk: acc=fma(in,w,acc)  (zero padding feeds
+ * exact zeros).
  */
 #include "urf_oracle.h"
 #include "oracle_math.h"
@@ -60,39 +61,43 @@ static void conv_nhwc(const float *in, int H, int W, int Cin, const float *w,
         float acc[PB][OB];
         for (int p = 0; p < PB; ++p)
           for (int o = 0; o < OB; ++o) acc[p][o] = (o < no) ? b[o0 + o] : 0.0f;
-        if (no == OB && np == PB) {
-          for (int ky = 0; ky < k; ++ky)
-            for (int kx = 0; kx < k; ++kx) {
-              const float *wp = w + (size_t)(ky * k + kx) * Cin * Cout + o0;
-              const float *ip = pin + ((size_t)(y + ky) * Wp + (x0 + kx)) * Cin;
-              for (int c = 0; c < Cin; ++c) {
-                const float *wr = wp + (size_t)c * Cout;
-                const float a0 = ip[c], a1 = ip[Cin + c], a2 = ip[2 * Cin + c],
-                            a3 = ip[3 * Cin + c];
-#pragma omp simd
-                for (int o = 0; o < OB; ++o) {
-                  const float wv = wr[o];
-                  acc[0][o] = __builtin_fmaf(a0, wv, acc[0][o]);
-                  acc[1][o] = __builtin_fmaf(a1, wv, acc[1][o]);
-                  acc[2][o] = __builtin_fmaf(a2, wv, acc[2][o]);
-                  acc[3][o] = __builtin_fmaf(a3, wv, acc[3][o]);
-                }
-              }
-            }
-        } else {
-          for (int ky = 0; ky < k; ++ky)
-            for (int kx = 0; kx < k; ++kx) {
-              const float *wp = w + (size_t)(ky * k + kx) * Cin * Cout + o0;
-              for (int p = 0; p < np; ++p) {
-                const float *ip = pin + ((size_t)(y + ky) * Wp + (x0 + p + kx)) * Cin;
-                for (int c = 0; c < Cin; ++c) {
-                  const float a = ip[c];
+        /* canonical order: 64-channel chunk -> tap -> channel */
+        for (int c0 = 0; c0 < Cin; c0 += 64) {
+          const int c1 = (c0 + 64 < Cin) ? c0 + 64 : Cin;
+          if (no == OB && np == PB) {
+            for (int ky = 0; ky < k; ++ky)
+              for (int kx = 0; kx < k; ++kx) {
+                const float *wp = w + (size_t)(ky * k + kx) * Cin * Cout + o0;
+                const float *ip = pin + ((size_t)(y + ky) * Wp + (x0 + kx)) * Cin;
+                for (int c = c0; c < c1; ++c) {
                   const float *wr = wp + (size_t)c * Cout;
-                  for (int o = 0; o < no; ++o)
-                    acc[p][o] = __builtin_fmaf(a, wr[o], acc[p][o]);
+                  const float a0 = ip[c], a1 = ip[Cin + c], a2 = ip[2 * Cin + c],
+                              a3 = ip[3 * Cin + c];
+#pragma omp simd
+                  for (int o = 0; o < OB; ++o) {
+                    const float wv = wr[o];
+                    acc[0][o] = __builtin_fmaf(a0, wv, acc[0][o]);
+                    acc[1][o] = __builtin_fmaf(a1, wv, acc[1][o]);
+                    acc[2][o] = __builtin_fmaf(a2, wv, acc[2][o]);
+                    acc[3][o] = __builtin_fmaf(a3, wv, acc[3][o]);
+                  }
                 }
               }
-            }
+          } else {
+            for (int ky = 0; ky < k; ++ky)
+              for (int kx = 0; kx < k; ++kx) {
+                const float *wp = w + (size_t)(ky * k + kx) * Cin * Cout + o0;
+                for (int p = 0; p < np; ++p) {
+                  const float *ip = pin + ((size_t)(y + ky) * Wp + (x0 + p + kx)) * Cin;
+                  for (int c = c0; c < c1; ++c) {
+                    const float a = ip[c];
+                    const float *wr = wp + (size_t)c * Cout;
+                    for (int o = 0; o < no; ++o)
+                      acc[p][o] = __builtin_fmaf(a, wr[o], acc[p][o]);
+                  }
+                }
+              }
+          }
         }
         for (int p = 0; p < np; ++p) {
           float *op = out + ((size_t)y * W + x0 + p) * Cout + o0;

@@ -1,0 +1,76 @@
+"""ctypes loader of liburf_front.so (the HIP product library).
+
+Fails loudly when the library is missing or does not export the C ABI declared
+in include/urf.h: there is no CPU or eager fallback in the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liburf_front.so")
+
+# every symbol include/urf.h declares
+SYMBOLS = [
+    "urf_last_error", "urf_device_count", "urf_sp_create", "urf_sp_build", "urf_sp_build_file",
+    "urf_weights_save", "urf_sp_destroy", "urf_sp_infer", "urf_sp_infer_batch", "urf_slot_bytes",
+    "urf_sp_infer_device", "urf_sp_sync", "urf_slot_to_host", "urf_sp_debug_tensor", "urf_pm_create",
+    "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
+    "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_sync",
+    "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
+    "urf_probe_math", "urf_probe_divsqrt",
+]
+
+
+class SPConfig(C.Structure):
+    _fields_ = [("max_keypoints", C.c_int), ("keypoint_threshold", C.c_double), ("remove_borders", C.c_int),
+                ("max_height", C.c_int), ("max_width", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+
+
+class SGConfig(C.Structure):
+    _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("matching_threshold", C.c_double),
+                ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
+                ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32)]
+
+
+class DMatch(C.Structure):
+    _fields_ = [("queryIdx", C.c_int), ("trainIdx", C.c_int), ("distance", C.c_float)]
+
+
+def build(force=False):
+    """compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python __graft_entry__.py` or `make -C ur-mvo_amd/csrc`. "
+                "The front-end has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        missing = [s for s in SYMBOLS if not hasattr(L, s)]
+        if missing:
+            raise RuntimeError(f"liburf_front.so lacks C-ABI symbols: {missing}")
+        L.urf_last_error.restype = C.c_char_p
+        L.urf_slot_bytes.restype = C.c_size_t
+        L.urf_normalize_keypoints.restype = None
+        L.urf_sp_destroy.restype = None
+        L.urf_pm_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().urf_last_error().decode()}")
+    return rc

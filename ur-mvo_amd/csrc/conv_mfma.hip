@@ -1,0 +1,281 @@
+// conv_mfma.hip -- 3x3 convolution / linear layer as implicit GEMM on the
+// gfx950 fp32 matrix core (v_mfma_f32_16x16x4_f32), exact fp32.
+//
+// Replaces the convolution / fully-connected nodes of the two TensorRT engines
+// the reference executes (src/super_point.cpp:147, src/super_glue.cpp:227); the
+// layer list is superpoint/SP/model.py:35-53 and SURVEY.md App. C.
+//
+// Tile: one 256-thread workgroup (4 waves) = 8x16 output pixels (TAPS==9) or
+// 128 rows (TAPS==1) x 64 output channels.  Wave w owns rows 2w,2w+1 of the
+// tile (two 16-pixel MFMA column blocks) x 4 blocks of 16 channels = 8
+// accumulators.  M = output channel (A = weights from LDS), N = pixel (B =
+// activations from LDS): a lane ends up with 4 consecutive channels of one
+// pixel -> one 16-byte NHWC store.
+//
+// LDS: input tile [(8+2)*(16+2)][66] f32 (stride 66: the 32 lanes of a half
+// wave hit 32 distinct banks), weights [64][80] f32 (stride 80 likewise).
+// Accumulation order: acc=bias; for 64-ch chunk; for tap; for c.
+#include "urf_common.h"
+
+namespace urf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 16;
+constexpr int IN_STRIDE = 66;
+constexpr int W_STRIDE = 80;
+
+template <int TAPS, bool POOL, bool FUSE1A>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PH = (TAPS == 9) ? TH + 2 : TH;
+  constexpr int PW = (TAPS == 9) ? TW + 2 : TW;
+  float *in_tile = smem;                          // [PH*PW][IN_STRIDE]
+  float *w_tile = smem + PH * PW * IN_STRIDE;     // [64][W_STRIDE]  (offset is a multiple of 4 floats)
+  float *patch = w_tile + 64 * W_STRIDE;          // FUSE1A: [12][20]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  const int cout_base = blockIdx.y * 64;
+
+  int y0 = 0, x0 = 0;
+  if (TAPS == 9) {
+    const int tiles_x = (a.W + TW - 1) / TW;
+    y0 = (blockIdx.x / tiles_x) * TH;
+    x0 = (blockIdx.x % tiles_x) * TW;
+  } else {
+    x0 = blockIdx.x * (TH * TW);
+    if (a.counts && x0 >= a.counts[b]) return;  // rows beyond this item's count
+  }
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cout_base + m * 16 + 4 * g + r;
+      bv[r] = co < a.Cout ? a.bias[co] : 0.0f;
+    }
+    acc[m][0] = bv;
+    acc[m][1] = bv;
+  }
+
+  // B-operand base addresses (pixel part) for this lane's two pixel blocks
+  int bpix[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (TAPS == 9) bpix[r] = ((2 * wave + r) * PW + px) * IN_STRIDE + g;
+    else bpix[r] = ((2 * wave + r) * TW + px) * IN_STRIDE + g;
+  }
+  const int aoff = g * W_STRIDE + px;
+
+  const int nchunks = FUSE1A ? 1 : (a.Cin + 63) / 64;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * 64;
+    const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
+    __syncthreads();  // previous chunk fully consumed
+    if (FUSE1A) {
+      // ---- fused conv1a: u8 patch -> f32 -> 3x3 conv (VALU fma chain) -> relu
+      const uint8_t *img = (const uint8_t *)a.in + (size_t)b * a.in_bstride;
+      for (int i = tid; i < 12 * 20; i += 256) {
+        const int yy = y0 - 2 + i / 20, xx = x0 - 2 + i % 20;
+        float v = 0.0f;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = a.lut[img[(size_t)yy * a.W + xx]];
+        patch[i] = v;
+      }
+      const int c = tid & 63;
+      float w1[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w1[t] = a.w1a[t * 64 + c];
+      const float b1 = a.b1a[c];
+      __syncthreads();
+      for (int p = tid >> 6; p < PH * PW; p += 4) {
+        const int py = p / PW, pxx = p % PW;
+        const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+        float v = 0.0f;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          v = b1;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) v = __builtin_fmaf(patch[(py + t / 3) * 20 + pxx + t % 3], w1[t], v);
+          v = v > 0.0f ? v : 0.0f;
+        }
+        in_tile[p * IN_STRIDE + c] = v;
+      }
+    } else {
+      // ---- stage the input tile chunk: each pixel's kc channels are contiguous
+      const int vec_per_pix = kc >> 2;  // float4 per pixel
+      const int total = PH * PW * vec_per_pix;
+      for (int i = tid; i < total; i += 256) {
+        const int p = i / vec_per_pix, j = i - p * vec_per_pix;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int cc = c0 + 4 * j;
+        if (TAPS == 9) {
+          const int yy = y0 - 1 + p / PW, xx = x0 - 1 + p % PW;
+          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+            const float *src = (const float *)a.in + (size_t)b * a.in_bstride +
+                               ((size_t)yy * a.W + xx) * a.in_ld + a.in_coff + cc;
+            v = *(const f32x4 *)src;
+          }
+        } else {
+          const int row = x0 + p;
+          if (row < a.W) {
+            const float *src;
+            if (a.in2 && cc >= a.Cin1)
+              src = a.in2 + (size_t)b * a.in2_bstride + (size_t)row * a.in2_ld + a.in2_coff + (cc - a.Cin1);
+            else
+              src = (const float *)a.in + (size_t)b * a.in_bstride + (size_t)row * a.in_ld + a.in_coff + cc;
+            v = *(const f32x4 *)src;
+          }
+        }
+        float *dst = in_tile + p * IN_STRIDE + 4 * j;  // 8-byte aligned
+        *(float2 *)dst = make_float2(v[0], v[1]);
+        *(float2 *)(dst + 2) = make_float2(v[2], v[3]);
+      }
+    }
+
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (tap > 0) __syncthreads();  // w_tile free again
+      // ---- stage weights [kc][64] of this (chunk, tap)
+      {
+        const float *wsrc = a.w + ((size_t)tap * a.Cin + c0) * a.Cout;
+        for (int i = tid; i < kc * 16; i += 256) {
+          const int k = i >> 4, j = i & 15;
+          const int co = cout_base + 4 * j;
+          f32x4 v;
+          const float *s = wsrc + (size_t)k * a.Cout + co;
+          if (co + 3 < a.Cout && ((a.Cout & 3) == 0)) {
+            v = *(const f32x4 *)s;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (co + r < a.Cout) ? s[r] : 0.0f;
+          }
+          *(f32x4 *)(w_tile + k * W_STRIDE + 4 * j) = v;
+        }
+      }
+      __syncthreads();
+      const int toff = (TAPS == 9) ? ((tap / 3) * PW + (tap % 3)) * IN_STRIDE : 0;
+      const float *bp0 = in_tile + bpix[0] + toff;
+      const float *bp1 = in_tile + bpix[1] + toff;
+      const float *ap = w_tile + aoff;
+#pragma unroll 4
+      for (int k = 0; k < kc; k += 4) {
+        const float b0 = bp0[k], b1 = bp1[k];
+        const float a0 = ap[k * W_STRIDE], a1 = ap[k * W_STRIDE + 16], a2 = ap[k * W_STRIDE + 32],
+                    a3 = ap[k * W_STRIDE + 48];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, acc[2][0], 0, 0, 0);
+        acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b0, acc[3][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, acc[2][1], 0, 0, 0);
+        acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b1, acc[3][1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  float *outb = a.out + (size_t)b * a.out_bstride;
+  if (POOL) {
+    // 2x2 max pool (model.py:34): rows 2w,2w+1 live in this wave, the x pair in
+    // lanes px, px^1.  max is exact and order independent; relu commutes.
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    const int oy = (y0 >> 1) + wave, ox = (x0 + px) >> 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = fmaxf(acc[m][0][r], acc[m][1][r]);
+        t = fmaxf(t, __shfl_xor(t, 1, 64));
+        if (a.relu) t = t > 0.0f ? t : 0.0f;
+        v[r] = t;
+      }
+      const int co = cout_base + m * 16 + 4 * g;
+      if ((px & 1) == 0 && oy < Ho && ox < Wo && co < a.Cout)
+        *(f32x4 *)(outb + ((size_t)oy * Wo + ox) * a.out_ld + a.out_coff + co) = v;
+    }
+  } else {
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      size_t pix;
+      bool ok;
+      if (TAPS == 9) {
+        const int yy = y0 + 2 * wave + r2, xx = x0 + px;
+        ok = yy < a.H && xx < a.W;
+        pix = (size_t)yy * a.W + xx;
+      } else {
+        const int row = x0 + (2 * wave + r2) * TW + px;
+        ok = row < a.W;
+        pix = row;
+      }
+      if (!ok) continue;
+      const float *resb = a.res ? a.res + (size_t)b * a.res_bstride + pix * a.res_ld + a.res_coff : nullptr;
+      float *op = outb + pix * a.out_ld + a.out_coff;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int co = cout_base + m * 16 + 4 * g;
+        f32x4 v = acc[m][r2];
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+        }
+        if (co + 3 < a.Cout) {
+          if (resb) {
+            const f32x4 rv = *(const f32x4 *)(resb + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rv[r] + v[r];
+          }
+          *(f32x4 *)(op + co) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < a.Cout) op[co + r] = resb ? resb[co + r] + v[r] : v[r];
+        }
+      }
+    }
+  }
+}
+
+static size_t conv_lds_bytes(int taps, bool fuse) {
+  const int PH = taps == 9 ? TH + 2 : TH, PW = taps == 9 ? TW + 2 : TW;
+  return sizeof(float) * ((size_t)PH * PW * IN_STRIDE + 64 * W_STRIDE + (fuse ? 12 * 20 : 0));
+}
+
+// host launcher.  batch = grid.z
+int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st) {
+  dim3 grid, block(256);
+  if (taps == 9) {
+    grid.x = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+  } else {
+    grid.x = (a.W + TH * TW - 1) / (TH * TW);
+  }
+  grid.y = (a.Cout + 63) / 64;
+  grid.z = batch;
+  const size_t lds = conv_lds_bytes(taps, fuse1a);
+  static bool attr_done = false;
+  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+    const int mx = 72 * 1024;
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    attr_done = true;
+  }
+  if (taps == 9 && fuse1a && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, true>), grid, block, lds, st, a);
+  } else if (taps == 9 && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, false>), grid, block, lds, st, a);
+  } else if (taps == 9) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, false, false>), grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_mfma_kernel<1, false, false>), grid, block, lds, st, a);
+  }
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace urf

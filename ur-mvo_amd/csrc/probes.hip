@@ -1,0 +1,94 @@
+// probes.hip -- micro-probes behind the C ABI used by the GPU parity tests:
+// (1) the MFMA fma-chain GEMM (is v_mfma_f32_16x16x4_f32 bit-for-bit a k-ordered
+//     fmaf chain?), (2) the canonical exp/log/sqrt/div on the device.
+#include "../../include/urf.h"
+#include "urf_common.h"
+#include "urf_math.h"
+
+namespace urf {
+int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
+
+__global__ void probe_math_kernel(const float *x, int n, float *e, float *l) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  e[i] = exp_c(x[i]);
+  const float ax = fabsf(x[i]) + 1.17549435e-38f;
+  l[i] = log_c(ax);
+}
+// sqrt / divide of f32 and f64 (IEEE correctly rounded is assumed by DESIGN.md)
+__global__ void probe_divsqrt_kernel(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  q[i] = a[i] / b[i];
+  s[i] = __builtin_sqrtf(fabsf(a[i]));
+  qd[i] = (double)a[i] / (double)b[i];
+  sd[i] = sqrt(fabs((double)a[i] * (double)b[i]));
+}
+}  // namespace urf
+using namespace urf;
+
+// C[m][n] = chain_k fma(A[m][k], B[k][n], bias[n])   (bias may be null -> 0)
+extern "C" int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C,
+                                  int device) {
+  URF_CHECK(A && B && C && (K % 4) == 0 && (N % 4) == 0 && M > 0, "probe_fma_gemm: need K%%4==0, N%%4==0");
+  URF_HIP(hipSetDevice(device));
+  float *dA, *dB, *db, *dC;
+  URF_HIP(hipMalloc((void **)&dA, (size_t)M * K * 4));
+  URF_HIP(hipMalloc((void **)&dB, (size_t)K * N * 4));
+  URF_HIP(hipMalloc((void **)&db, (size_t)N * 4));
+  URF_HIP(hipMalloc((void **)&dC, (size_t)M * N * 4));
+  URF_HIP(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+  URF_HIP(hipMemcpy(dB, B, (size_t)K * N * 4, hipMemcpyHostToDevice));
+  if (bias) URF_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  else URF_HIP(hipMemset(db, 0, (size_t)N * 4));
+  ConvArgs a = {};
+  a.in = dA; a.in_ld = K; a.H = 1; a.W = M; a.Cin = K; a.w = dB; a.bias = db; a.Cout = N;
+  a.out = dC; a.out_ld = N;
+  int rc = launch_conv(a, 1, false, false, 1, 0);
+  if (rc == 0) {
+    URF_HIP(hipDeviceSynchronize());
+    URF_HIP(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(db); (void)hipFree(dC);
+  return rc;
+}
+
+extern "C" int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device) {
+  URF_CHECK(x && exp_out && log_out && n > 0, "probe_math: bad argument");
+  URF_HIP(hipSetDevice(device));
+  float *dx, *de, *dl;
+  URF_HIP(hipMalloc((void **)&dx, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&de, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&dl, (size_t)n * 4));
+  URF_HIP(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(probe_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, de, dl);
+  URF_HIP(hipDeviceSynchronize());
+  URF_HIP(hipMemcpy(exp_out, de, (size_t)n * 4, hipMemcpyDeviceToHost));
+  URF_HIP(hipMemcpy(log_out, dl, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(de); (void)hipFree(dl);
+  return 0;
+}
+
+extern "C" int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd,
+                                 int device) {
+  URF_CHECK(a && b && n > 0, "probe_divsqrt: bad argument");
+  URF_HIP(hipSetDevice(device));
+  float *da, *db, *dq, *ds;
+  double *dqd, *dsd;
+  URF_HIP(hipMalloc((void **)&da, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&db, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&dq, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&ds, (size_t)n * 4));
+  URF_HIP(hipMalloc((void **)&dqd, (size_t)n * 8));
+  URF_HIP(hipMalloc((void **)&dsd, (size_t)n * 8));
+  URF_HIP(hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+  URF_HIP(hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(probe_divsqrt_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, da, db, n, dq, ds, dqd, dsd);
+  URF_HIP(hipDeviceSynchronize());
+  URF_HIP(hipMemcpy(q, dq, (size_t)n * 4, hipMemcpyDeviceToHost));
+  URF_HIP(hipMemcpy(s, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
+  URF_HIP(hipMemcpy(qd, dqd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  URF_HIP(hipMemcpy(sd, dsd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dq); (void)hipFree(ds); (void)hipFree(dqd); (void)hipFree(dsd);
+  return 0;
+}

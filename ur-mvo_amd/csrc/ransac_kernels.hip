@@ -1,0 +1,324 @@
+// ransac_kernels.hip -- epipolar 8-point RANSAC on the GPU: the outlier stage of
+// PointMatching::MatchingPoints (src/point_matching.cc:47-58).  The reference
+// calls cv::findFundamentalMat there (OpenCV, un-vendored, unpinned); this build
+// runs the in-tree routine EpipolarGeometry::_find_F / _normalize /
+// _compute_F21 / _check_F (src/epipolar_geometry.cc:161-205,735-780,247-283,
+// 372-449) with the deviations listed in DESIGN.md "RANSAC" (counter-hash
+// sampler, Jacobi eigen-solver in double, canonical wave-order float sums).
+//
+// Kernels: normalise (1 wave per point set) -> one thread per hypothesis
+// (8-point solve, double) -> one wave per hypothesis (score all matches) ->
+// one workgroup per pair (first-best hypothesis, inlier mask, ordered compaction).
+#include "urf_common.h"
+#include "urf_math.h"
+
+namespace urf {
+
+constexpr int RNP = kCap;
+
+struct DMatchR { int queryIdx, trainIdx; float distance; };
+
+__device__ __forceinline__ uint32_t rs_hash(uint32_t seed, uint32_t ctr) {
+  uint32_t x = seed ^ (ctr * 0x9E3779B9u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+// Random::RandomInt (src/epipolar_geometry.cc:114-117), rand() -> 31-bit counter hash
+__device__ __forceinline__ int random_int(uint32_t seed, uint32_t ctr, int mn, int mx) {
+  const int d = mx - mn + 1;
+  const uint32_t r = rs_hash(seed, ctr) >> 1;
+  return (int)(((double)r / 2147483648.0) * d) + mn;
+}
+// minimal-set draw (:59-71): swap-with-back sampling via a sparse map
+__device__ void draw_set(uint32_t seed, int it, int n, int set[8]) {
+  int mpos[8], mval[8], nm = 0;
+  for (int j = 0; j < 8; ++j) {
+    const int size = n - j;
+    const int randi = random_int(seed, (uint32_t)(it * 8 + j), 0, size - 1);
+    int idx = randi, back = size - 1;
+    for (int t = 0; t < nm; ++t) if (mpos[t] == randi) idx = mval[t];
+    for (int t = 0; t < nm; ++t) if (mpos[t] == size - 1) back = mval[t];
+    set[j] = idx;
+    int found = 0;
+    for (int t = 0; t < nm; ++t) if (mpos[t] == randi) { mval[t] = back; found = 1; }
+    if (!found) { mpos[nm] = randi; mval[nm] = back; ++nm; }
+  }
+}
+
+#define JAC_SWEEPS 12
+__device__ void jacobi_sym(double *a, double *v, int n) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < JAC_SWEEPS; ++sweep) {
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = a[k * n + p], akq = a[k * n + q];
+          a[k * n + p] = c * akp - s * akq;
+          a[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = a[p * n + k], aqk = a[q * n + k];
+          a[p * n + k] = c * apk - s * aqk;
+          a[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = v[k * n + p], vkq = v[k * n + q];
+          v[k * n + p] = c * vkp - s * vkq;
+          v[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+__device__ int argmin_diag(const double *a, int n) {
+  int m = 0;
+  for (int i = 1; i < n; ++i) if (a[i * n + i] < a[m * n + m]) m = i;
+  return m;
+}
+
+// _compute_F21 (:247-283): null vector of A (8x9) via Jacobi on A^T A, rank-2
+// projection F - (F v) v^T with v the weakest right-singular vector of F.
+__device__ void compute_F21(const float *p1, const float *p2, double Fn[9]) {
+  double A[8][9];
+  for (int i = 0; i < 8; ++i) {
+    const float u1 = p1[2 * i], v1 = p1[2 * i + 1], u2 = p2[2 * i], v2 = p2[2 * i + 1];
+    A[i][0] = (double)(u2 * u1); A[i][1] = (double)(u2 * v1); A[i][2] = (double)u2;
+    A[i][3] = (double)(v2 * u1); A[i][4] = (double)(v2 * v1); A[i][5] = (double)v2;
+    A[i][6] = (double)u1;        A[i][7] = (double)v1;        A[i][8] = 1.0;
+  }
+  double ata[81], V[81];
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      double s = 0.0;
+      for (int i = 0; i < 8; ++i) s = s + A[i][r] * A[i][c];
+      ata[r * 9 + c] = s;
+    }
+  jacobi_sym(ata, V, 9);
+  const int m = argmin_diag(ata, 9);
+  double Fpre[9];
+  for (int k = 0; k < 9; ++k) Fpre[k] = V[k * 9 + m];
+  double g[9], W[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s = s + Fpre[k * 3 + r] * Fpre[k * 3 + c];
+      g[r * 3 + c] = s;
+    }
+  jacobi_sym(g, W, 3);
+  const int m3 = argmin_diag(g, 3);
+  double vv[3] = {W[0 * 3 + m3], W[1 * 3 + m3], W[2 * 3 + m3]}, fv[3];
+  for (int r = 0; r < 3; ++r)
+    fv[r] = (Fpre[r * 3 + 0] * vv[0] + Fpre[r * 3 + 1] * vv[1]) + Fpre[r * 3 + 2] * vv[2];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Fn[r * 3 + c] = Fpre[r * 3 + c] - fv[r] * vv[c];
+}
+
+__device__ void mat3_mul_f(const float *a, const float *b, float *o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      o[i * 3 + j] = (a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j]) + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+__device__ __forceinline__ float wave_sum_strided(const float *x, int stride, int n, int lane) {
+  float a = 0.0f;
+  for (int i = lane; i < n; i += 64) a = a + x[(size_t)i * stride];
+  return bfly64_sum(a);
+}
+
+// _normalize (:735-780); wave 0 = image 1 points, wave 1 = image 2 points
+__global__ void __launch_bounds__(128) ransac_normalize_kernel(const int *nmatch, const float *pts0,
+                                                               const float *pts1, float *pn0, float *pn1,
+                                                               float *T /*[P][2][9]*/) {
+  const int p = blockIdx.x, which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = nmatch[p];
+  if (n < 8) return;
+  const float *pts = (which ? pts1 : pts0) + (size_t)p * RNP * 2;
+  float *pn = (which ? pn1 : pn0) + (size_t)p * RNP * 2;
+  const float meanX = wave_sum_strided(pts, 2, n, lane) / (float)n;
+  const float meanY = wave_sum_strided(pts + 1, 2, n, lane) / (float)n;
+  float ax = 0.0f, ay = 0.0f;
+  for (int i = lane; i < n; i += 64) {
+    const float dx = pts[2 * i] - meanX, dy = pts[2 * i + 1] - meanY;
+    pn[2 * i] = dx; pn[2 * i + 1] = dy;
+    ax = ax + fabsf(dx); ay = ay + fabsf(dy);
+  }
+  const float meanDevX = bfly64_sum(ax) / (float)n, meanDevY = bfly64_sum(ay) / (float)n;
+  const float sX = (float)(1.0 / (double)meanDevX), sY = (float)(1.0 / (double)meanDevY);
+  for (int i = lane; i < n; i += 64) { pn[2 * i] = pn[2 * i] * sX; pn[2 * i + 1] = pn[2 * i + 1] * sY; }
+  if (lane == 0) {
+    float *t = T + ((size_t)p * 2 + which) * 9;
+    for (int k = 0; k < 9; ++k) t[k] = 0.0f;
+    t[0] = sX; t[4] = sY; t[2] = -meanX * sX; t[5] = -meanY * sY; t[8] = 1.0f;
+  }
+}
+
+__global__ void __launch_bounds__(64) ransac_hyp_kernel(const int *nmatch, const float *pn0, const float *pn1,
+                                                        const float *T, uint32_t seed, int iters,
+                                                        float *F /*[P][iters][9]*/) {
+  const int p = blockIdx.y, it = blockIdx.x * 64 + threadIdx.x;
+  const int n = nmatch[p];
+  if (it >= iters || n < 8) return;
+  int set[8];
+  draw_set(seed, it, n, set);
+  float a[16], b[16];
+  const float *q0 = pn0 + (size_t)p * RNP * 2, *q1 = pn1 + (size_t)p * RNP * 2;
+  for (int j = 0; j < 8; ++j) {
+    a[2 * j] = q0[2 * set[j]]; a[2 * j + 1] = q0[2 * set[j] + 1];
+    b[2 * j] = q1[2 * set[j]]; b[2 * j + 1] = q1[2 * set[j] + 1];
+  }
+  double Fn[9];
+  compute_F21(a, b, Fn);
+  float Fnf[9], M[9], T2t[9];
+  const float *T1 = T + ((size_t)p * 2) * 9, *T2 = T1 + 9;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2t[i * 3 + j] = T2[j * 3 + i];
+  for (int k = 0; k < 9; ++k) Fnf[k] = (float)Fn[k];
+  mat3_mul_f(T2t, Fnf, M);
+  float out[9];
+  mat3_mul_f(M, T1, out);
+  float *fo = F + ((size_t)p * iters + it) * 9;
+  for (int k = 0; k < 9; ++k) fo[k] = out[k];
+}
+
+// per-match chi-square terms of _check_F (:372-449)
+__device__ __forceinline__ bool check_pair(const float *F, float u1, float v1, float u2, float v2,
+                                           float invSigmaSquare, float &score) {
+  const float th = 3.841f, thScore = 5.991f;
+  bool bIn = true;
+  const float a2 = (F[0] * u1 + F[1] * v1) + F[2];
+  const float b2 = (F[3] * u1 + F[4] * v1) + F[5];
+  const float c2 = (F[6] * u1 + F[7] * v1) + F[8];
+  const float num2 = (a2 * u2 + b2 * v2) + c2;
+  const float squareDist1 = (num2 * num2) / (a2 * a2 + b2 * b2);
+  const float chiSquare1 = squareDist1 * invSigmaSquare;
+  if (chiSquare1 > th) bIn = false; else score = score + (thScore - chiSquare1);
+  const float a1 = (F[0] * u2 + F[3] * v2) + F[6];
+  const float b1 = (F[1] * u2 + F[4] * v2) + F[7];
+  const float c1 = (F[2] * u2 + F[5] * v2) + F[8];
+  const float num1 = (a1 * u1 + b1 * v1) + c1;
+  const float squareDist2 = (num1 * num1) / (a1 * a1 + b1 * b1);
+  const float chiSquare2 = squareDist2 * invSigmaSquare;
+  if (chiSquare2 > th) bIn = false; else score = score + (thScore - chiSquare2);
+  return bIn;
+}
+
+__global__ void __launch_bounds__(256) ransac_score_kernel(const int *nmatch, const float *pts0, const float *pts1,
+                                                           const float *F, float sigma, int iters, float *score) {
+  const int p = blockIdx.y, it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = nmatch[p];
+  if (it >= iters || n < 8) return;
+  const float *f = F + ((size_t)p * iters + it) * 9;
+  float Fl[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Fl[k] = f[k];
+  const float invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));
+  const float *q0 = pts0 + (size_t)p * RNP * 2, *q1 = pts1 + (size_t)p * RNP * 2;
+  float sc = 0.0f;
+  for (int i = lane; i < n; i += 64) check_pair(Fl, q0[2 * i], q0[2 * i + 1], q1[2 * i], q1[2 * i + 1], invSigmaSquare, sc);
+  sc = bfly64_sum(sc);
+  if (lane == 0) score[(size_t)p * iters + it] = sc;
+}
+
+// best hypothesis (strict '>' against 0, first wins: :197-201), inlier mask,
+// ordered compaction of the match list (src/point_matching.cc:52-58).
+__global__ void __launch_bounds__(1024) ransac_select_kernel(const int *nmatch, const float *pts0, const float *pts1,
+                                                             const float *F, const float *score, float sigma,
+                                                             int iters, int enable, const DMatchR *matches,
+                                                             DMatchR *out, int *nout, uint8_t *inliers, float *Fbest,
+                                                             float *best_score) {
+  __shared__ float s_best[16];
+  __shared__ int s_bi[16];
+  __shared__ int wsum[16];
+  __shared__ float s_F[9];
+  __shared__ int s_it;
+  const int p = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
+  const int n = nmatch[p];
+  const DMatchR *mi = matches + (size_t)p * RNP;
+  DMatchR *mo = out + (size_t)p * RNP;
+  if (!enable || n < 8) {  // no rejection: fewer than 8 matches cannot seed a hypothesis
+    if (i < n) { mo[i] = mi[i]; if (inliers) inliers[(size_t)p * RNP + i] = 1; }
+    if (i == 0) { nout[p] = n; if (best_score) best_score[p] = 0.0f; }
+    if (Fbest && i < 9) Fbest[(size_t)p * 9 + i] = 0.0f;
+    return;
+  }
+  float best = 0.0f;
+  int bi = 0x7fffffff;
+  for (int it = i; it < iters; it += 1024) {
+    const float s = score[(size_t)p * iters + it];
+    if (s > best) { best = s; bi = it; }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const float ob = __shfl_xor(best, s, 64);
+    const int oi = __shfl_xor(bi, s, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { s_best[wave] = best; s_bi[wave] = bi; }
+  __syncthreads();
+  if (i == 0) {
+    float b = s_best[0];
+    int k = s_bi[0];
+    for (int w = 1; w < 16; ++w)
+      if (s_best[w] > b || (s_best[w] == b && s_bi[w] < k)) { b = s_best[w]; k = s_bi[w]; }
+    s_it = (b > 0.0f) ? k : -1;
+    if (best_score) best_score[p] = (b > 0.0f) ? b : 0.0f;
+  }
+  __syncthreads();
+  const int bit = s_it;
+  if (i < 9) {
+    const float v = bit >= 0 ? F[((size_t)p * iters + bit) * 9 + i] : 0.0f;
+    s_F[i] = v;
+    if (Fbest) Fbest[(size_t)p * 9 + i] = v;
+  }
+  __syncthreads();
+  int flag = 0;
+  if (i < n && bit >= 0) {
+    float Fl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Fl[k] = s_F[k];
+    const float invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));
+    const float *q0 = pts0 + (size_t)p * RNP * 2, *q1 = pts1 + (size_t)p * RNP * 2;
+    float dummy = 0.0f;
+    flag = check_pair(Fl, q0[2 * i], q0[2 * i + 1], q1[2 * i], q1[2 * i + 1], invSigmaSquare, dummy) ? 1 : 0;
+  }
+  if (inliers && i < n) inliers[(size_t)p * RNP + i] = (uint8_t)flag;
+  // ordered compaction
+  int incl = flag;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  if (flag) mo[base + incl - 1] = mi[i];
+  if (i == 0) nout[p] = tot;
+}
+
+int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *pn0, float *pn1, float *T, float *F,
+                  float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
+                  int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st) {
+  if (enable) {
+    hipLaunchKernelGGL(ransac_normalize_kernel, dim3(P), dim3(128), 0, st, nmatch, pts0, pts1, pn0, pn1, T);
+    hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, P), dim3(64), 0, st, nmatch, pn0, pn1, T, seed, iters,
+                       F);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, P), dim3(256), 0, st, nmatch, pts0, pts1, F, sigma,
+                       iters, score);
+  }
+  hipLaunchKernelGGL(ransac_select_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, F, score, sigma, iters,
+                     enable, (const DMatchR *)matches, (DMatchR *)out, nout, inliers, Fbest, best_score);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace urf

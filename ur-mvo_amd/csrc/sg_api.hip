@@ -1,0 +1,452 @@
+// sg_api.hip -- host side of SuperGlue + PointMatching behind the C ABI
+// (include/urf.h).  Mirrors SuperGlue::build / infer (src/super_glue.cpp:21-241)
+// and PointMatching::MatchingPoints (src/point_matching.cc:14-61): persistent
+// arena, weight repack (fused QKV), one HIP stream, batched pairs.
+#include "../../include/urf.h"
+#include "urf_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+namespace urf {
+extern int g_profiling;
+int weights_load(const char *path, int kind, std::vector<float> &out);
+int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
+int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int height, int *counts, float *kin,
+                         float *kxy, float *x, hipStream_t st);
+int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st);
+int launch_score(const float *mdesc, const int *counts, float alpha, float *C, float *Ct, float *u, float *v, int P,
+                 hipStream_t st);
+int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
+                    hipStream_t st);
+int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
+                  const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
+                  double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int P,
+                  hipStream_t st);
+int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *pn0, float *pn1, float *T, float *F,
+                  float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
+                  int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st);
+
+constexpr int NP = kCap, LDC = 1028, SG_LAYERS = 18;
+enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC, PT_COUNT };
+}  // namespace urf
+using namespace urf;
+
+struct urf_pm {
+  urf_sg_config cfg;
+  int device = 0, maxP = 1, iters = 100, r_iters = 200;
+  float r_sigma = 1.0f;
+  hipStream_t st = nullptr;
+  bool built = false;
+  float *d_w = nullptr;
+  size_t kw[5], kb[5];
+  struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2; } L[18];
+  size_t wf, bf;
+  float bin_score = 1.0f;
+  // activations
+  int *counts = nullptr;
+  float *kin = nullptr, *kxy = nullptr, *x = nullptr, *tA = nullptr, *tB = nullptr, *qkv = nullptr, *o = nullptr,
+        *msg = nullptr, *hid = nullptr, *mdesc = nullptr;
+  float *C = nullptr, *Ct = nullptr, *u = nullptr, *v = nullptr, *Z = nullptr;
+  int *mi0 = nullptr, *mi1 = nullptr, *idx0 = nullptr, *idx1 = nullptr, *nmatch = nullptr, *nfinal = nullptr;
+  float *mv0 = nullptr, *mv1 = nullptr;
+  double *ms0 = nullptr, *ms1 = nullptr;
+  urf_dmatch *matches = nullptr, *fmatches = nullptr;
+  float *pts0 = nullptr, *pts1 = nullptr, *pn0 = nullptr, *pn1 = nullptr, *T = nullptr, *F = nullptr, *score = nullptr,
+        *Fbest = nullptr, *best_score = nullptr;
+  uint8_t *inliers = nullptr;
+  const float **d_slotptrs = nullptr;
+  // pinned host
+  urf_dmatch *h_matches = nullptr;
+  int *h_n = nullptr;
+  const float **h_slotptrs = nullptr;
+  hipEvent_t ev[PT_COUNT + 1];
+  float stage_ms[PT_COUNT];
+  bool ev_valid = false;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+template <typename T>
+static int dalloc(T **p, size_t n) {
+  URF_HIP(hipMalloc((void **)p, n * sizeof(T)));
+  URF_HIP(hipMemset(*p, 0, n * sizeof(T)));
+  return 0;
+}
+
+extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
+  URF_CHECK(cfg && out, "urf_pm_create: null argument");
+  int ndev = 0;
+  URF_HIP(hipGetDeviceCount(&ndev));
+  URF_CHECK(ndev > 0, "no HIP device: liburf_front needs a gfx950 GPU (there is no CPU fallback)");
+  URF_CHECK(cfg->device >= 0 && cfg->device < ndev, "device %d out of range (%d devices)", cfg->device, ndev);
+  urf_pm *h = new urf_pm();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  h->maxP = cfg->max_pairs > 0 ? cfg->max_pairs : 1;
+  h->iters = cfg->sinkhorn_iterations > 0 ? cfg->sinkhorn_iterations : 100;
+  h->r_iters = cfg->ransac_iterations > 0 ? cfg->ransac_iterations : 200;
+  h->r_sigma = cfg->ransac_sigma > 0 ? cfg->ransac_sigma : 1.0f;
+  *out = h;
+  return 0;
+}
+
+extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
+  URF_CHECK(h && blob, "urf_pm_build: null argument");
+  URF_CHECK(n_floats == URF_SG_BLOB_FLOATS, "SG blob has %zu floats, expected %d", n_floats, URF_SG_BLOB_FLOATS);
+  URF_CHECK(!h->built, "urf_pm_build: already built");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  std::vector<float> host;
+  auto put = [&](const float *src, size_t n) {
+    size_t off = align_up(host.size(), 64);
+    host.resize(off + n, 0.0f);
+    if (src) memcpy(host.data() + off, src, n * sizeof(float));
+    return off;
+  };
+  static const int kd[6] = {3, 32, 64, 128, 256, 256};
+  const float *p = blob;
+  for (int i = 0; i < 5; ++i) {
+    if (i == 0) {  // pad cin 3 -> 4 with a zero row (fma(0,0,acc) == acc)
+      h->kw[0] = put(nullptr, 4 * 32);
+      memcpy(host.data() + h->kw[0], p, 3 * 32 * sizeof(float));
+    } else {
+      h->kw[i] = put(p, (size_t)kd[i] * kd[i + 1]);
+    }
+    p += (size_t)kd[i] * kd[i + 1];
+    h->kb[i] = put(p, kd[i + 1]);
+    p += kd[i + 1];
+  }
+  for (int l = 0; l < SG_LAYERS; ++l) {
+    const float *wq = p, *bq = wq + 65536, *wk = bq + 256, *bk = wk + 65536, *wv = bk + 256, *bv = wv + 65536;
+    const float *wm = bv + 256, *bm = wm + 65536, *w1 = bm + 256, *b1 = w1 + 262144, *w2 = b1 + 512,
+                *b2 = w2 + 131072;
+    p = b2 + 256;
+    h->L[l].wqkv = put(nullptr, (size_t)256 * 768);
+    float *d = host.data() + h->L[l].wqkv;
+    for (int c = 0; c < 256; ++c) {
+      memcpy(d + (size_t)c * 768, wq + (size_t)c * 256, 1024);
+      memcpy(d + (size_t)c * 768 + 256, wk + (size_t)c * 256, 1024);
+      memcpy(d + (size_t)c * 768 + 512, wv + (size_t)c * 256, 1024);
+    }
+    h->L[l].bqkv = put(nullptr, 768);
+    memcpy(host.data() + h->L[l].bqkv, bq, 1024);
+    memcpy(host.data() + h->L[l].bqkv + 256, bk, 1024);
+    memcpy(host.data() + h->L[l].bqkv + 512, bv, 1024);
+    h->L[l].wm = put(wm, 65536); h->L[l].bm = put(bm, 256);
+    h->L[l].w1 = put(w1, 262144); h->L[l].b1 = put(b1, 512);
+    h->L[l].w2 = put(w2, 131072); h->L[l].b2 = put(b2, 256);
+  }
+  h->wf = put(p, 65536); p += 65536;
+  h->bf = put(p, 256); p += 256;
+  h->bin_score = *p;
+  URF_HIP(hipMalloc((void **)&h->d_w, host.size() * sizeof(float)));
+  URF_HIP(hipMemcpy(h->d_w, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+
+  const size_t P = h->maxP, NI = 2 * P;
+  if (dalloc(&h->counts, NI)) return -1;
+  if (dalloc(&h->kin, NI * NP * 4)) return -1;
+  if (dalloc(&h->kxy, NI * NP * 2)) return -1;
+  if (dalloc(&h->x, NI * NP * 256)) return -1;
+  if (dalloc(&h->tA, NI * NP * 256)) return -1;
+  if (dalloc(&h->tB, NI * NP * 256)) return -1;
+  if (dalloc(&h->qkv, NI * NP * 768)) return -1;
+  if (dalloc(&h->o, NI * NP * 256)) return -1;
+  if (dalloc(&h->msg, NI * NP * 256)) return -1;
+  if (dalloc(&h->hid, NI * NP * 512)) return -1;
+  if (dalloc(&h->mdesc, NI * NP * 256)) return -1;
+  const size_t msz = (size_t)(NP + 1) * LDC;
+  if (dalloc(&h->C, P * msz)) return -1;
+  if (dalloc(&h->Ct, P * msz)) return -1;
+  if (dalloc(&h->Z, P * msz)) return -1;
+  if (dalloc(&h->u, P * LDC)) return -1;
+  if (dalloc(&h->v, P * LDC)) return -1;
+  if (dalloc(&h->mi0, P * NP)) return -1;
+  if (dalloc(&h->mi1, P * NP)) return -1;
+  if (dalloc(&h->mv0, P * NP)) return -1;
+  if (dalloc(&h->mv1, P * NP)) return -1;
+  if (dalloc(&h->idx0, P * NP)) return -1;
+  if (dalloc(&h->idx1, P * NP)) return -1;
+  if (dalloc(&h->ms0, P * NP)) return -1;
+  if (dalloc(&h->ms1, P * NP)) return -1;
+  if (dalloc(&h->matches, P * NP)) return -1;
+  if (dalloc(&h->fmatches, P * NP)) return -1;
+  if (dalloc(&h->nmatch, P)) return -1;
+  if (dalloc(&h->nfinal, P)) return -1;
+  if (dalloc(&h->pts0, P * NP * 2)) return -1;
+  if (dalloc(&h->pts1, P * NP * 2)) return -1;
+  if (dalloc(&h->pn0, P * NP * 2)) return -1;
+  if (dalloc(&h->pn1, P * NP * 2)) return -1;
+  if (dalloc(&h->T, P * 18)) return -1;
+  if (dalloc(&h->F, P * (size_t)h->r_iters * 9)) return -1;
+  if (dalloc(&h->score, P * (size_t)h->r_iters)) return -1;
+  if (dalloc(&h->Fbest, P * 9)) return -1;
+  if (dalloc(&h->best_score, P)) return -1;
+  if (dalloc(&h->inliers, P * NP)) return -1;
+  if (dalloc(&h->d_slotptrs, NI)) return -1;
+  URF_HIP(hipHostMalloc((void **)&h->h_matches, P * NP * sizeof(urf_dmatch), hipHostMallocDefault));
+  URF_HIP(hipHostMalloc((void **)&h->h_n, P * sizeof(int), hipHostMallocDefault));
+  URF_HIP(hipHostMalloc((void **)&h->h_slotptrs, NI * sizeof(float *), hipHostMallocDefault));
+  for (int i = 0; i <= PT_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
+  h->built = true;
+  return 0;
+}
+
+extern "C" int urf_pm_build_file(urf_pm *h, const char *path) {
+  std::vector<float> blob;
+  if (urf::weights_load(path, 2, blob)) return -1;
+  return urf_pm_build(h, blob.data(), blob.size());
+}
+
+extern "C" void urf_pm_destroy(urf_pm *h) {
+  if (!h) return;
+  if (h->built) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->st);
+    void *bufs[] = {h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
+                    h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
+                    h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F,
+                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs};
+    for (void *p : bufs) (void)hipFree(p);
+    (void)hipHostFree(h->h_matches);
+    (void)hipHostFree(h->h_n);
+    (void)hipHostFree((void *)h->h_slotptrs);
+    for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+    (void)hipStreamDestroy(h->st);
+  }
+  delete h;
+}
+
+// Y = act(X W + b) [+res] over all 2P images; rows beyond counts[] are skipped per tile
+static int sg_linear(urf_pm *h, int nimg, const float *in, int in_ld, int cin, const float *in2, int in2_ld, int cin1,
+                     size_t w, size_t b, int cout, float *out, int out_ld, bool relu, const float *res) {
+  ConvArgs a = {};
+  a.in = in; a.in_ld = in_ld; a.in_bstride = (long)NP * in_ld;
+  a.in2 = in2; a.in2_ld = in2_ld; a.in2_bstride = (long)NP * in2_ld; a.Cin1 = cin1;
+  a.H = 1; a.W = NP; a.Cin = cin;
+  a.w = h->d_w + w; a.bias = h->d_w + b; a.Cout = cout;
+  a.out = out; a.out_ld = out_ld; a.out_bstride = (long)NP * out_ld;
+  a.res = res; a.res_ld = out_ld; a.res_bstride = (long)NP * out_ld;
+  a.relu = relu ? 1 : 0;
+  a.counts = h->counts;
+  return launch_conv(a, 1, false, false, nimg, h->st);
+}
+
+// the whole matching pipeline for P pairs whose inputs (counts, kin, kxy, x) are in place
+static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
+  hipStream_t st = h->st;
+  const int NI = 2 * P;
+  const bool prof = urf::g_profiling != 0;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
+  mark(PT_KENC);
+  // keypoint encoder: 4(3)->32->64->128->256->256, + descriptors
+  if (sg_linear(h, NI, h->kin, 4, 4, nullptr, 0, 0, h->kw[0], h->kb[0], 32, h->tA, 256, true, nullptr)) return -1;
+  if (sg_linear(h, NI, h->tA, 256, 32, nullptr, 0, 0, h->kw[1], h->kb[1], 64, h->tB, 256, true, nullptr)) return -1;
+  if (sg_linear(h, NI, h->tB, 256, 64, nullptr, 0, 0, h->kw[2], h->kb[2], 128, h->tA, 256, true, nullptr)) return -1;
+  if (sg_linear(h, NI, h->tA, 256, 128, nullptr, 0, 0, h->kw[3], h->kb[3], 256, h->tB, 256, true, nullptr)) return -1;
+  if (sg_linear(h, NI, h->tB, 256, 256, nullptr, 0, 0, h->kw[4], h->kb[4], 256, h->x, 256, false, h->x)) return -1;
+  mark(PT_GNN);
+  for (int l = 0; l < SG_LAYERS; ++l) {
+    if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->L[l].wqkv, h->L[l].bqkv, 768, h->qkv, 768, false, nullptr))
+      return -1;
+    if (launch_attn(h->qkv, h->counts, l & 1, h->o, NI, st)) return -1;
+    if (sg_linear(h, NI, h->o, 256, 256, nullptr, 0, 0, h->L[l].wm, h->L[l].bm, 256, h->msg, 256, false, nullptr))
+      return -1;
+    if (sg_linear(h, NI, h->x, 256, 512, h->msg, 256, 256, h->L[l].w1, h->L[l].b1, 512, h->hid, 512, true, nullptr))
+      return -1;
+    if (sg_linear(h, NI, h->hid, 512, 512, nullptr, 0, 0, h->L[l].w2, h->L[l].b2, 256, h->x, 256, false, h->x))
+      return -1;
+  }
+  mark(PT_SCORE);
+  if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
+  if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
+  mark(PT_SINKHORN);
+  if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, st)) return -1;
+  mark(PT_DECODE);
+  if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
+                    h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,
+                    want_Z ? h->Z : nullptr, P, st))
+    return -1;
+  mark(PT_RANSAC);
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
+                    h->r_sigma, ransac ? 1 : 0, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest,
+                    h->best_score, P, st))
+    return -1;
+  mark(PT_COUNT);
+  return 0;
+}
+
+static void pm_collect_times(urf_pm *h) {
+  if (!urf::g_profiling) return;
+  for (int i = 0; i < PT_COUNT; ++i) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0.0f;
+    h->stage_ms[i] = ms;
+  }
+  h->ev_valid = true;
+}
+
+extern "C" void urf_normalize_keypoints(const double *feat, int n, int width, int height, double *out) {
+  if (out != feat) memcpy(out, feat, (size_t)259 * n * sizeof(double));
+  const int mx = width > height ? width : height;
+  for (int c = 0; c < n; ++c) {
+    out[(size_t)259 * c + 1] = (feat[(size_t)259 * c + 1] - width / 2) / (mx * 0.7);
+    out[(size_t)259 * c + 2] = (feat[(size_t)259 * c + 2] - height / 2) / (mx * 0.7);
+  }
+}
+
+// upload one pair given as host f64 features with NORMALISED keypoints (nf) and,
+// optionally, the pixel coordinates for the outlier stage (raw, may be null)
+static int pm_upload_pair(urf_pm *h, const double *nf0, const double *raw0, int n0, const double *nf1,
+                          const double *raw1, int n1) {
+  std::vector<float> kin((size_t)2 * NP * 4, 0.0f), kxy((size_t)2 * NP * 2, 0.0f), x((size_t)2 * NP * 256, 0.0f);
+  const double *nf[2] = {nf0, nf1}, *raw[2] = {raw0, raw1};
+  const int n[2] = {n0, n1};
+  for (int im = 0; im < 2; ++im)
+    for (int j = 0; j < n[im]; ++j) {
+      const double *col = nf[im] + (size_t)259 * j;
+      float *k = kin.data() + ((size_t)im * NP + j) * 4;
+      k[0] = (float)col[1]; k[1] = (float)col[2]; k[2] = (float)col[0];  // src/super_glue.cpp:259-275
+      if (raw[im]) {
+        kxy[((size_t)im * NP + j) * 2] = (float)raw[im][(size_t)259 * j + 1];      // cv::Point2f, point_matching.cc:39-41
+        kxy[((size_t)im * NP + j) * 2 + 1] = (float)raw[im][(size_t)259 * j + 2];
+      }
+      float *d = x.data() + ((size_t)im * NP + j) * 256;
+      for (int c = 0; c < 256; ++c) d[c] = (float)col[3 + c];                   // :277-283
+    }
+  URF_HIP(hipMemcpyAsync(h->counts, n, 2 * sizeof(int), hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->kin, kin.data(), kin.size() * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->kxy, kxy.data(), kxy.size() * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->x, x.data(), x.size() * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));  // staging vectors die with this frame
+  return 0;
+}
+
+static int pm_check(urf_pm *h, int n0, int n1) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(n0 >= 0 && n0 <= NP && n1 >= 0 && n1 <= NP, "keypoint counts (%d, %d) outside [0, %d]", n0, n1, NP);
+  return 0;
+}
+
+extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f1, int n1, int *idx0, int *idx1,
+                            double *ms0, double *ms1, float *Zout) {
+  if (pm_check(h, n0, n1)) return -2;
+  URF_CHECK(n0 >= 1 && n1 >= 1, "SuperGlue needs at least one keypoint per image (profile min, src/super_glue.cpp:63-66)");
+  URF_CHECK(f0 && f1 && idx0 && idx1 && ms0 && ms1, "urf_sg_infer: null pointer");
+  URF_HIP(hipSetDevice(h->device));
+  if (pm_upload_pair(h, f0, nullptr, n0, f1, nullptr, n1)) return -1;
+  if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
+  if (pm_pipeline(h, 1, Zout != nullptr, false)) return -1;
+  URF_HIP(hipMemcpyAsync(idx0, h->idx0, n0 * sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(idx1, h->idx1, n1 * sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(ms0, h->ms0, n0 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(ms1, h->ms1, n1 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  if (Zout)
+    URF_HIP(hipMemcpy2DAsync(Zout, (size_t)(n1 + 1) * 4, h->Z, (size_t)LDC * 4, (size_t)(n1 + 1) * 4, n0 + 1,
+                             hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));
+  pm_collect_times(h);
+  return 0;
+}
+
+extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, int n1, int outlier_rejection,
+                         urf_dmatch *out, int cap) {
+  if (pm_check(h, n0, n1)) return -2;
+  URF_CHECK(f0 && f1 && out, "urf_match: null pointer");
+  if (n0 < 1 || n1 < 1) return 0;
+  URF_HIP(hipSetDevice(h->device));
+  std::vector<double> nf0((size_t)259 * n0), nf1((size_t)259 * n1);
+  urf_normalize_keypoints(f0, n0, h->cfg.image_width, h->cfg.image_height, nf0.data());
+  urf_normalize_keypoints(f1, n1, h->cfg.image_width, h->cfg.image_height, nf1.data());
+  if (pm_upload_pair(h, nf0.data(), f0, n0, nf1.data(), f1, n1)) return -1;
+  if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
+  if (pm_pipeline(h, 1, false, outlier_rejection != 0)) return -1;
+  URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));
+  pm_collect_times(h);
+  const int n = h->h_n[0];
+  URF_CHECK(n <= cap, "match buffer too small: %d > cap %d", n, cap);
+  memcpy(out, h->h_matches, (size_t)n * sizeof(urf_dmatch));
+  return n;
+}
+
+extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1,
+                                      int outlier_rejection) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(P >= 1 && P <= h->maxP, "pairs %d outside [1, %d]", P, h->maxP);
+  URF_CHECK(d_slots0 && d_slots1, "urf_match_device: null pointer");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamSynchronize(h->st));  // the pinned pointer table may still be in flight
+  for (int p = 0; p < P; ++p) {
+    h->h_slotptrs[2 * p] = (const float *)d_slots0[p];
+    h->h_slotptrs[2 * p + 1] = (const float *)d_slots1[p];
+  }
+  if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
+  URF_HIP(hipMemcpyAsync(h->d_slotptrs, h->h_slotptrs, 2 * P * sizeof(float *), hipMemcpyHostToDevice, h->st));
+  if (launch_sg_prep_slots(h->d_slotptrs, 2 * P, h->cfg.image_width, h->cfg.image_height, h->counts, h->kin, h->kxy,
+                           h->x, h->st))
+    return -1;
+  if (pm_pipeline(h, P, false, outlier_rejection != 0)) return -1;
+  URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+  return 0;
+}
+
+extern "C" int urf_pm_sync(urf_pm *h) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamSynchronize(h->st));
+  pm_collect_times(h);
+  return 0;
+}
+
+extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
+  if (urf_pm_sync(h)) return -1;
+  URF_CHECK(P >= 1 && P <= h->maxP && out && nout, "urf_pm_fetch: bad argument");
+  for (int p = 0; p < P; ++p) {
+    const int n = h->h_n[p];
+    URF_CHECK(n >= 0 && n <= cap, "match buffer too small: %d > cap %d", n, cap);
+    nout[p] = n;
+    memcpy(out + (size_t)p * cap, h->h_matches + (size_t)p * NP, (size_t)n * sizeof(urf_dmatch));
+  }
+  return 0;
+}
+
+extern "C" int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1,
+                                int outlier_rejection, urf_dmatch *out, int cap, int *nout) {
+  int rc = urf_match_device_async(h, P, d_slots0, d_slots1, outlier_rejection);
+  if (rc) return rc;
+  return urf_pm_fetch(h, P, out, cap, nout);
+}
+
+extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n, uint8_t *inliers, float *F21,
+                                 float *score) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(pts0 && pts1 && inliers && F21 && score && n >= 0 && n <= NP, "urf_ransac_find_F: bad argument");
+  memset(inliers, 0, n);
+  for (int k = 0; k < 9; ++k) F21[k] = 0.0f;
+  *score = 0.0f;
+  if (n < 8) return 0;
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipMemcpyAsync(h->nmatch, &n, sizeof(int), hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->pts0, pts0, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->pts1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
+                    h->r_sigma, 1, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, 1, h->st))
+    return -1;
+  URF_HIP(hipMemcpyAsync(inliers, h->inliers, n, hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(F21, h->Fbest, 9 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(score, h->best_score, sizeof(float), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));
+  return 0;
+}
+
+extern "C" int urf_pm_stage_ms(urf_pm *h, float *ms, int n) {
+  URF_CHECK(h && ms, "urf_pm_stage_ms: null");
+  URF_CHECK(h->ev_valid, "no timed call yet (urf_set_profiling(1) before the call)");
+  for (int i = 0; i < n && i < PT_COUNT; ++i) ms[i] = h->stage_ms[i];
+  return PT_COUNT;
+}

@@ -1,0 +1,456 @@
+// sg_kernels.hip -- SuperGlue device kernels: input prep, multi-head attention,
+// score matrix, log-domain Sinkhorn, decode and match assembly.
+// Replaces the SuperGlue TensorRT engine (src/super_glue.cpp:227) and the host
+// decode / match assembly (src/super_glue.cpp:303-430, src/point_matching.cc:
+// 26-45).  The linear layers run on conv_mfma.hip (TAPS==1).
+//
+// All matrix products are exact-fp32 v_mfma_f32_16x16x4_f32 fma chains in the
+// canonical order of DESIGN.md; exp/log are the canonical polynomials.
+#include "urf_common.h"
+#include "urf_math.h"
+
+#include <float.h>
+
+namespace urf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NP = kCap;          // rows reserved per image
+constexpr int LDC = 1028;         // leading dimension of the couplings matrices (>= NP+1, multiple of 4)
+
+// ------------------------------------------------------------------- prep
+// From feature slots: counts, kenc input [x_n, y_n, score, 0] and descriptors.
+// NormalizeKeypoints (src/point_matching.cc:63-76) in double, narrowed like
+// SuperGlue::process_input (src/super_glue.cpp:259-275).
+__global__ void __launch_bounds__(256) sg_prep_slots_kernel(const float *const *slots, int width, int height,
+                                                            int *counts, float *kin /*[img][NP][4]*/,
+                                                            float *kxy /*[img][NP][2]*/,
+                                                            float *x /*[img][NP][256]*/) {
+  const int im = blockIdx.y;
+  const float *sl = slots[im];
+  const int n = ((const int *)sl)[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[im] = n;
+  const int mx = width > height ? width : height;
+  for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < NP; j += gridDim.x * 4) {
+    const int lane = threadIdx.x & 63;
+    f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (j < n) d = *(const f32x4 *)(sl + kSlotHeader + 4 * (size_t)kCap + (size_t)j * 256 + 4 * lane);
+    *(f32x4 *)(x + ((size_t)im * NP + j) * 256 + 4 * lane) = d;
+    if (lane == 0) {
+      f32x4 k = {0.0f, 0.0f, 0.0f, 0.0f};
+      float2 xy = make_float2(0.0f, 0.0f);
+      if (j < n) {
+        const f32x4 m = *(const f32x4 *)(sl + kSlotHeader + 4 * (size_t)j);
+        k[0] = (float)(((double)m[1] - width / 2) / (mx * 0.7));
+        k[1] = (float)(((double)m[2] - height / 2) / (mx * 0.7));
+        k[2] = m[0];
+        xy = make_float2(m[1], m[2]);
+      }
+      *(f32x4 *)(kin + ((size_t)im * NP + j) * 4) = k;
+      *(float2 *)(kxy + ((size_t)im * NP + j) * 2) = xy;
+    }
+  }
+}
+
+// -------------------------------------------------------------- attention
+// One workgroup = 64 queries x 1 head of one image; wave w = 16 queries.
+// Phase 1: S^T = K Q^T on MFMA (M = key, N = query), the whole 16 x ns score
+//   block of the wave stays in registers (64 x f32x4).
+// softmax: row max (4-lane butterfly), p = exp_c(s*0.125 - m), row sum in the
+//   canonical order P_g = seq_{t,r} p[16t+4g+r], l = (P0+P1)+(P2+P3).
+// Phase 2: O^T = V^T P^T on MFMA with the S^T accumulators used directly as the
+//   B operand (k-slot g <-> key 16t+4g+r), so the P.V chain visits the keys of
+//   each 16-block in the order 0,4,8,12,1,5,... (canonical).
+constexpr int KSTR = 66, VSTR = 68;
+
+__global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
+                                                      int cross, float *o /*[img][NP][256]*/) {
+  __shared__ __attribute__((aligned(16))) float kv[64 * VSTR];
+  const int im = blockIdx.z, sm = cross ? (im ^ 1) : im;
+  const int head = blockIdx.y;
+  const int nq = counts[im], ns = counts[sm];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= nq) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const float *qb = qkv + ((size_t)im * NP) * 768 + head * 64;
+  const float *kb = qkv + ((size_t)sm * NP) * 768 + 256 + head * 64;
+  const float *vb = qkv + ((size_t)sm * NP) * 768 + 512 + head * 64;
+
+  // Q fragment: B[k = g][col = px] = Q[q0 + 16*wave + px][4*s + g]
+  float qreg[16];
+  {
+    const float *qr = qb + (size_t)(q0 + wave * 16 + px) * 768 + g;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qreg[s] = qr[4 * s];
+  }
+  f32x4 sreg[64];
+  const int nchunk = (ns + 63) >> 6;
+  // ---------------- phase 1
+#pragma unroll
+  for (int ch = 0; ch < 16; ++ch) {
+    if (ch < nchunk) {
+      __syncthreads();
+      for (int i = tid; i < 64 * 16; i += 256) {  // stage K chunk [64 keys][64 d]
+        const int r = i >> 4, j = i & 15;
+        const int key = ch * 64 + r;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (key < ns) v = *(const f32x4 *)(kb + (size_t)key * 768 + 4 * j);
+        float *dst = kv + r * KSTR + 4 * j;
+        *(float2 *)dst = make_float2(v[0], v[1]);
+        *(float2 *)(dst + 2) = make_float2(v[2], v[3]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *ap = kv + (kt * 16 + px) * KSTR + g;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], qreg[s], acc, 0, 0, 0);
+        const int kbase = ch * 64 + kt * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (kbase + r < ns) ? acc[r] * 0.125f : -FLT_MAX;
+        sreg[ch * 4 + kt] = acc;
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) sreg[ch * 4 + kt] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    }
+  }
+  // ---------------- softmax over keys (per query = per px; 4 lanes g share it)
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int t = 0; t < 64; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, sreg[t][r]);
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float part = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    if (t * 16 < ns) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = sreg[t][r];
+        const float p = (s == -FLT_MAX) ? 0.0f : exp_c(s - m);
+        sreg[t][r] = p;
+        part = part + p;
+      }
+    }
+  }
+  float l = part + __shfl_xor(part, 16, 64);
+  l = l + __shfl_xor(l, 32, 64);
+  // ---------------- phase 2
+  f32x4 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ch = 0; ch < 16; ++ch) {
+    if (ch < nchunk) {
+      __syncthreads();
+      for (int i = tid; i < 64 * 16; i += 256) {  // stage V chunk [64 keys][64 d]
+        const int r = i >> 4, j = i & 15;
+        const int key = ch * 64 + r;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (key < ns) v = *(const f32x4 *)(vb + (size_t)key * 768 + 4 * j);
+        *(f32x4 *)(kv + r * VSTR + 4 * j) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        if ((ch * 4 + kt) * 16 < ns) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pb = sreg[ch * 4 + kt][r];
+            const float *ap = kv + (kt * 16 + 4 * g + r) * VSTR + px;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+              oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[dt * 16], pb, oacc[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  const int q = q0 + wave * 16 + px;
+  float *op = o + ((size_t)im * NP + q) * 256 + head * 64 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r] / l;
+    *(f32x4 *)(op + dt * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------ score matrix
+// S_ij = (chain_c fma(m0_ic, m1_jc, 0)) / 16 written into the couplings matrix
+// C[pair][i][j] (ld LDC) and its transpose Ct[pair][j][i].
+__global__ void __launch_bounds__(256) score_kernel(const float *mdesc /*[img][NP][256]*/, const int *counts,
+                                                    float *C, float *Ct) {
+  __shared__ __attribute__((aligned(16))) float at[64 * 66];
+  __shared__ __attribute__((aligned(16))) float bt[64 * 66];
+  const int p = blockIdx.z;
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (i0 >= n0 || j0 >= n1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const float *m0 = mdesc + ((size_t)(2 * p) * NP) * 256;
+  const float *m1 = mdesc + ((size_t)(2 * p + 1) * NP) * 256;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int c0 = 0; c0 < 256; c0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, j = i & 15;
+      const f32x4 va = *(const f32x4 *)(m0 + (size_t)(i0 + r) * 256 + c0 + 4 * j);
+      const f32x4 vb = *(const f32x4 *)(m1 + (size_t)(j0 + r) * 256 + c0 + 4 * j);
+      float *da = at + r * 66 + 4 * j, *db = bt + r * 66 + 4 * j;
+      *(float2 *)da = make_float2(va[0], va[1]); *(float2 *)(da + 2) = make_float2(va[2], va[3]);
+      *(float2 *)db = make_float2(vb[0], vb[1]); *(float2 *)(db + 2) = make_float2(vb[2], vb[3]);
+    }
+    __syncthreads();
+    const float *ap = at + (wave * 16 + px) * 66 + g;
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const float a = ap[k];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bt[(t * 16 + px) * 66 + g + k], acc[t], 0, 0, 0);
+    }
+  }
+  float *Cp = C + (size_t)p * (NP + 1) * LDC, *Ctp = Ct + (size_t)p * (NP + 1) * LDC;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + t * 16 + px;
+    const int ib = i0 + wave * 16 + 4 * g;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * 0.0625f;
+    if (j < n1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ib + r < n0) Cp[(size_t)(ib + r) * LDC + j] = v[r];
+      if (ib + 3 < n0) *(f32x4 *)(Ctp + (size_t)j * LDC + ib) = v;
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ib + r < n0) Ctp[(size_t)j * LDC + ib + r] = v[r];
+    }
+  }
+}
+
+// dustbin row/column = bin_score (src/super_glue.cpp:466-474); u = v = 0
+__global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float alpha, float *C, float *Ct, float *u,
+                                                      float *v) {
+  const int p = blockIdx.y;
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  float *Cp = C + (size_t)p * (NP + 1) * LDC, *Ctp = Ct + (size_t)p * (NP + 1) * LDC;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i <= NP; i += gridDim.x * 256) {
+    if (i <= n0) { Cp[(size_t)i * LDC + n1] = alpha; Ctp[(size_t)n1 * LDC + i] = alpha; }
+    if (i <= n1) { Cp[(size_t)n0 * LDC + i] = alpha; Ctp[(size_t)i * LDC + n0] = alpha; }
+    u[(size_t)p * LDC + i] = 0.0f;
+    v[(size_t)p * LDC + i] = 0.0f;
+  }
+}
+
+// One Sinkhorn half-iteration (src/super_glue.cpp:436-451, max-stabilised):
+//   out[r] = log_marg[r] - LSE_c( M[r][c] + add[c] ),  r < R, c < Cn
+// One wave per row; lane l holds columns l, l+64, ... (<= 17); the sum is the
+// canonical wave-strided sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
+template <bool ROWPASS>
+__global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
+                                                            float *out) {
+  const int p = blockIdx.y;
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)row * LDC;
+  const float *ad = add + (size_t)p * LDC;
+  float x[17];
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int t = 0; t < 17; ++t) {
+    const int c = lane + 64 * t;
+    x[t] = -FLT_MAX;
+    if (c < Cn) { x[t] = mr[c] + ad[c]; m = fmaxf(m, x[t]); }
+  }
+  m = bfly64_max(m);
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 17; ++t) {
+    const int c = lane + 64 * t;
+    if (c < Cn) s = s + exp_c(x[t] - m);
+  }
+  s = bfly64_sum(s);
+  if (lane == 0) {
+    const float norm = -log_c((float)(n0 + n1));
+    const int last = R - 1;
+    const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
+    out[(size_t)p * LDC + row] = lm - (m + log_c(s));
+  }
+}
+
+// ------------------------------------------------------------------ decode
+// Z_ij = ((C_ij + u_i) + v_j) - norm ; row / column argmax over the inner
+// n0 x n1 block with first-max-wins (max_matrix, src/super_glue.cpp:314-343).
+// ROWS: wave per i on C; else wave per j on Ct.  Optionally writes Z rows.
+template <bool ROWS>
+__global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const float *M, const float *u, const float *v,
+                                                     int *midx, float *mval, float *Zout) {
+  const int p = blockIdx.y;
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const int R = ROWS ? n0 : n1, Cn = ROWS ? n1 : n0;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const float norm = -log_c((float)(n0 + n1));
+  const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)row * LDC;
+  const float *up = u + (size_t)p * LDC, *vp = v + (size_t)p * LDC;
+  if (ROWS && Zout && row <= n0) {  // full (n0+1) x (n1+1) tensor, dustbins included
+    float *zr = Zout + (size_t)p * (NP + 1) * LDC + (size_t)row * LDC;
+    const float ui = up[row];
+    for (int c = lane; c <= n1; c += 64) zr[c] = ((mr[c] + ui) + vp[c]) - norm;
+  }
+  if (row >= R) return;
+  // reference semantics (max_matrix): value starts at -FLT_MAX, index 0, strict '<'
+  float best = -FLT_MAX;
+  int bi = 0;
+  for (int c = lane; c < Cn; c += 64) {
+    const float z = ROWS ? (((mr[c] + up[row]) + vp[c]) - norm) : (((mr[c] + up[c]) + vp[row]) - norm);
+    if (best < z) { best = z; bi = c; }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const float ob = __shfl_xor(best, s, 64);
+    const int oi = __shfl_xor(bi, s, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) {
+    midx[(size_t)p * NP + row] = bi;
+    mval[(size_t)p * NP + row] = best;
+  }
+}
+
+// decode() tail (src/super_glue.cpp:345-430) + match assembly
+// (src/point_matching.cc:26-45).  One 1024-thread workgroup per pair.
+struct DMatch { int queryIdx, trainIdx; float distance; };
+
+__device__ __forceinline__ int block_excl_scan1024(int v, int *wsum, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  total = tot;
+  return base + incl - v;
+}
+
+__global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const int *mi0, const float *mv0,
+                                                      const int *mi1, double thresh, const float *kxy,
+                                                      int *idx0, int *idx1, double *ms0,
+                                                      double *ms1, DMatch *matches, float *pts0, float *pts1,
+                                                      int *nmatch) {
+  __shared__ int s_valid0[NP];
+  __shared__ double s_ms0[NP];
+  __shared__ int wsum[16];
+  const int p = blockIdx.x, i = threadIdx.x;
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const int *a0 = mi0 + (size_t)p * NP, *a1 = mi1 + (size_t)p * NP;
+  int my0 = -1;
+  double m0 = 0.0;
+  if (i < n0) {
+    const int j = a0[i];
+    const bool mutual0 = (j < n1) && (a1[j] == i);
+    m0 = mutual0 ? (double)exp_c(mv0[(size_t)p * NP + i]) : 0.0;
+    const bool valid0 = mutual0 && (m0 > thresh);
+    s_valid0[i] = valid0 ? 1 : 0;
+    s_ms0[i] = m0;
+    my0 = valid0 ? j : -1;
+    idx0[(size_t)p * NP + i] = my0;
+    ms0[(size_t)p * NP + i] = m0;
+  }
+  __syncthreads();
+  if (i < n1) {
+    const int k = a1[i];
+    const bool mutual1 = (k < n0) && (a0[k] == i);
+    const double m1 = mutual1 ? s_ms0[k] : 0.0;
+    const bool valid1 = mutual1 && s_valid0[k];
+    idx1[(size_t)p * NP + i] = valid1 ? k : -1;
+    ms1[(size_t)p * NP + i] = m1;
+  }
+  // match list: i with 0 <= idx0[i] < n1 and idx1[idx0[i]] == i  (always true for valid0)
+  const int flag = (my0 >= 0) ? 1 : 0;
+  int total;
+  const int pos = block_excl_scan1024(flag, wsum, total);
+  if (flag) {
+    // mscores1[idx0[i]] == mscores0[i] for a valid mutual match
+    const double d = 1.0 - (m0 + m0) / 2.0;
+    DMatch dm;
+    dm.queryIdx = i; dm.trainIdx = my0; dm.distance = (float)d;
+    matches[(size_t)p * NP + pos] = dm;
+    const float *k0 = kxy + ((size_t)(2 * p) * NP) * 2, *k1 = kxy + ((size_t)(2 * p + 1) * NP) * 2;
+    pts0[((size_t)p * NP + pos) * 2] = k0[2 * i];
+    pts0[((size_t)p * NP + pos) * 2 + 1] = k0[2 * i + 1];
+    pts1[((size_t)p * NP + pos) * 2] = k1[2 * my0];
+    pts1[((size_t)p * NP + pos) * 2 + 1] = k1[2 * my0 + 1];
+  }
+  if (i == 0) nmatch[p] = total;
+}
+
+// ------------------------------------------------------------------ launchers
+int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int height, int *counts, float *kin,
+                         float *kxy, float *x, hipStream_t st) {
+  hipLaunchKernelGGL(sg_prep_slots_kernel, dim3(64, nimg), dim3(256), 0, st, slots, width, height, counts, kin, kxy, x);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st) {
+  hipLaunchKernelGGL(attn_kernel, dim3(NP / 64, 4, nimg), dim3(256), 0, st, qkv, counts, cross, o);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_score(const float *mdesc, const int *counts, float alpha, float *C, float *Ct, float *u, float *v, int P,
+                 hipStream_t st) {
+  hipLaunchKernelGGL(score_kernel, dim3(NP / 64, NP / 64, P), dim3(256), 0, st, mdesc, counts, C, Ct);
+  hipLaunchKernelGGL(ot_init_kernel, dim3(5, P), dim3(256), 0, st, counts, alpha, C, Ct, u, v);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
+                    hipStream_t st) {
+  const dim3 grid((NP + 1 + 3) / 4, P), block(256);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL((sinkhorn_half_kernel<true>), grid, block, 0, st, counts, C, v, u);
+    hipLaunchKernelGGL((sinkhorn_half_kernel<false>), grid, block, 0, st, counts, Ct, u, v);
+  }
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
+                  const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1,
+                  int *idx0, int *idx1, double *ms0, double *ms1, void *matches, float *pts0, float *pts1,
+                  int *nmatch, float *Zout, int P, hipStream_t st) {
+  const dim3 grid((NP + 1 + 3) / 4, P), block(256);
+  hipLaunchKernelGGL((argmax_kernel<true>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout);
+  hipLaunchKernelGGL((argmax_kernel<false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr);
+  hipLaunchKernelGGL(decode_kernel, dim3(P), dim3(1024), 0, st, counts, mi0, mv0, mi1, thresh, kxy, idx0,
+                     idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace urf

@@ -1,0 +1,454 @@
+// sp_kernels.hip -- SuperPoint tail: softmax + depth-to-space, the in-graph
+// simple_nms, threshold / border / top-k selection, descriptor normalisation and
+// bilinear sampling.  Replaces the tail of the SuperPoint ONNX graph
+// (superpoint/SP/model.py:15-26,73-84) and SuperPoint::process_output
+// (src/super_point.cpp:178-386).  HBM/LDS-bound VALU kernels: coalesced loads,
+// LDS tiles with halo for the 9x9 max filters, wave reductions.
+#include "urf_common.h"
+#include "urf_math.h"
+
+#include <float.h>
+
+namespace urf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ softmax
+// logits [B][Hc*Wc][ld] (65 used) -> heat [B][Hs][Ws].  One lane per cell:
+// m = max; e_k = exp_c(l_k - m); sum sequential k=0..64; p_k = e_k / sum.
+__global__ void __launch_bounds__(256) softmax_d2s_kernel(const float *logits, int ld, int Hc, int Wc,
+                                                          float *heat) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (cell >= Hc * Wc) return;
+  const float *l = logits + ((size_t)b * Hc * Wc + cell) * ld;
+  float v[65];
+  float m = l[0];
+  v[0] = m;
+#pragma unroll
+  for (int k = 1; k < 65; ++k) { v[k] = l[k]; m = v[k] > m ? v[k] : m; }
+  float sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 65; ++k) { v[k] = exp_c(v[k] - m); sum = sum + v[k]; }
+  const int hc = cell / Wc, wc = cell % Wc, Ws = Wc * 8;
+  float *hp = heat + (size_t)b * Hc * 8 * Ws + (size_t)(hc * 8) * Ws + wc * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    f32x4 a, c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = v[r * 8 + j] / sum; c[j] = v[r * 8 + 4 + j] / sum; }
+    *(f32x4 *)(hp + (size_t)r * Ws) = a;
+    *(f32x4 *)(hp + (size_t)r * Ws + 4) = c;
+  }
+}
+
+// ---------------------------------------------------------------------- NMS
+// simple_nms (model.py:15-26) as five 9x9 max-filter passes.  Block = 32x64
+// pixel tile; LDS holds the tile with a 4-pixel halo (implicit -inf padding).
+//  MODE 0 (A): mask = (s == mp(s))
+//  MODE 1 (B): supp = mp(mask) > 0 ; ss = supp ? 0 : s
+//  MODE 2 (C): mask |= (ss == mp(ss)) & ~supp ; if LAST: out = mask ? s : 0
+constexpr int NR = 32, NC = 64;
+template <int MODE, bool LAST>
+__global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *mask, uint8_t *supp, float *ss,
+                                                       float *out, int H, int W) {
+  __shared__ float tin[(NR + 8)][(NC + 8)];
+  __shared__ float hm[(NR + 8)][NC];
+  const int b = blockIdx.z;
+  const size_t boff = (size_t)b * H * W;
+  const int y0 = blockIdx.y * NR, x0 = blockIdx.x * NC;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (NR + 8) * (NC + 8); i += 256) {
+    const int r = i / (NC + 8), c = i % (NC + 8);
+    const int y = y0 - 4 + r, x = x0 - 4 + c;
+    float v = -FLT_MAX;  // stands for -inf padding; every real value is > -FLT_MAX
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const size_t p = boff + (size_t)y * W + x;
+      if (MODE == 0) v = s[p];
+      else if (MODE == 1) v = mask[p] ? 1.0f : 0.0f;
+      else v = ss[p];
+    }
+    tin[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < (NR + 8) * NC; i += 256) {
+    const int r = i / NC, c = i % NC;
+    float m = tin[r][c];
+#pragma unroll
+    for (int d = 1; d < 9; ++d) m = fmaxf(m, tin[r][c + d]);
+    hm[r][c] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < NR * NC; i += 256) {
+    const int r = i / NC, c = i % NC;
+    const int y = y0 + r, x = x0 + c;
+    if (y >= H || x >= W) continue;
+    float m = hm[r][c];
+#pragma unroll
+    for (int d = 1; d < 9; ++d) m = fmaxf(m, hm[r + d][c]);
+    const size_t p = boff + (size_t)y * W + x;
+    const float center = tin[r + 4][c + 4];
+    if (MODE == 0) {
+      mask[p] = (center == m) ? 1 : 0;
+    } else if (MODE == 1) {
+      const bool sp = m > 0.0f;
+      supp[p] = sp ? 1 : 0;
+      ss[p] = sp ? 0.0f : s[p];
+    } else {
+      const bool nm = (center == m) && (supp[p] == 0);
+      const uint8_t mk = (mask[p] != 0 || nm) ? 1 : 0;
+      if (LAST) out[p] = mk ? s[p] : 0.0f;
+      else mask[p] = mk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- selection
+// find_high_score_index + remove_borders / filter_points
+// (src/super_point.cpp:178-228), ordered (raster) compaction in two passes.
+constexpr int SEL_PIX = 2048;  // pixels per block, 8 consecutive per thread
+
+__device__ __forceinline__ bool sel_flag(float sc, int y, int x, int H, int W, double thr, int border,
+                                          const uint8_t *mask, size_t moff) {
+  if (!((double)sc > thr)) return false;
+  if (mask) return mask[moff + (size_t)y * W + x] != 0;
+  return y >= border && y < H - border && x >= border && x < W - border;
+}
+
+// block-wide exclusive scan of one int per thread (blockDim = 256 or 1024)
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const int t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  total = tot;
+  return base + incl - v;
+}
+
+__global__ void __launch_bounds__(256) sel_count_kernel(const float *scores, int H, int W, double thr, int border,
+                                                        const uint8_t *mask, int *counts, int nchunk) {
+  __shared__ int wsum[16];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const size_t boff = (size_t)b * H * W;
+  const int base = chunk * SEL_PIX + threadIdx.x * 8;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = base + j;
+    if (i < H * W) c += sel_flag(scores[boff + i], i / W, i % W, H, W, thr, border, mask, boff) ? 1 : 0;
+  }
+  int total;
+  block_excl_scan(c, wsum, total);
+  if (threadIdx.x == 0) counts[b * nchunk + chunk] = total;
+}
+
+__global__ void __launch_bounds__(256) sel_scatter_kernel(const float *scores, int H, int W, double thr, int border,
+                                                          const uint8_t *mask, const int *counts, int nchunk,
+                                                          float *cand_score, int *cand_idx, int cand_cap,
+                                                          int *cand_n) {
+  __shared__ int wsum[16];
+  __shared__ int s_off;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const size_t boff = (size_t)b * H * W;
+  // offset of this chunk = sum of the counts of earlier chunks (integers: exact)
+  int part = 0;
+  for (int i = threadIdx.x; i < nchunk; i += 256)
+    if (i < chunk) part += counts[b * nchunk + i];
+  int tot_all = 0;
+  for (int i = threadIdx.x; i < nchunk; i += 256) tot_all += counts[b * nchunk + i];
+  // reduce both
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { part += __shfl_xor(part, d, 64); tot_all += __shfl_xor(tot_all, d, 64); }
+  __shared__ int red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = part; red[1][threadIdx.x >> 6] = tot_all; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    if (chunk == 0) {
+      const int t = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      cand_n[b] = t < cand_cap ? t : cand_cap;
+    }
+  }
+  __syncthreads();
+  const int base = chunk * SEL_PIX + threadIdx.x * 8;
+  bool f[8];
+  float sc[8];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = base + j;
+    f[j] = false;
+    sc[j] = 0.0f;
+    if (i < H * W) {
+      sc[j] = scores[boff + i];
+      f[j] = sel_flag(sc[j], i / W, i % W, H, W, thr, border, mask, boff);
+    }
+    c += f[j] ? 1 : 0;
+  }
+  int total;
+  int pos = s_off + block_excl_scan(c, wsum, total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (f[j]) {
+      if (pos < cand_cap) {
+        cand_score[(size_t)b * cand_cap + pos] = sc[j];
+        cand_idx[(size_t)b * cand_cap + pos] = base + j;
+      }
+      ++pos;
+    }
+}
+
+// top_k_keypoints (src/super_point.cpp:230-251).  n <= k: raster order kept.
+// Otherwise the k best by (score desc, raster index asc): 4-pass radix select
+// on the score bits, first-come tie completion, bitonic sort of <=1024 keys.
+__global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, const int *cand_idx, const int *cand_n,
+                                                    int cand_cap, int k, float *kp_score, int *kp_idx, int *kp_n) {
+  __shared__ int hist[256];
+  __shared__ int wsum[16];
+  __shared__ unsigned long long keys[kCap];
+  __shared__ unsigned s_prefix, s_mask;
+  __shared__ int s_rank, s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = cand_n[b];
+  const float *cs = cand_score + (size_t)b * cand_cap;
+  const int *ci = cand_idx + (size_t)b * cand_cap;
+  float *os = kp_score + (size_t)b * kCap;
+  int *oi = kp_idx + (size_t)b * kCap;
+  const int kk = (k < 0 || k > kCap) ? kCap : k;
+  if (n <= kk) {  // includes the k == -1 case up to the slot capacity
+    for (int i = tid; i < n; i += 1024) { os[i] = cs[i]; oi[i] = ci[i]; }
+    if (tid == 0) kp_n[b] = n;
+    return;
+  }
+  // ---- radix select: find T = kk-th largest score bit pattern
+  if (tid == 0) { s_prefix = 0; s_mask = 0; s_rank = kk; }
+  __syncthreads();
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, msk = s_mask;
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned u = __float_as_uint(cs[i]);
+      if ((u & msk) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int r = s_rank, bin = 255;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= r) break;
+        r -= hist[bin];
+      }
+      s_rank = r;  // rank inside the chosen bin
+      s_prefix = prefix | ((unsigned)bin << (8 * pass));
+      s_mask = msk | (0xFFu << (8 * pass));
+    }
+    __syncthreads();
+  }
+  const unsigned T = s_prefix;
+  const int need_eq = s_rank;  // how many candidates with bits == T to take (first in raster order)
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < kCap; i += 1024) keys[i] = 0ull;
+  __syncthreads();
+  int eq_seen = 0;  // number of == T candidates in earlier rounds
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    unsigned u = 0;
+    bool gt = false, eq = false;
+    if (i < n) { u = __float_as_uint(cs[i]); gt = u > T; eq = u == T; }
+    int tot;
+    const int erank = eq_seen + block_excl_scan(eq ? 1 : 0, wsum, tot);
+    if (gt || (eq && erank < need_eq)) {
+      const int p = atomicAdd(&s_cnt, 1);
+      keys[p] = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ci[i]);
+    }
+    eq_seen += tot;
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending, 1024 keys
+  for (int size = 2; size <= kCap; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int i = tid;
+      const int j = i ^ stride;
+      if (j > i) {
+        const unsigned long long a = keys[i], c = keys[j];
+        const bool desc = ((i & size) == 0);
+        if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < kk) {
+    const unsigned long long key = keys[tid];
+    os[tid] = __uint_as_float((unsigned)(key >> 32));
+    oi[tid] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+  }
+  if (tid == 0) kp_n[b] = kk;
+}
+
+// ------------------------------------------------------- descriptor normalise
+// F.normalize(p=2, dim=1) (model.py:83).  One wave per cell; lane l owns
+// channels 4l..4l+3 (fma chain from x0*x0), 64-lane butterfly, x / max(norm,1e-12)
+__global__ void __launch_bounds__(256) desc_norm_kernel(float *desc, int ld, int coff, int ncell, float *out) {
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (cell >= ncell) return;
+  const f32x4 v = *(const f32x4 *)(desc + (size_t)cell * ld + coff + 4 * lane);
+  float a = v[0] * v[0];
+  a = __builtin_fmaf(v[1], v[1], a);
+  a = __builtin_fmaf(v[2], v[2], a);
+  a = __builtin_fmaf(v[3], v[3], a);
+  float nrm = __builtin_sqrtf(bfly64_sum(a));
+  nrm = nrm > 1e-12f ? nrm : 1e-12f;
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = v[r] / nrm;
+  *(f32x4 *)(out + (size_t)cell * 256 + 4 * lane) = o;
+}
+
+// ------------------------------------------------------------------ sampling
+// sample_descriptors (src/super_point.cpp:253-336) in double like the reference,
+// plus packing of the 259-row feature column (:364-384) and of the f32 slot.
+// One wave per keypoint, lane l = channels 4l..4l+3; lane 0 does the
+// sequential 256-term double sum of squares (std::inner_product order).
+__device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : (v < mx - 1 ? v : mx - 1); }
+
+__global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*Wc][256]*/, int Hc, int Wc,
+                                                     const float *kp_score, const int *kp_idx, const int *kp_n,
+                                                     int Ws, double *feat /*[B][kCap][259] or null*/,
+                                                     float *slots /*[B][kSlotFloats] or null*/) {
+  __shared__ double vals[4][256];
+  __shared__ double s_inv[4];
+  const int b = blockIdx.y;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wv;
+  const int n = kp_n[b];
+  if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
+    int *hdr = (int *)(slots + (size_t)b * kSlotFloats);
+    hdr[0] = n; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0;
+  }
+  const bool active = j < n;
+  double v[4] = {0, 0, 0, 0};
+  int kx = 0, ky = 0;
+  float sc = 0.0f;
+  if (active) {
+    const int idx = kp_idx[(size_t)b * kCap + j];
+    sc = kp_score[(size_t)b * kCap + j];
+    kx = idx % Ws; ky = idx / Ws;
+    const int s = 8, h = Hc, w = Wc;
+    double g0 = kx - s / 2 + 0.5, g1 = ky - s / 2 + 0.5;
+    g0 = g0 / (w * s - s / 2 - 0.5);
+    g1 = g1 / (h * s - s / 2 - 0.5);
+    g0 = g0 * 2 - 1;
+    g1 = g1 * 2 - 1;
+    const double ix = ((g0 + 1) / 2) * (w - 1);
+    const double iy = ((g1 + 1) / 2) * (h - 1);
+    const int ix_nw = clipi((int)floor(ix), w), iy_nw = clipi((int)floor(iy), h);
+    const int ix_ne = clipi(ix_nw + 1, w), iy_ne = clipi(iy_nw, h);
+    const int ix_sw = clipi(ix_nw, w), iy_sw = clipi(iy_nw + 1, h);
+    const int ix_se = clipi(ix_nw + 1, w), iy_se = clipi(iy_nw + 1, h);
+    const double nw = (ix_se - ix) * (iy_se - iy);
+    const double ne = (ix - ix_sw) * (iy_sw - iy);
+    const double sw = (ix_ne - ix) * (iy - iy_ne);
+    const double se = (ix - ix_nw) * (iy - iy_nw);
+    const float *db = desc + (size_t)b * Hc * Wc * 256;
+    const f32x4 a = *(const f32x4 *)(db + ((size_t)iy_nw * w + ix_nw) * 256 + 4 * lane);
+    const f32x4 c = *(const f32x4 *)(db + ((size_t)iy_ne * w + ix_ne) * 256 + 4 * lane);
+    const f32x4 d = *(const f32x4 *)(db + ((size_t)iy_sw * w + ix_sw) * 256 + 4 * lane);
+    const f32x4 e = *(const f32x4 *)(db + ((size_t)iy_se * w + ix_se) * 256 + 4 * lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = (double)a[r] * nw + (double)c[r] * ne + (double)d[r] * sw + (double)e[r] * se;
+      vals[wv][4 * lane + r] = v[r];
+    }
+  }
+  __syncthreads();
+  if (active && lane == 0) {
+    double ssq = 0.0;
+    for (int c = 0; c < 256; ++c) ssq = ssq + vals[wv][c] * vals[wv][c];
+    s_inv[wv] = 1.0 / sqrt(ssq);
+  }
+  __syncthreads();
+  if (!active) return;
+  const double inv = s_inv[wv];
+  if (feat) {
+    double *col = feat + ((size_t)b * kCap + j) * 259;
+    if (lane == 0) { col[0] = (double)sc; col[1] = (double)kx; col[2] = (double)ky; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) col[3 + 4 * lane + r] = v[r] * inv;
+  }
+  if (slots) {
+    float *sl = slots + (size_t)b * kSlotFloats;
+    if (lane == 0) {
+      f32x4 m = {sc, (float)kx, (float)ky, 0.0f};
+      *(f32x4 *)(sl + kSlotHeader + 4 * (size_t)j) = m;
+    }
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (float)(v[r] * inv);
+    *(f32x4 *)(sl + kSlotHeader + 4 * (size_t)kCap + (size_t)j * 256 + 4 * lane) = o;
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, hipStream_t st) {
+  dim3 grid((Hc * Wc + 255) / 256, B);
+  hipLaunchKernelGGL(softmax_d2s_kernel, grid, dim3(256), 0, st, logits, ld, Hc, Wc, heat);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nms(const float *heat, uint8_t *mask, uint8_t *supp, float *ss, float *out, int H, int W, int B,
+               hipStream_t st) {
+  dim3 grid((W + NC - 1) / NC, (H + NR - 1) / NR, B), block(256);
+  hipLaunchKernelGGL((nms_pass_kernel<0, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  hipLaunchKernelGGL((nms_pass_kernel<2, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  hipLaunchKernelGGL((nms_pass_kernel<2, true>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_select(const float *scores, int H, int W, double thr, int border, const uint8_t *mask, int *counts,
+                  float *cand_score, int *cand_idx, int cand_cap, int *cand_n, int k, float *kp_score, int *kp_idx,
+                  int *kp_n, int B, hipStream_t st) {
+  const int nchunk = (H * W + SEL_PIX - 1) / SEL_PIX;
+  dim3 grid(nchunk, B);
+  hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), 0, st, scores, H, W, thr, border, mask, counts, nchunk);
+  hipLaunchKernelGGL(sel_scatter_kernel, grid, dim3(256), 0, st, scores, H, W, thr, border, mask, counts, nchunk,
+                     cand_score, cand_idx, cand_cap, cand_n);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, st, cand_score, cand_idx, cand_n, cand_cap, k, kp_score,
+                     kp_idx, kp_n);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int select_nchunk(int H, int W) { return (H * W + SEL_PIX - 1) / SEL_PIX; }
+
+int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(desc_norm_kernel, dim3((ncell_total + 3) / 4), dim3(256), 0, st, desc, ld, coff, ncell_total, out);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, const int *kp_idx, const int *kp_n,
+                  int Ws, double *feat, float *slots, int B, hipStream_t st) {
+  hipLaunchKernelGGL(sample_kernel, dim3(kCap / 4, B), dim3(256), 0, st, desc, Hc, Wc, kp_score, kp_idx, kp_n, Ws,
+                     feat, slots);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace urf

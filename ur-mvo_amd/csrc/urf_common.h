@@ -1,0 +1,64 @@
+// urf_common.h -- shared host/device declarations of liburf_front.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace urf {
+
+void set_error(const char *fmt, ...);
+
+#define URF_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      urf::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return -1;                                                                   \
+    }                                                                              \
+  } while (0)
+
+#define URF_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      urf::set_error(__VA_ARGS__);      \
+      return -2;                        \
+    }                                   \
+  } while (0)
+
+// ---------------------------------------------------------------- conv/GEMM
+// One launch = act( W (*) in + bias ) [+ res], implicit GEMM on
+// v_mfma_f32_16x16x4_f32; every output is ONE fp32 fma chain:
+//   acc = bias; for chunk(64 ch); for tap; for c in chunk: acc = fma(in, w, acc)
+struct ConvArgs {
+  const void *in;        // f32 NHWC (or u8 image when FUSE1A)
+  long in_bstride;       // elements per batch item
+  int in_ld, in_coff;    // floats per pixel, first channel
+  const float *in2;      // optional 2nd K-source (TAPS==1): channels [Cin1, Cin) come from here
+  int in2_ld, in2_coff, Cin1;
+  long in2_bstride;
+  int H, W;              // TAPS==9: conv spatial size.  TAPS==1: H=1, W=rows
+  int Cin;               // multiple of 4; chunks of 64
+  const float *w;        // [taps][Cin][Cout]
+  const float *bias;     // [Cout]
+  int Cout;
+  float *out;
+  long out_bstride;
+  int out_ld, out_coff;
+  const float *res;      // optional residual, same geometry as out
+  long res_bstride;
+  int res_ld, res_coff;
+  int relu;
+  const int *counts;     // optional per-batch-item valid row count (TAPS==1)
+  // fused conv1a (FUSE1A): in = u8 image H x W
+  const float *w1a;      // [9][64]
+  const float *b1a;      // [64]
+  const float *lut;      // [256] u8 -> f32 ( float(u8)/255.0 )
+};
+
+// feature slot (device): header + meta[cap][4] + desc[cap][256], all 4-byte units
+constexpr int kCap = 1024;
+constexpr int kSlotHeader = 4;  // [K, 0, 0, 0]
+constexpr size_t kSlotFloats = kSlotHeader + (size_t)kCap * 4 + (size_t)kCap * 256;
+
+}  // namespace urf

@@ -1,0 +1,279 @@
+"""Python mirror of the reference's C++ front-end classes over the C ABI.
+
+Same class / method names and argument meaning as the reference headers
+(include/super_point.h:20-33, include/super_glue.h:20-33,
+include/point_matching.h:7-25 of UR-MVO) so the parity tests read like tests of
+the reference.  numpy arrays stand in for cv::Mat / Eigen: a feature matrix is
+an array of shape [K, 259] whose row j is column j of the reference's
+Eigen::Matrix<double,259,Dynamic> (same memory layout).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DMatch, SGConfig, SPConfig, check
+
+CAP = 1024
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SuperPointConfig:
+    """include/read_configs.h:9-18"""
+
+    def __init__(self, max_keypoints=1000, keypoint_threshold=0.0005, remove_borders=4, onnx_file="",
+                 engine_file="", dla_core=-1, input_tensor_names=("input",),
+                 output_tensor_names=("scores", "descriptors")):
+        self.max_keypoints = max_keypoints
+        self.keypoint_threshold = keypoint_threshold
+        self.remove_borders = remove_borders
+        self.onnx_file = onnx_file
+        self.engine_file = engine_file
+        self.dla_core = dla_core
+        self.input_tensor_names = list(input_tensor_names)
+        self.output_tensor_names = list(output_tensor_names)
+
+
+class SuperGlueConfig:
+    """include/read_configs.h:20-29"""
+
+    def __init__(self, image_width=640, image_height=512, matching_threshold=0.5, onnx_file="", engine_file="",
+                 dla_core=-1):
+        self.image_width = image_width
+        self.image_height = image_height
+        self.matching_threshold = matching_threshold
+        self.onnx_file = onnx_file
+        self.engine_file = engine_file
+        self.dla_core = dla_core
+
+
+class SuperPoint:
+    """SuperPoint (include/super_point.h:20-33)."""
+
+    def __init__(self, super_point_config, max_height=0, max_width=0, max_batch=1, device=0):
+        self.cfg = super_point_config
+        self._c = SPConfig(super_point_config.max_keypoints, super_point_config.keypoint_threshold,
+                           super_point_config.remove_borders, max_height, max_width, max_batch, device)
+        self._h = C.c_void_p()
+        self._built = False
+        check(_lib.lib().urf_sp_create(C.byref(self._c), C.byref(self._h)), "urf_sp_create")
+
+    def build(self, blob=None):
+        """build(): weights from `blob` (f32 container) or from cfg.engine_file."""
+        L = _lib.lib()
+        if blob is not None:
+            blob = np.ascontiguousarray(blob, np.float32)
+            rc = L.urf_sp_build(self._h, _p(blob), C.c_size_t(blob.size))
+        else:
+            rc = L.urf_sp_build_file(self._h, self.cfg.engine_file.encode())
+        self._built = rc == 0
+        return self._built
+
+    def infer(self, image, mask=None):
+        """infer(image, mask, features) -> features [K,259] (or None on failure)."""
+        image = np.asarray(image)
+        assert image.dtype == np.uint8 and image.ndim == 2
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        feat = np.zeros((CAP, 259), np.float64)
+        K = C.c_int(0)
+        mp, ms = None, 0
+        if mask is not None and mask.size:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            mp, ms = _p(mask), mask.strides[0]
+        rc = _lib.lib().urf_sp_infer(self._h, _p(image), image.shape[0], image.shape[1],
+                                     C.c_size_t(image.strides[0]), mp, C.c_size_t(ms), _p(feat), CAP, C.byref(K))
+        if rc != 0:
+            return None
+        return feat[:K.value].copy()
+
+    def infer_batch(self, images):
+        B = len(images)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+        H, W = imgs[0].shape
+        ptrs = (C.c_void_p * B)(*[i.ctypes.data for i in imgs])
+        feat = np.zeros((B, CAP, 259), np.float64)
+        K = (C.c_int * B)()
+        check(_lib.lib().urf_sp_infer_batch(self._h, B, ptrs, H, W, C.c_size_t(W), _p(feat), CAP, K), "infer_batch")
+        return [feat[b, :K[b]].copy() for b in range(B)]
+
+    def infer_device(self, d_imgs_ptr, B, rows, cols, d_slots_ptr):
+        check(_lib.lib().urf_sp_infer_device(self._h, B, C.c_void_p(d_imgs_ptr), rows, cols, C.c_void_p(d_slots_ptr)),
+              "urf_sp_infer_device")
+
+    def sync(self):
+        check(_lib.lib().urf_sp_sync(self._h), "urf_sp_sync")
+
+    def debug_tensor(self, which, shape):
+        out = np.zeros(shape, np.float32)
+        check(_lib.lib().urf_sp_debug_tensor(self._h, which, _p(out), C.c_size_t(out.size)), "debug_tensor")
+        return out
+
+    def stage_ms(self):
+        ms = (C.c_float * 32)()
+        n = check(_lib.lib().urf_sp_stage_ms(self._h, ms, 32), "stage_ms")
+        return [ms[i] for i in range(n)]
+
+    def save_engine(self, blob=None):
+        if self.cfg.engine_file and blob is not None:
+            blob = np.ascontiguousarray(blob, np.float32)
+            check(_lib.lib().urf_weights_save(self.cfg.engine_file.encode(), 1, _p(blob), C.c_size_t(blob.size)))
+
+    def deserialize_engine(self):
+        return self.build(None)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().urf_sp_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+SP_STAGES = ["upload", "conv1a+1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa|Da",
+             "convPb", "convDb", "softmax", "nms", "select", "desc_norm", "sample", "download"]
+PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac"]
+
+
+class _PM:
+    def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
+                 ransac_sigma=1.0, ransac_seed=0):
+        self.cfg = cfg
+        self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
+                           max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed)
+        self._h = C.c_void_p()
+        check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
+
+    def build(self, blob=None):
+        L = _lib.lib()
+        if blob is not None:
+            blob = np.ascontiguousarray(blob, np.float32)
+            rc = L.urf_pm_build(self._h, _p(blob), C.c_size_t(blob.size))
+        else:
+            rc = L.urf_pm_build_file(self._h, self.cfg.engine_file.encode())
+        return rc == 0
+
+    def stage_ms(self):
+        ms = (C.c_float * 16)()
+        n = check(_lib.lib().urf_pm_stage_ms(self._h, ms, 16), "stage_ms")
+        return [ms[i] for i in range(n)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().urf_pm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class SuperGlue(_PM):
+    """SuperGlue (include/super_glue.h:20-33)."""
+
+    def infer(self, features0, features1, want_scores=False):
+        """infer(features0, features1, indices0, indices1, mscores0, mscores1);
+        features carry normalised keypoints.  Returns the four vectors (+ the
+        (n0+1)x(n1+1) log-assignment when want_scores)."""
+        f0 = np.ascontiguousarray(features0, np.float64)
+        f1 = np.ascontiguousarray(features1, np.float64)
+        n0, n1 = f0.shape[0], f1.shape[0]
+        i0 = np.zeros(n0, np.int32)
+        i1 = np.zeros(n1, np.int32)
+        m0 = np.zeros(n0, np.float64)
+        m1 = np.zeros(n1, np.float64)
+        Z = np.zeros((n0 + 1, n1 + 1), np.float32) if want_scores else None
+        rc = _lib.lib().urf_sg_infer(self._h, _p(f0), n0, _p(f1), n1, _p(i0), _p(i1), _p(m0), _p(m1), _p(Z))
+        if rc != 0:
+            return None
+        return (i0, i1, m0, m1, Z) if want_scores else (i0, i1, m0, m1)
+
+
+class PointMatching(_PM):
+    """PointMatching (include/point_matching.h:7-25)."""
+
+    def NormalizeKeypoints(self, features, width, height):
+        f = np.ascontiguousarray(features, np.float64)
+        out = np.zeros_like(f)
+        _lib.lib().urf_normalize_keypoints(_p(f), f.shape[0], width, height, _p(out))
+        return out
+
+    def MatchingPoints(self, features0, features1, outlier_rejection=False):
+        """-> list of (queryIdx, trainIdx, distance)."""
+        f0 = np.ascontiguousarray(features0, np.float64)
+        f1 = np.ascontiguousarray(features1, np.float64)
+        out = (DMatch * CAP)()
+        n = check(_lib.lib().urf_match(self._h, _p(f0), f0.shape[0], _p(f1), f1.shape[0],
+                                       int(bool(outlier_rejection)), out, CAP), "urf_match")
+        return [(out[i].queryIdx, out[i].trainIdx, out[i].distance) for i in range(n)]
+
+    def match_device_async(self, slot_ptrs0, slot_ptrs1, outlier_rejection=True):
+        P = len(slot_ptrs0)
+        a = (C.c_void_p * P)(*slot_ptrs0)
+        b = (C.c_void_p * P)(*slot_ptrs1)
+        check(_lib.lib().urf_match_device_async(self._h, P, a, b, int(bool(outlier_rejection))), "match_device_async")
+
+    def fetch(self, P):
+        out = (DMatch * (CAP * P))()
+        n = (C.c_int * P)()
+        check(_lib.lib().urf_pm_fetch(self._h, P, out, CAP, n), "urf_pm_fetch")
+        return [[(out[p * CAP + i].queryIdx, out[p * CAP + i].trainIdx, out[p * CAP + i].distance)
+                 for i in range(n[p])] for p in range(P)]
+
+    def sync(self):
+        check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
+
+    def find_F(self, pts0, pts1):
+        p0 = np.ascontiguousarray(pts0, np.float32)
+        p1 = np.ascontiguousarray(pts1, np.float32)
+        n = p0.shape[0]
+        inl = np.zeros(max(n, 1), np.uint8)
+        F = np.zeros(9, np.float32)
+        s = C.c_float(0)
+        check(_lib.lib().urf_ransac_find_F(self._h, _p(p0), _p(p1), n, _p(inl), _p(F), C.byref(s)), "find_F")
+        return float(s.value), inl[:n], F.reshape(3, 3)
+
+
+def slot_to_host(d_slot_ptr):
+    feat = np.zeros((CAP, 259), np.float64)
+    K = C.c_int(0)
+    check(_lib.lib().urf_slot_to_host(C.c_void_p(d_slot_ptr), _p(feat), CAP, C.byref(K)), "slot_to_host")
+    return feat[:K.value].copy()
+
+
+def probe_fma_gemm(A, B, bias=None, device=0):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    M, K = A.shape
+    N = B.shape[1]
+    out = np.zeros((M, N), np.float32)
+    if bias is not None:
+        bias = np.ascontiguousarray(bias, np.float32)
+    check(_lib.lib().urf_probe_fma_gemm(_p(A), _p(B), _p(bias), M, N, K, _p(out), device), "probe_fma_gemm")
+    return out
+
+
+def probe_math(x, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    e = np.zeros_like(x)
+    l = np.zeros_like(x)
+    check(_lib.lib().urf_probe_math(_p(x), x.size, _p(e), _p(l), device), "probe_math")
+    return e, l
+
+
+def probe_divsqrt(a, b, device=0):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    q = np.zeros_like(a)
+    s = np.zeros_like(a)
+    qd = np.zeros(a.size, np.float64)
+    sd = np.zeros(a.size, np.float64)
+    check(_lib.lib().urf_probe_divsqrt(_p(a), _p(b), a.size, _p(q), _p(s), _p(qd), _p(sd), device), "probe_divsqrt")
+    return q, s, qd, sd
+
+
+def set_profiling(on):
+    _lib.lib().urf_set_profiling(int(bool(on)))
