@@ -1,0 +1,218 @@
+"""bench.py -- VO front-end throughput on MI355X.
+
+One "step" = one batch of 8 new 640x480 frames per GPU through the whole hot
+path: SuperPoint on the 8 frames, SuperGlue + 8-point RANSAC on the 8 pairs
+(frame t-1, t), inputs already resident in HBM, match lists delivered to the
+host.  N>1: one process per GPU (torch.distributed, backend nccl = RCCL), frames
+block-sharded, one all-gather of feature slots per step (weak scaling: 8 frames
+per GPU per step).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
+the library's own stream; `cpu_baseline` times the CPU oracle on one frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_pkg  # noqa: E402
+
+H, W = 480, 640
+BATCH = 8
+MAX_KP = 1000
+# algorithmic work, SURVEY.md 8(d): GFLOP per 640x480 frame / per pair at n=1000
+GF_CONV1 = 22.649 + 0.354          # conv1b + fused conv1a
+FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+
+
+def sg_linear_gflop(n0, n1):
+    per_pt = 2 * (3 * 32 + 32 * 64 + 64 * 128 + 128 * 256 + 256 * 256)          # kenc
+    per_pt += 18 * 2 * (3 * 256 * 256 + 256 * 256 + 512 * 512 + 512 * 256)      # qkv, merge, mlp
+    per_pt += 2 * 256 * 256                                                      # final proj
+    return per_pt * (n0 + n1) / 1e9
+
+
+def sg_attn_gflop(n0, n1):
+    # per layer, per image: QK^T + PV = 2 * 2*nq*ns*256
+    self_l = 4 * 256 * (n0 * n0 + n1 * n1)
+    cross_l = 4 * 256 * (2 * n0 * n1)
+    return 9 * (self_l + cross_l) / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    U = load_pkg()
+    F, synth, D = U.frontend, U.synth, U.dist
+    spb = synth.pack_sp(synth.sp_weights(0))
+    sgb = synth.pack_sg(synth.sg_weights(0))
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
+                      device=local_rank)
+    assert sp.build(spb), U._lib.lib().urf_last_error()
+    pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank)
+    assert pm.build(sgb), U._lib.lib().urf_last_error()
+
+    # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
+    # = frames [k*8*world, (k+1)*8*world); rank g owns the block [g*8, g*8+8) of
+    # it.  3 global batches are cycled.
+    NB = 3
+    stream = synth.shift_stream(100, NB * BATCH * world, H, W)
+    mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
+    d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
+    del stream
+    slot_floats = U._lib.lib().urf_slot_bytes() // 4
+    ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)   # local slots, 3-deep ring
+    gathered = [None] * NB
+    carry = torch.zeros((slot_floats,), dtype=torch.float32, device=dev)      # last frame of the previous batch
+    torch.cuda.synchronize()
+    F.set_profiling(True)
+
+    def sp_step(b):
+        k = b % NB
+        sp.infer_device(d_frames[k * BATCH].data_ptr(), BATCH, H, W, ring[k].data_ptr())
+
+    def pm_step(b):
+        """match the pairs this rank owns in global batch b; returns nothing (async)."""
+        k = b % NB
+        if world == 1:
+            allslots = ring[k]
+            base = 0
+        else:
+            allslots = gathered[k]
+            base = rank * BATCH
+        s0, s1 = [], []
+        for j in range(BATCH):
+            g = base + j
+            prev = allslots[g - 1].data_ptr() if g > 0 else carry.data_ptr()
+            s0.append(prev)
+            s1.append(allslots[g].data_ptr())
+        pm.match_device_async(s0, s1, True)
+
+    sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
+    n_matches = []
+
+    def one_step(b, record):
+        """steady state: PM(b) on the pm stream overlaps SP(b+1) on the sp stream"""
+        k = b % NB
+        if world > 1:
+            gathered[k] = D.all_gather_slots(ring[k], world)      # RCCL over xGMI
+            torch.cuda.synchronize()
+        pm_step(b)
+        sp_step(b + 1)
+        sp.sync()
+        res = pm.fetch(BATCH)
+        # carry = globally last slot of batch b (for pair (last, first) of batch b+1)
+        src = gathered[k][-1] if world > 1 else ring[k][-1]
+        carry.copy_(src)
+        torch.cuda.synchronize()
+        if record:
+            s = sp.stage_ms()
+            p = pm.stage_ms()
+            sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1])
+            pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
+            sink_ms.append(p[4]); ransac_ms.append(p[6])
+            n_matches.append(sum(len(r) for r in res))
+        return res
+
+    # prologue: SP(0) so that the loop body is exactly one SP + one PM per step
+    sp_step(0)
+    sp.sync()
+    for b in range(args.warmup):
+        one_step(b, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, args.warmup + args.steps):
+        one_step(b, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev, world)
+    total_frames = args.steps * BATCH * world
+    fps = total_frames / dt
+
+    if rank == 0:
+        kp = [int(F.slot_to_host(ring[b % NB][j].data_ptr()).shape[0]) for b in range(1) for j in range(BATCH)]
+        n_avg = float(np.mean(kp))
+        # ---- roofline of the dominant kernel (largest summed device time per step)
+        per_step = {
+            "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)": (np.mean(conv1_ms), GF_CONV1 * BATCH),
+            "SuperGlue linear layers (conv_mfma_kernel<1>)": (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH),
+            "SuperGlue attention (attn_kernel)": (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH),
+        }
+        dom = max(per_step, key=lambda k: per_step[k][0])
+        ms, gf = per_step[dom]
+        achieved = gf / ms  # GFLOP / ms = TFLOP/s
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                    "launch_ms": round(float(ms), 4), "algorithmic_gflop_per_step": round(gf, 2),
+                    "all_kernels_tflops": {k: round(v[1] / v[0], 2) for k, v in per_step.items()},
+                    "all_kernels_ms_per_step": {k: round(float(v[0]), 3) for k, v in per_step.items()}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            ncores = len(os.sched_getaffinity(0))
+            fr = synth.shift_stream(100, 2, H, W)
+            ocfg = O.SPConfig(MAX_KP, 0.0005, 4)
+            t = time.perf_counter()
+            f0 = O.sp_infer(spb, ocfg, fr[0])
+            t_sp = time.perf_counter() - t
+            f1 = O.sp_infer(spb, ocfg, fr[1])
+            t = time.perf_counter()
+            om = O.match_points(sgb, O.SGConfig(640, 512, 0.5, 100), O.RansacConfig(200, 1.0, 0), f0, f1, True)
+            t_pm = time.perf_counter() - t
+            cpu = {"value": round(1.0 / (t_sp + t_pm), 4), "unit": "frames/s", "cores": O.threads(),
+                   "kind": "port", "host_cores_visible": ncores,
+                   "sample": f"1 frame 640x480: SuperPoint {t_sp:.2f}s + 1 pair SuperGlue+RANSAC {t_pm:.2f}s "
+                             f"(K={f0.shape[0]},{f1.shape[0]}, {len(om)} matches), C oracle with OpenMP"}
+        out = {
+            "metric": "VO front-end frames/sec (SP+SG+RANSAC) @640x480", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "640x480 grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
+                                   f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json configs[2])",
+                       "resolution": "640x480", "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
+                       "sinkhorn_iterations": 100, "ransac_iterations": 200,
+                       "weights": "seeded synthetic (reference ships none)",
+                       "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stage_ms_per_step": {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
+                                  "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)},
+            "matches_per_step": round(float(np.mean(n_matches)), 1),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

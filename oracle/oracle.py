@@ -42,10 +42,21 @@ class DMatch(C.Structure):
 _lib = None
 
 
+def threads():
+    """OpenMP threads the oracle uses: the cores this process may run on, <= 32."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         _lib = C.CDLL(_SO)
         _lib.o_exp.restype = C.c_float
         _lib.o_exp.argtypes = [C.c_float]

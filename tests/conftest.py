@@ -1,0 +1,67 @@
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pkg():
+    """import the hyphenated package directory ur-mvo_amd/ as module ur_mvo_amd"""
+    if "ur_mvo_amd" in sys.modules:
+        return sys.modules["ur_mvo_amd"]
+    d = os.path.join(ROOT, "ur-mvo_amd")
+    spec = importlib.util.spec_from_file_location("ur_mvo_amd", os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["ur_mvo_amd"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="session")
+def U():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def sp_blob(U):
+    return U.synth.pack_sp(U.synth.sp_weights(0))
+
+
+@pytest.fixture(scope="session")
+def sg_blob(U):
+    return U.synth.pack_sg(U.synth.sg_weights(0))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def make_features(rng, n, planted_from=None, m=0, shift=3):
+    f = np.zeros((n, 259))
+    f[:, 0] = rng.uniform(0.001, 1, n).astype(np.float32)
+    f[:, 1] = rng.integers(4, 636, n)
+    f[:, 2] = rng.integers(4, 476, n)
+    d = rng.standard_normal((n, 256))
+    f[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    if planted_from is not None and m:
+        f[:m, 3:] = planted_from[:m, 3:]
+        f[:m, 1:3] = planted_from[:m, 1:3] + shift
+    return f

@@ -1,0 +1,91 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol
+include/urf.h declares, fails loudly without a GPU, and the host-side pieces
+(keypoint normalisation, weight files, sharding logic) behave like the
+reference.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(U):
+    hdr = open(os.path.join(ROOT, "include", "urf.h")).read()
+    declared = set(re.findall(r"\b(urf_[a-z0-9_]+)\s*\(", hdr, flags=re.I))
+    declared = {d for d in declared if not d.startswith("urf_sp_config") and d != "urf_dmatch"}
+    assert len(declared) >= 30
+    L = U._lib.lib()
+    missing = [d for d in sorted(declared) if not hasattr(L, d)]
+    assert not missing, missing
+    assert set(U._lib.SYMBOLS) == declared
+
+
+def test_no_gpu_fails_loudly_not_silently(U):
+    L = U._lib.lib()
+    if L.urf_device_count() > 0:
+        pytest.skip("GPU present")
+    cfg = U._lib.SPConfig(1000, 0.0005, 4, 480, 640, 1, 0)
+    h = C.c_void_p()
+    rc = L.urf_sp_create(C.byref(cfg), C.byref(h))
+    assert rc < 0 and not h.value
+    assert b"HIP" in L.urf_last_error() or b"device" in L.urf_last_error()
+    with pytest.raises(RuntimeError):
+        U.frontend.SuperPoint(U.frontend.SuperPointConfig())
+    with pytest.raises(RuntimeError):
+        U.frontend.PointMatching(U.frontend.SuperGlueConfig())
+
+
+def test_product_never_touches_the_oracle():
+    """the product path must not import, link or call anything under oracle/"""
+    pk = os.path.join(ROOT, "ur-mvo_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle/" not in txt.replace("tools/calibrate", "") or f == "synth.py", (dp, f)
+                assert "import oracle" not in txt and "from oracle" not in txt, (dp, f)
+                assert "liburf_oracle" not in txt, (dp, f)
+
+
+def test_normalize_keypoints_host_matches_oracle(U, O):
+    rng = np.random.default_rng(0)
+    f = rng.random((37, 259))
+    f[:, 1] = rng.integers(0, 640, 37)
+    f[:, 2] = rng.integers(0, 480, 37)
+    pm_out = np.zeros_like(f)
+    U._lib.lib().urf_normalize_keypoints(f.ctypes.data_as(C.c_void_p), 37, 640, 512, pm_out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(pm_out, O.sg_normalize(f, 640, 512))
+    assert pm_out[0, 1] == (f[0, 1] - 320) / (640 * 0.7)      # src/point_matching.cc:71-74
+
+
+def test_weight_file_roundtrip_and_rejects_garbage(U, tmp_path):
+    L = U._lib.lib()
+    blob = np.arange(100, dtype=np.float32)
+    p = str(tmp_path / "w.urfw").encode()
+    assert L.urf_weights_save(p, 1, blob.ctypes.data_as(C.c_void_p), C.c_size_t(100)) == 0
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"URFW" and len(raw) == 16 + 400
+    assert np.array_equal(np.frombuffer(raw[16:], np.float32), blob)
+
+
+def test_synthetic_weights_are_bit_reproducible(U):
+    import hashlib
+    spb = U.synth.pack_sp(U.synth.sp_weights(0))
+    sgb = U.synth.pack_sg(U.synth.sg_weights(0))
+    assert spb.size == 1300865 and sgb.size == 12003905
+    # digests pinned when the golden fixtures were generated (tests/golden/make_golden.py)
+    d = open(os.path.join(ROOT, "tests", "golden", "weights.sha256")).read().split()
+    assert hashlib.sha256(spb.tobytes()).hexdigest() == d[0]
+    assert hashlib.sha256(sgb.tobytes()).hexdigest() == d[1]
+
+
+def test_shard_and_pair_assignment(U):
+    D = U.dist
+    assert [D.shard_range(32, r, 8) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
+    pairs = sum((D.pairs_for_rank(16, r, 4) for r in range(4)), [])
+    assert pairs == [(t - 1, t) for t in range(16)]       # every pair exactly once, in order
+    with pytest.raises(AssertionError):
+        D.shard_range(10, 0, 4)

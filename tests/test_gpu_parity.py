@@ -1,0 +1,248 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs (bit-exact), against the committed
+golden fixtures made from the reference graph, and through size-independent
+properties at the full BASELINE sizes."""
+import numpy as np
+import pytest
+
+from conftest import golden, make_features
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F(U):
+    assert U._lib.lib().urf_device_count() >= 1, "GPU tests need an MI355X"
+    return U.frontend
+
+
+@pytest.fixture(scope="module")
+def sp640(F, sp_blob):
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=480, max_width=1248, max_batch=8)
+    assert sp.build(sp_blob)
+    return sp
+
+
+@pytest.fixture(scope="module")
+def pm(F, sg_blob):
+    p = F.PointMatching(F.SuperGlueConfig(), max_pairs=8)
+    assert p.build(sg_blob)
+    return p
+
+
+# ------------------------------------------------------------------ primitives
+def test_mfma_f32_is_an_ordered_fma_chain(F, O):
+    """v_mfma_f32_16x16x4_f32 accumulates k in order, one rounding per product:
+    the property the whole exact-parity design rests on."""
+    rng = np.random.default_rng(0)
+    for (M, N, K) in [(16, 16, 4), (128, 64, 64), (200, 68, 256), (257, 512, 512)]:
+        A = (rng.standard_normal((M, K)) * 3).astype(np.float32)
+        B = (rng.standard_normal((K, N)) * 3).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        assert np.array_equal(F.probe_fma_gemm(A, B, bias), O.fma_gemm(A, B, np.tile(bias, (M, 1))))
+
+
+def test_canonical_math_matches_oracle_bit_for_bit(F, O):
+    x = np.concatenate([np.linspace(-100, 20, 20001), -np.logspace(-8, 2, 3000)]).astype(np.float32)
+    e, l = F.probe_math(x)
+    eo = np.array([O.lib().o_exp(float(v)) for v in x], np.float32)
+    lo = np.array([O.lib().o_log(float(abs(v)) + 1.17549435e-38) for v in x], np.float32)
+    assert np.array_equal(e, eo) and np.array_equal(l, lo)
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal(100000) * 10).astype(np.float32)
+    b = (rng.standard_normal(100000) * 3 + 0.01).astype(np.float32)
+    q, s, qd, sd = F.probe_divsqrt(a, b)
+    assert np.array_equal(q, a / b) and np.array_equal(s, np.sqrt(np.abs(a)))          # IEEE divide / sqrt
+    assert np.array_equal(qd, a.astype(np.float64) / b) and np.array_equal(sd, np.sqrt(np.abs(a.astype(np.float64) * b)))
+
+
+# ------------------------------------------------------------------ SuperPoint
+@pytest.mark.parametrize("H,W,k,seed", [(120, 160, 1000, 1), (104, 136, -1, 2), (250, 333, 200, 3)])
+def test_superpoint_dense_and_features_bit_exact_vs_oracle(U, F, O, sp_blob, H, W, k, seed):
+    img = U.synth.shift_stream(seed, 1, H, W)[0]
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=k), max_height=H, max_width=W)
+    assert sp.build(sp_blob)
+    feat = sp.infer(img)
+    o = O.sp_dense(sp_blob, img)
+    Hc, Wc = H // 8, W // 8
+    assert np.array_equal(sp.debug_tensor(1, (Hc * 8, Wc * 8)), o["heat"])
+    assert np.array_equal(sp.debug_tensor(0, (Hc * 8, Wc * 8)), o["scores"])
+    assert np.array_equal(sp.debug_tensor(2, (Hc, Wc, 256)), o["desc"])
+    of = O.sp_infer(sp_blob, O.SPConfig(k, 0.0005, 4), img)
+    assert feat.shape == of.shape and np.array_equal(feat, of)      # keypoints, scores AND f64 descriptors
+
+
+def test_superpoint_full_size_640x480_and_kitti(U, O, sp_blob, sp640):
+    for (H, W, seed) in [(480, 640, 11), (376, 1241, 12)]:
+        img = U.synth.shift_stream(seed, 1, H, W)[0]
+        feat = sp640.infer(img)
+        of = O.sp_infer(sp_blob, O.SPConfig(1000, 0.0005, 4), img)
+        assert feat.shape == (1000, 259) and np.array_equal(feat, of)
+        assert feat[:, 1].max() < (W // 8) * 8 and feat[:, 1].min() >= 4           # valid region, borders
+        assert np.all(np.diff(feat[:, 0]) <= 0)                                     # score-descending
+        assert np.abs(np.linalg.norm(feat[:, 3:], axis=1) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz"])
+def test_superpoint_vs_reference_graph_golden(F, sp_blob, name):
+    """HIP output vs the torch run of the reference's model.py (committed fixture)."""
+    g = golden(name)
+    H, W = g["image"].shape
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=int(g["k"])), max_height=H, max_width=W)
+    assert sp.build(sp_blob)
+    f = sp.infer(g["image"])
+    ko = {(int(r[1]), int(r[2])): j for j, r in enumerate(f)}
+    assert set(ko) == {(int(x), int(y)) for x, y in zip(g["x"], g["y"])}            # same keypoint set
+    perm = np.array([ko[(int(x), int(y))] for x, y in zip(g["x"], g["y"])])
+    np.testing.assert_allclose(f[perm, 0], g["score"], rtol=1e-3, atol=1e-5)
+    assert np.abs(f[perm, 3:] - g["desc"].astype(np.float64)).max() < 1e-3
+
+
+def test_superpoint_dense_golden(F, sp_blob):
+    g = golden("sp_dense_96x128.npz")
+    sp = F.SuperPoint(F.SuperPointConfig(), max_height=96, max_width=128)
+    assert sp.build(sp_blob)
+    sp.infer(g["image"])
+    np.testing.assert_allclose(sp.debug_tensor(0, (96, 128)), g["scores"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sp.debug_tensor(2, (12, 16, 256)), g["desc"], rtol=1e-3, atol=1e-5)
+
+
+def test_superpoint_mask_blank_and_strided_inputs(U, F, O, sp_blob):
+    H, W = 128, 160
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W)
+    assert sp.build(sp_blob)
+    img = U.synth.shift_stream(5, 1, H, W)[0]
+    mask = np.zeros((H, W), np.uint8)
+    mask[:, :80] = 7
+    f = sp.infer(img, mask)
+    of = O.sp_infer(sp_blob, O.SPConfig(1000, 0.0005, 4), img, mask=mask)
+    assert np.array_equal(f, of) and f[:, 1].max() < 80 and f[:, 2].min() < 4       # mask path: no border test
+    blank = np.zeros((H, W), np.uint8)
+    fb = sp.infer(blank)
+    assert np.array_equal(fb, O.sp_infer(sp_blob, O.SPConfig(1000, 0.0005, 4), blank))
+    big = np.zeros((H, W + 32), np.uint8)
+    big[:, :W] = img
+    view = big[:, :W]                                                                # cv::Mat with step > cols
+    assert np.array_equal(sp.infer(view), sp.infer(img))
+    assert sp.infer(np.zeros((8, 8), np.uint8)) is None                              # below the profile minimum
+
+
+def test_superpoint_batch_and_device_slots_equal_single(U, F, sp_blob, sp640):
+    import torch
+    frames = U.synth.shift_stream(21, 8, 480, 640)
+    single = [sp640.infer(f) for f in frames]
+    batch = sp640.infer_batch(frames)
+    assert all(np.array_equal(a, b) for a, b in zip(single, batch))
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    slots = torch.zeros((8, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp640.infer_device(d.data_ptr(), 8, 480, 640, slots.data_ptr())
+    sp640.sync()
+    for j in range(8):
+        s = F.slot_to_host(slots[j].data_ptr())
+        assert np.array_equal(s[:, :3], single[j][:, :3])
+        assert np.array_equal(s[:, 3:], single[j][:, 3:].astype(np.float32).astype(np.float64))
+
+
+def test_nms_idempotent_on_its_own_output(U, F, sp_blob, sp640, O):
+    """size-independent property at full size: simple_nms(simple_nms(x)) keeps
+    every survivor (survivors are >= 5 px apart)."""
+    img = U.synth.shift_stream(31, 1, 480, 640)[0]
+    sp640.infer(img)
+    s = sp640.debug_tensor(0, (480, 640))
+    assert np.array_equal(O.sp_nms(s) != 0, s != 0)
+    ys, xs = np.nonzero(s)
+    assert len(ys) > 1000
+    order = np.lexsort((xs, ys))
+    pts = np.c_[ys[order], xs[order]]
+    for i in range(0, len(pts), 37):
+        d = np.abs(pts - pts[i]).max(axis=1)
+        assert (d[d > 0] > 4).all()
+
+
+# ------------------------------------------------------------------- SuperGlue
+@pytest.mark.parametrize("n0,n1,seed", [(1, 1, 0), (17, 130, 1), (64, 64, 2), (300, 257, 3)])
+def test_superglue_bit_exact_vs_oracle(F, O, sg_blob, n0, n1, seed):
+    rng = np.random.default_rng(seed)
+    f0 = make_features(rng, n0)
+    f1 = make_features(rng, n1, planted_from=f0, m=min(n0, n1) // 2)
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
+    sg = F.SuperGlue(F.SuperGlueConfig())
+    assert sg.build(sg_blob)
+    i0, i1, m0, m1, Z = sg.infer(nf0, nf1, want_scores=True)
+    oi0, oi1, om0, om1, oZ = O.sg_infer(sg_blob, O.SGConfig(640, 512, 0.5, 100), nf0, nf1)
+    assert np.array_equal(Z, oZ)                                   # the whole log-assignment tensor
+    assert np.array_equal(i0, oi0) and np.array_equal(i1, oi1)
+    assert np.array_equal(m0, om0) and np.array_equal(m1, om1)
+
+
+def test_superglue_vs_public_architecture_golden(F, O, sg_blob):
+    g = golden("sg_n96.npz")
+    nf0, nf1 = O.sg_normalize(g["f0"], 640, 512), O.sg_normalize(g["f1"], 640, 512)
+    sg = F.SuperGlue(F.SuperGlueConfig())
+    assert sg.build(sg_blob)
+    i0, i1, m0, m1, Z = sg.infer(nf0, nf1, want_scores=True)
+    assert np.abs(Z - g["Z"]).max() < 1e-3                          # north_star tolerance on the score tensor
+    j0, j1, _, _ = O.sg_decode(g["Z"], 0.5)
+    assert np.array_equal(i0, j0) and np.array_equal(i1, j1)
+
+
+def test_superglue_full_size_and_swap_symmetry(F, O, sg_blob, pm):
+    """n = 1024 (profile maximum): swapping the two images transposes the result,
+    up to borderline pairs (Sinkhorn updates u before v, so the swap is not an
+    exact symmetry in floating point)."""
+    rng = np.random.default_rng(9)
+    f0 = make_features(rng, 1024)
+    f1 = make_features(rng, 1000, planted_from=f0, m=600)
+    a = pm.MatchingPoints(f0, f1, False)
+    b = pm.MatchingPoints(f1, f0, False)
+    assert len(a) >= 590
+    sa, sb = {(q, t) for q, t, _ in a}, {(t, q) for q, t, _ in b}
+    planted = {(i, i) for i in range(600)}
+    assert len(planted & sa) >= 590 and len(planted & sb) >= 590
+    assert len(planted & sa & sb) >= 585                      # the confident matches agree
+    assert len(sa & sb) >= 0.9 * max(len(sa), len(sb))
+    assert len(set(q for q, _, _ in a)) == len(a) and len(set(t for _, t, _ in a)) == len(a)   # one-to-one
+    assert pm.MatchingPoints(f0[:0], f1, True) == []
+
+
+# ------------------------------------------------------------ matching + RANSAC
+def test_matching_points_and_ransac_bit_exact_vs_oracle(U, F, O, sp_blob, sg_blob, pm):
+    fr = U.synth.shift_stream(1, 2, 240, 320)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=500), max_height=240, max_width=320)
+    assert sp.build(sp_blob)
+    f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])
+    cfg, rc = O.SGConfig(640, 512, 0.5, 100), O.RansacConfig(200, 1.0, 0)
+    g_raw, g_rej = pm.MatchingPoints(f0, f1, False), pm.MatchingPoints(f0, f1, True)
+    assert g_raw == O.match_points(sg_blob, cfg, rc, f0, f1, False)
+    assert g_rej == O.match_points(sg_blob, cfg, rc, f0, f1, True)
+    # most matches are true correspondences of the 8-px shift and survive RANSAC
+    true = [(q, t) for q, t, _ in g_rej if abs(f0[q, 1] - 8 - f1[t, 1]) < 0.5 and abs(f0[q, 2] - 8 - f1[t, 2]) < 0.5]
+    assert len(g_rej) > 200 and len(true) > 0.85 * len(g_rej)
+    q = np.array([m[0] for m in g_raw])
+    t = np.array([m[1] for m in g_raw])
+    s, inl, Fm = pm.find_F(f0[q, 1:3], f1[t, 1:3])
+    so, inlo, Fo = O.ransac_find_F(f0[q, 1:3], f1[t, 1:3], rc)
+    assert s == so and np.array_equal(inl, inlo) and np.array_equal(Fm, Fo)
+    s7, inl7, _ = pm.find_F(f0[q[:7], 1:3], f1[t[:7], 1:3])
+    assert s7 == 0 and inl7.sum() == 0                                   # fewer than 8 points
+
+
+def test_device_resident_batch_equals_host_path(U, F, sp_blob, sg_blob, sp640, pm):
+    """SP slots -> SuperGlue -> RANSAC entirely on the GPU (8 pairs) gives the
+    same match lists as the host-feature API of the reference."""
+    import torch
+    frames = U.synth.shift_stream(41, 9, 480, 640)
+    feats = [sp640.infer(f) for f in frames]
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    slots = torch.zeros((9, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp640.infer_device(d[0].data_ptr(), 1, 480, 640, slots[0].data_ptr())
+    sp640.infer_device(d[1].data_ptr(), 8, 480, 640, slots[1].data_ptr())
+    sp640.sync()
+    pm.match_device_async([slots[j].data_ptr() for j in range(8)], [slots[j + 1].data_ptr() for j in range(8)], True)
+    dev = pm.fetch(8)
+    # the host API takes f64 features; SuperGlue narrows them to f32 like the slots do
+    for j in range(8):
+        assert dev[j] == pm.MatchingPoints(feats[j], feats[j + 1], True)
+        assert len(dev[j]) > 300

@@ -1,0 +1,220 @@
+"""CPU tests: the oracle against the golden vectors made from the reference's
+own SuperPoint graph (tests/golden/make_golden.py) and against independent
+restatements of the reference's host code.  No GPU."""
+import numpy as np
+import pytest
+
+from conftest import golden, make_features
+
+
+def test_canonical_exp_log_within_2ulp(O):
+    x = np.concatenate([np.linspace(-87, 20, 4001), -np.logspace(-8, 1.9, 500)]).astype(np.float32)
+    e = np.array([O.lib().o_exp(float(v)) for v in x], np.float32)
+    ref = np.exp(x.astype(np.float64))
+    ulp = np.abs(e - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 2.0
+    assert O.lib().o_exp(-100.0) == 0.0 and O.lib().o_exp(0.0) == 1.0
+    xl = np.concatenate([np.linspace(0.5, 2100, 4001), np.logspace(-30, 30, 500)]).astype(np.float32)
+    l = np.array([O.lib().o_log(float(v)) for v in xl], np.float32)
+    refl = np.log(xl.astype(np.float64))
+    assert (np.abs(l - refl) <= 2.0 * np.spacing(np.abs(refl).astype(np.float32)) + 1e-7).all()
+    assert O.lib().o_log(1.0) == 0.0
+
+
+def test_wave_sum_is_the_documented_order(O):
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 64, 65, 1025):
+        x = rng.standard_normal(n).astype(np.float32)
+        p = np.zeros(64, np.float32)
+        for l in range(64):
+            a = np.float32(0)
+            for j in range(l, n, 64):
+                a = np.float32(a + x[j])
+            p[l] = a
+        s = 32
+        while s >= 1:
+            p = (p + p[np.arange(64) ^ s]).astype(np.float32)
+            s //= 2
+        got = O.lib().o_wave_sum(x.ctypes.data_as(__import__("ctypes").c_void_p), n)
+        assert np.float32(got) == p[0]
+
+
+def test_sp_dense_matches_reference_graph(O, sp_blob):
+    """oracle dense network vs superpoint/SP/model.py run under torch fp32
+    (tolerance = the reference's own export check, rtol 1e-3 / atol 1e-5,
+    superpoint/SP/convert_superpoint_to_onnx.py:71-74)."""
+    g = golden("sp_dense_96x128.npz")
+    o = O.sp_dense(sp_blob, g["image"])
+    np.testing.assert_allclose(o["scores"], g["scores"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(o["desc"], g["desc"], rtol=1e-3, atol=1e-5)
+    # discrete outputs identical: NMS support and thresholded candidate set
+    assert np.array_equal(o["scores"] != 0, g["scores"] != 0)
+    assert np.array_equal(o["scores"] > 0.0005, g["scores"] > 0.0005)
+
+
+@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz"])
+def test_sp_infer_matches_reference_postprocess(O, sp_blob, name):
+    g = golden(name)
+    cfg = O.SPConfig(int(g["k"]), 0.0005, 4)
+    f = O.sp_infer(sp_blob, cfg, g["image"])
+    assert f.shape[0] == len(g["x"])
+    # the keypoint SET is identical to the torch run of the reference graph.  The
+    # ORDER is score-descending; torch and the oracle sum in different orders, so
+    # two scores closer than ~1e-6 relative may swap places (never more).
+    ko = {(int(r[1]), int(r[2])): j for j, r in enumerate(f)}
+    kg = {(int(x), int(y)): j for j, (x, y) in enumerate(zip(g["x"], g["y"]))}
+    assert set(ko) == set(kg)
+    perm = np.array([ko[(int(x), int(y))] for x, y in zip(g["x"], g["y"])])
+    np.testing.assert_allclose(f[perm, 0], g["score"], rtol=1e-3, atol=1e-5)
+    moved = np.nonzero(perm != np.arange(len(perm)))[0]
+    for j in moved:
+        assert abs(perm[j] - j) <= 2 and abs(f[perm[j], 0] - f[j, 0]) < 2e-6 * f[j, 0]
+    assert np.abs(f[perm, 3:] - g["desc"].astype(np.float64)).max() < 1e-3         # stored as f16
+    assert np.abs(np.linalg.norm(f[:, 3:], axis=1) - 1).max() < 1e-12
+
+
+def test_sp_width_not_multiple_of_8_uses_valid_region(O, sp_blob):
+    g = golden("sp_sparse_376x1241.npz")
+    o = O.sp_dense(sp_blob, g["image"])
+    assert o["scores"].shape == (376, 1240) and o["desc"].shape == (47, 155, 256)
+
+
+def test_nms_is_simple_nms(O):
+    """osp_simple_nms vs a direct numpy restatement of model.py:15-26."""
+    rng = np.random.default_rng(1)
+    s = rng.random((40, 56)).astype(np.float32)
+    s[5, 5] = s[5, 9] = 2.0  # exact tie inside one window
+
+    def mp(a):
+        p = np.pad(a, 4, constant_values=-np.inf)
+        out = np.full_like(a, -np.inf)
+        for dy in range(9):
+            for dx in range(9):
+                out = np.maximum(out, p[dy:dy + a.shape[0], dx:dx + a.shape[1]])
+        return out
+
+    mask = s == mp(s)
+    for _ in range(2):
+        supp = mp(mask.astype(np.float32)) > 0
+        ss = np.where(supp, 0, s)
+        new = ss == mp(ss)
+        mask = mask | (new & ~supp)
+    ref = np.where(mask, s, 0).astype(np.float32)
+    assert np.array_equal(O.sp_nms(s), ref)
+
+
+def test_sp_postprocess_edge_cases(O, sp_blob):
+    Hs, Ws = 64, 80
+    desc = np.random.default_rng(2).standard_normal((8, 10, 256)).astype(np.float32)
+    zero = np.zeros((Hs, Ws), np.float32)
+    f, _ = O.sp_postprocess(zero, desc, O.SPConfig(1000, 0.0005, 4))
+    assert f.shape == (0, 259)                                     # empty frame
+    s = zero.copy()
+    s[2, 40] = 0.9      # inside the 4-px border: removed
+    # float(0.0005) widens to 0.000500000023748... > double 0.0005: the reference's
+    # float->double compare (src/super_point.cpp:201) keeps it; one ulp lower is dropped
+    s[10, 40] = np.nextafter(np.float32(0.0005), np.float32(0))
+    s[20, 10] = 0.7
+    s[30, 70] = 0.8
+    f, idx = O.sp_postprocess(s, desc, O.SPConfig(1000, 0.0005, 4))
+    assert [(int(r[1]), int(r[2])) for r in f] == [(10, 20), (70, 30)]   # raster order, (x, y)
+    f, _ = O.sp_postprocess(s, desc, O.SPConfig(1, 0.0005, 4))
+    assert f.shape[0] == 1 and (f[0, 1], f[0, 2]) == (70, 30)            # top-1 by score
+    m = np.zeros((Hs, Ws), np.uint8)
+    m[2, 40] = 1
+    f, _ = O.sp_postprocess(s, desc, O.SPConfig(1000, 0.0005, 4), mask=m)
+    assert f.shape[0] == 1 and (f[0, 1], f[0, 2]) == (40, 2)             # mask path skips the border test
+    # ties at the top-k boundary: lower raster index wins (the build's definition)
+    t = zero.copy()
+    t[10, 10] = t[10, 30] = t[20, 20] = 0.5
+    f, _ = O.sp_postprocess(t, desc, O.SPConfig(2, 0.0005, 4))
+    assert [(int(r[1]), int(r[2])) for r in f] == [(10, 10), (30, 10)]
+
+
+def test_sg_graph_matches_public_architecture(O, sg_blob):
+    """oracle SuperGlue vs the transformers implementation of the public graph
+    (fixture sg_n96.npz).  The reference's own graph is missing: unpinned."""
+    g = golden("sg_n96.npz")
+    nf0, nf1 = O.sg_normalize(g["f0"], 640, 512), O.sg_normalize(g["f1"], 640, 512)
+    Z, m0, m1 = O.sg_graph(sg_blob, 100, nf0, nf1, want_final=True)
+    scale = np.abs(g["final0"]).max()
+    assert np.abs(m0 - g["final0"]).max() < 1e-5 * scale and np.abs(m1 - g["final1"]).max() < 1e-5 * scale
+    assert np.abs(Z - g["Z"]).max() < 1e-3
+    i0, i1, ms0, ms1 = O.sg_decode(Z, 0.5)
+    j0, j1, _, _ = O.sg_decode(g["Z"], 0.5)
+    assert np.array_equal(i0, j0) and np.array_equal(i1, j1)
+    assert (i0[:40] == np.arange(40)).sum() >= 38   # planted matches are found
+
+
+def test_sg_decode_follows_reference_semantics(O):
+    """decode() src/super_glue.cpp:401-430 vs a brute-force restatement."""
+    rng = np.random.default_rng(3)
+    Z = np.log(rng.random((21, 31)).astype(np.float32) + 1e-3)
+    Z[3, 7] = Z[3, 9] = 0.0  # row tie: first max wins
+    Z[5, 2] = Z[8, 2] = -0.01
+    i0, i1, m0, m1 = O.sg_decode(Z, 0.5)
+    inner = Z[:-1, :-1]
+    a0 = np.array([int(np.argmax(r)) for r in inner])
+    a1 = np.array([int(np.argmax(inner[:, j])) for j in range(inner.shape[1])])
+    mutual0 = a1[a0] == np.arange(20)
+    ms0 = np.where(mutual0, np.exp(inner[np.arange(20), a0]), 0)
+    valid0 = mutual0 & (ms0 > 0.5)
+    assert np.array_equal(i0, np.where(valid0, a0, -1))
+    mutual1 = a0[a1] == np.arange(30)
+    assert np.array_equal(i1, np.where(mutual1 & valid0[a1], a1, -1))
+    np.testing.assert_allclose(m0, ms0, rtol=2e-7)
+    assert a0[3] == 7
+
+
+def test_normalize_keypoints_uses_integer_half_and_config_size(O):
+    f = np.zeros((2, 259))
+    f[:, 1] = [0, 639]
+    f[:, 2] = [0, 479]
+    g = O.sg_normalize(f, 641, 512)   # 641/2 -> 320 (integer division, src/point_matching.cc:71)
+    assert g[0, 1] == (0 - 320) / (641 * 0.7) and g[1, 2] == (479 - 256) / (641 * 0.7)
+
+
+def test_jacobi_null_vector_and_ransac_recover_inliers(O):
+    rng = np.random.default_rng(4)
+    n = 300
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(4, 8, n)]
+    K = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1.0]])
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([0.3, 0.02, 0.05])
+    p0 = (K @ X.T).T
+    p0 = p0[:, :2] / p0[:, 2:]
+    p1 = (K @ (R @ X.T + t[:, None])).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    p1 += rng.normal(0, 0.3, p1.shape)
+    out = rng.choice(n, 60, replace=False)
+    p1[out] += rng.uniform(20, 60, (60, 2))
+    score, inl, F = O.ransac_find_F(p0, p1, O.RansacConfig(200, 1.0, 0))
+    good = np.ones(n, bool)
+    good[out] = False
+    assert inl[good].mean() > 0.9 and inl[~good].mean() < 0.1
+    assert abs(np.linalg.det(F.astype(np.float64))) < 1e-6 * np.abs(F).max() ** 3   # rank 2
+    x0 = np.c_[p0, np.ones(n)]
+    x1 = np.c_[p1, np.ones(n)]
+    r = np.abs(np.einsum("ni,ij,nj->n", x1, F.astype(np.float64), x0))
+    assert np.median(r[good]) < 0.05 * np.median(r[~good])
+    # determinism and the <8 rule
+    s2, inl2, F2 = O.ransac_find_F(p0, p1, O.RansacConfig(200, 1.0, 0))
+    assert s2 == score and np.array_equal(inl, inl2) and np.array_equal(F, F2)
+    s3, inl3, _ = O.ransac_find_F(p0[:7], p1[:7], O.RansacConfig(200, 1.0, 0))
+    assert s3 == 0 and inl3.sum() == 0
+
+
+def test_match_points_end_to_end_on_planted_pairs(O, sg_blob):
+    rng = np.random.default_rng(5)
+    f0 = make_features(rng, 120)
+    f1 = make_features(rng, 100, planted_from=f0, m=60, shift=4)
+    cfg = O.SGConfig(640, 512, 0.5, 100)
+    rc = O.RansacConfig(200, 1.0, 0)
+    raw = O.match_points(sg_blob, cfg, rc, f0, f1, outlier_rejection=False)
+    rej = O.match_points(sg_blob, cfg, rc, f0, f1, outlier_rejection=True)
+    planted = [m for m in raw if m[0] == m[1] and m[0] < 60]
+    assert len(planted) >= 55
+    assert set(rej) <= set(raw) and len([m for m in rej if m[0] == m[1]]) >= 50
+    assert all(0.0 <= m[2] <= 0.5 for m in raw)          # distance = 1 - mscore, mscore > 0.5
+    assert O.match_points(sg_blob, cfg, rc, f0[:0], f1, True) == []     # empty side

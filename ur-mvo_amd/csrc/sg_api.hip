@@ -31,6 +31,7 @@ int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float
 
 constexpr int NP = kCap, LDC = 1028, SG_LAYERS = 18;
 enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC, PT_COUNT };
+// stage_ms[PT_COUNT] additionally reports the attention kernels' share of PT_GNN
 }  // namespace urf
 using namespace urf;
 
@@ -63,7 +64,8 @@ struct urf_pm {
   int *h_n = nullptr;
   const float **h_slotptrs = nullptr;
   hipEvent_t ev[PT_COUNT + 1];
-  float stage_ms[PT_COUNT];
+  hipEvent_t ev_attn[18][2];
+  float stage_ms[PT_COUNT + 1];
   bool ev_valid = false;
 };
 
@@ -189,6 +191,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_HIP(hipHostMalloc((void **)&h->h_n, P * sizeof(int), hipHostMallocDefault));
   URF_HIP(hipHostMalloc((void **)&h->h_slotptrs, NI * sizeof(float *), hipHostMallocDefault));
   for (int i = 0; i <= PT_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
+  for (int i = 0; i < 18; ++i) { URF_HIP(hipEventCreate(&h->ev_attn[i][0])); URF_HIP(hipEventCreate(&h->ev_attn[i][1])); }
   h->built = true;
   return 0;
 }
@@ -213,6 +216,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     (void)hipHostFree(h->h_n);
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 18; ++i) { (void)hipEventDestroy(h->ev_attn[i][0]); (void)hipEventDestroy(h->ev_attn[i][1]); }
     (void)hipStreamDestroy(h->st);
   }
   delete h;
@@ -250,7 +254,9 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   for (int l = 0; l < SG_LAYERS; ++l) {
     if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->L[l].wqkv, h->L[l].bqkv, 768, h->qkv, 768, false, nullptr))
       return -1;
+    if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
     if (launch_attn(h->qkv, h->counts, l & 1, h->o, NI, st)) return -1;
+    if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
     if (sg_linear(h, NI, h->o, 256, 256, nullptr, 0, 0, h->L[l].wm, h->L[l].bm, 256, h->msg, 256, false, nullptr))
       return -1;
     if (sg_linear(h, NI, h->x, 256, 512, h->msg, 256, 256, h->L[l].w1, h->L[l].b1, 512, h->hid, 512, true, nullptr))
@@ -284,6 +290,12 @@ static void pm_collect_times(urf_pm *h) {
     if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0.0f;
     h->stage_ms[i] = ms;
   }
+  float at = 0.0f;
+  for (int l = 0; l < 18; ++l) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, h->ev_attn[l][0], h->ev_attn[l][1]) == hipSuccess) at += ms;
+  }
+  h->stage_ms[PT_COUNT] = at;
   h->ev_valid = true;
 }
 
@@ -447,6 +459,6 @@ extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1
 extern "C" int urf_pm_stage_ms(urf_pm *h, float *ms, int n) {
   URF_CHECK(h && ms, "urf_pm_stage_ms: null");
   URF_CHECK(h->ev_valid, "no timed call yet (urf_set_profiling(1) before the call)");
-  for (int i = 0; i < n && i < PT_COUNT; ++i) ms[i] = h->stage_ms[i];
-  return PT_COUNT;
+  for (int i = 0; i < n && i <= PT_COUNT; ++i) ms[i] = h->stage_ms[i];
+  return PT_COUNT + 1;
 }

@@ -136,7 +136,7 @@ class SuperPoint:
 
 SP_STAGES = ["upload", "conv1a+1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa|Da",
              "convPb", "convDb", "softmax", "nms", "select", "desc_norm", "sample", "download"]
-PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac"]
+PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac", "attn(in gnn)"]
 
 
 class _PM:
