@@ -1,0 +1,50 @@
+// point_matching.h -- drop-in replacement of UR-MVO include/point_matching.h:7-25.
+#ifndef POINT_MATCHING_H_
+#define POINT_MATCHING_H_
+
+#include <iostream>
+#include <vector>
+
+#include "super_glue.h"
+
+class PointMatching {
+ public:
+  // src/point_matching.cc:6-12: a failed SuperGlue build is only reported
+  PointMatching(SuperGlueConfig &superglue_config) : superglue(superglue_config) {
+    _superglue_config = superglue_config;
+    if (!superglue_config.engine_file.empty() && !superglue.build())
+      std::cout << "Erron in superglue building" << std::endl;
+  }
+  bool build(const float *blob, size_t n_floats) { return superglue.build(blob, n_floats); }
+
+  // src/point_matching.cc:14-61
+  int MatchingPoints(const Eigen::Matrix<double, 259, Eigen::Dynamic> &features0,
+                     const Eigen::Matrix<double, 259, Eigen::Dynamic> &features1, std::vector<cv::DMatch> &matches,
+                     bool outlier_rejection = false) {
+    matches.clear();
+    if (!superglue.handle()) return 0;
+    std::vector<urf_dmatch> out(URF_MAX_KEYPOINTS);
+    const int n = urf_match(superglue.handle(), features0.data(), (int)features0.cols(), features1.data(),
+                            (int)features1.cols(), outlier_rejection ? 1 : 0, out.data(), URF_MAX_KEYPOINTS);
+    if (n < 0) { std::cout << "PointMatching: " << urf_last_error() << std::endl; return 0; }
+    for (int i = 0; i < n; ++i) matches.emplace_back(out[i].queryIdx, out[i].trainIdx, out[i].distance);
+    return (int)matches.size();
+  }
+
+  // src/point_matching.cc:63-76
+  Eigen::Matrix<double, 259, Eigen::Dynamic> NormalizeKeypoints(
+      const Eigen::Matrix<double, 259, Eigen::Dynamic> &features, int width, int height) {
+    Eigen::Matrix<double, 259, Eigen::Dynamic> norm_features;
+    norm_features.resize(259, features.cols());
+    urf_normalize_keypoints(features.data(), (int)features.cols(), width, height, norm_features.data());
+    return norm_features;
+  }
+
+ private:
+  SuperGlue superglue;
+  SuperGlueConfig _superglue_config;
+};
+
+typedef std::shared_ptr<PointMatching> PointMatchingPtr;
+
+#endif  // POINT_MATCHING_H_

@@ -1,0 +1,81 @@
+// super_glue.h -- drop-in replacement of UR-MVO include/super_glue.h:20-33,69.
+#ifndef SUPER_GLUE_H_
+#define SUPER_GLUE_H_
+
+#include <cstdio>
+#include <memory>
+#include <string>
+
+#if __has_include(<Eigen/Core>) && __has_include(<opencv2/opencv.hpp>)
+#include <Eigen/Core>
+#include <opencv2/opencv.hpp>
+#else
+#include "urf_compat.h"
+#endif
+#if __has_include("read_configs.h")
+#include "read_configs.h"
+#endif
+#include "urf.h"
+
+class SuperGlue {
+ public:
+  explicit SuperGlue(const SuperGlueConfig &superglue_config) : superglue_config_(superglue_config) {}
+  ~SuperGlue() { urf_pm_destroy(h_); }
+  SuperGlue(const SuperGlue &) = delete;
+  SuperGlue &operator=(const SuperGlue &) = delete;
+
+  bool build() {  // src/super_glue.cpp:21-147
+    if (h_) return true;
+    if (!create()) return false;
+    if (!deserialize_engine()) { urf_pm_destroy(h_); h_ = nullptr; return false; }
+    return true;
+  }
+  bool build(const float *blob, size_t n_floats) {
+    if (!create()) return false;
+    if (urf_pm_build(h_, blob, n_floats) != 0) { report("build"); urf_pm_destroy(h_); h_ = nullptr; return false; }
+    return true;
+  }
+
+  // src/super_glue.cpp:166-241; features carry NORMALISED keypoints
+  bool infer(const Eigen::Matrix<double, 259, Eigen::Dynamic> &features0,
+             const Eigen::Matrix<double, 259, Eigen::Dynamic> &features1, Eigen::VectorXi &indices0,
+             Eigen::VectorXi &indices1, Eigen::VectorXd &mscores0, Eigen::VectorXd &mscores1) {
+    if (!h_) return false;
+    const int n0 = (int)features0.cols(), n1 = (int)features1.cols();
+    Eigen::VectorXi i0, i1;
+    Eigen::VectorXd m0, m1;
+    i0.resize(n0); i1.resize(n1); m0.resize(n0); m1.resize(n1);
+    if (urf_sg_infer(h_, features0.data(), n0, features1.data(), n1, i0.data(), i1.data(), m0.data(), m1.data(),
+                     nullptr) != 0) {
+      report("infer");
+      return false;  // outputs untouched, like the reference on failure
+    }
+    indices0 = i0; indices1 = i1; mscores0 = m0; mscores1 = m1;
+    return true;
+  }
+
+  void save_engine() {}
+  bool deserialize_engine() {
+    if (!h_) return false;
+    if (urf_pm_build_file(h_, superglue_config_.engine_file.c_str()) != 0) { report("deserialize_engine"); return false; }
+    return true;
+  }
+  urf_pm *handle() { return h_; }
+
+ private:
+  bool create() {
+    urf_sg_config c{};
+    c.image_width = superglue_config_.image_width;
+    c.image_height = superglue_config_.image_height;
+    c.matching_threshold = superglue_config_.matching_threshold;
+    if (urf_pm_create(&c, &h_) != 0) { report("create"); return false; }
+    return true;
+  }
+  void report(const char *what) const { std::fprintf(stderr, "SuperGlue::%s: %s\n", what, urf_last_error()); }
+  SuperGlueConfig superglue_config_;
+  urf_pm *h_ = nullptr;
+};
+
+typedef std::shared_ptr<SuperGlue> SuperGluePtr;
+
+#endif  // SUPER_GLUE_H_

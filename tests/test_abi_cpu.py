@@ -89,3 +89,15 @@ def test_shard_and_pair_assignment(U):
     assert pairs == [(t - 1, t) for t in range(16)]       # every pair exactly once, in order
     with pytest.raises(AssertionError):
         D.shard_range(10, 0, 4)
+
+
+def test_cpp_shim_headers_compile_and_link(tmp_path):
+    """include/super_point.h, super_glue.h, point_matching.h (the kept C++ API)
+    compile against the C ABI and link with liburf_front.so."""
+    import subprocess
+    exe = str(tmp_path / "test_shim")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ur-mvo_amd")])
+    assert os.path.exists(exe)

@@ -246,3 +246,35 @@ def test_device_resident_batch_equals_host_path(U, F, sp_blob, sg_blob, sp640, p
     for j in range(8):
         assert dev[j] == pm.MatchingPoints(feats[j], feats[j + 1], True)
         assert len(dev[j]) > 300
+
+
+def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path):
+    """the reference's C++ classes (include/*.h shims), driven like
+    Tracking::ExtractFeatureAndMatch, give the same matches as the C-ABI path."""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "test_shim")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ur-mvo_amd")])
+    L = U._lib.lib()
+    spw, sgw = str(tmp_path / "sp.urfw"), str(tmp_path / "sg.urfw")
+    assert L.urf_weights_save(spw.encode(), 1, sp_blob.ctypes.data_as(C.c_void_p), C.c_size_t(sp_blob.size)) == 0
+    assert L.urf_weights_save(sgw.encode(), 2, sg_blob.ctypes.data_as(C.c_void_p), C.c_size_t(sg_blob.size)) == 0
+    H, W = 240, 320
+    fr = U.synth.shift_stream(1, 2, H, W)
+    f0p, f1p = str(tmp_path / "f0.raw"), str(tmp_path / "f1.raw")
+    fr[0].tofile(f0p)
+    fr[1].tofile(f1p)
+    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True).strip().split("\n")
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=400, engine_file=spw), max_height=H, max_width=W)
+    assert sp.build()                                     # engine_file path (deserialize_engine)
+    f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])
+    m = pm.MatchingPoints(f0, f1, True)
+    assert out[0] == f"K0={f0.shape[0]} K1={f1.shape[0]} matches={len(m)}"
+    got = [tuple(l.split()) for l in out[1:]]
+    assert [(int(a), int(b)) for a, b, _ in got] == [(q, t) for q, t, _ in m]
+    assert np.allclose([float(c) for _, _, c in got], [d for _, _, d in m], rtol=0, atol=1e-7)
