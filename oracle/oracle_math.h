@@ -97,4 +97,21 @@ static inline float om_wave_sum(const float *x, int n) {
   return om_bfly64_sum(p);
 }
 
+/* Canonical "wave-strided-by-4" sum (Sinkhorn LSE): lane l accumulates the
+   elements 256t + 4l + r (t ascending, r = 0..3) -- the order of 16-byte loads
+   per lane -- starting from +0, then the butterfly. */
+static inline float om_wave_sum4(const float *x, int n) {
+  float p[64];
+  for (int l = 0; l < 64; ++l) {
+    float a = 0.0f;
+    for (int t = 0; 256 * t + 4 * l < n; ++t)
+      for (int r = 0; r < 4; ++r) {
+        const int j = 256 * t + 4 * l + r;
+        if (j < n) a = a + x[j];
+      }
+    p[l] = a;
+  }
+  return om_bfly64_sum(p);
+}
+
 #endif

@@ -11,8 +11,9 @@
  * Deviations that are part of the written spec (DESIGN.md "RANSAC"):
  *  - glibc rand() after a process-global srand(0) is replaced by a counter
  *    hash rs_hash(seed, 8*it+j) so hypotheses are reproducible and parallel;
- *  - Eigen::JacobiSVD is replaced by a cyclic Jacobi eigen-solver on A^T A in
- *    double (null vector) and on F^T F (rank-2 projection F - (F v)v^T);
+ *  - Eigen::JacobiSVD is replaced by a fully pivoted Gaussian elimination of the
+ *    8x9 design matrix in double (null vector) and a cyclic Jacobi eigen-solver
+ *    on F^T F (rank-2 projection F - (F v)v^T);
  *  - float sums over the matches use the canonical wave-strided order.
  */
 #include "urf_oracle.h"
@@ -88,6 +89,49 @@ static int argmin_diag(const double *a, int n) {
   return m;
 }
 
+/* null vector of the 8x9 design matrix by Gaussian elimination with full
+   pivoting (f64).  For 8 points in general position rank(A) = 8 and the null
+   vector equals the smallest right-singular vector the reference takes from
+   Eigen::JacobiSVD (:267-273), up to sign.  Pivot search order: rows s..7 outer,
+   columns s..8 inner, strict '>' (first maximum wins). */
+static void null_vector_8x9(double A[8][9], double f[9]) {
+  int perm[9];
+  for (int c = 0; c < 9; ++c) perm[c] = c;
+  int rank = 8;
+  for (int s = 0; s < 8; ++s) {
+    double best = 0.0; int pr = -1, pc = -1;
+    for (int r = s; r < 8; ++r)
+      for (int c = s; c < 9; ++c) {
+        const double v = fabs(A[r][c]);
+        if (v > best) { best = v; pr = r; pc = c; }
+      }
+    if (pr < 0) { rank = s; break; }
+    if (pr != s) for (int c = 0; c < 9; ++c) { const double t = A[s][c]; A[s][c] = A[pr][c]; A[pr][c] = t; }
+    if (pc != s) {
+      for (int r = 0; r < 8; ++r) { const double t = A[r][s]; A[r][s] = A[r][pc]; A[r][pc] = t; }
+      const int t = perm[s]; perm[s] = perm[pc]; perm[pc] = t;
+    }
+    const double piv = A[s][s];
+    for (int r = s + 1; r < 8; ++r) {
+      const double m = A[r][s] / piv;
+      A[r][s] = 0.0;
+      for (int c = s + 1; c < 9; ++c) A[r][c] = A[r][c] - m * A[s][c];
+    }
+  }
+  double g[9];
+  for (int c = 0; c < 9; ++c) g[c] = 0.0;
+  g[rank] = 1.0;
+  for (int s = rank - 1; s >= 0; --s) {
+    double sum = 0.0;
+    for (int c = s + 1; c < 9; ++c) sum = sum + A[s][c] * g[c];
+    g[s] = -sum / A[s][s];
+  }
+  double ss = 0.0;
+  for (int c = 0; c < 9; ++c) ss = ss + g[c] * g[c];
+  const double inv = 1.0 / sqrt(ss);
+  for (int c = 0; c < 9; ++c) f[perm[c]] = g[c] * inv;
+}
+
 /* _compute_F21 :247-283 on 8 normalised pairs -> Fn (row-major, double) */
 static void compute_F21(const float *p1, const float *p2, double Fn[9]) {
   double A[8][9];
@@ -98,17 +142,10 @@ static void compute_F21(const float *p1, const float *p2, double Fn[9]) {
     A[i][3] = (double)(v2 * u1); A[i][4] = (double)(v2 * v1); A[i][5] = (double)v2;
     A[i][6] = (double)u1;        A[i][7] = (double)v1;        A[i][8] = 1.0;
   }
-  double ata[81], V[81];
-  for (int r = 0; r < 9; ++r)
-    for (int c = 0; c < 9; ++c) {
-      double s = 0.0;
-      for (int i = 0; i < 8; ++i) s = s + A[i][r] * A[i][c];
-      ata[r * 9 + c] = s;
-    }
-  jacobi_sym(ata, V, 9);
-  const int m = argmin_diag(ata, 9);
   double Fpre[9];
-  for (int k = 0; k < 9; ++k) Fpre[k] = V[k * 9 + m]; /* row-major 3x3 (:273) */
+  null_vector_8x9(A, Fpre); /* row-major 3x3 (:273) */
+  /* rank-2 enforcement (:275-282): F - (F v) v^T, v = weakest right-singular
+     vector of F = eigenvector of F^T F (cyclic Jacobi, 3x3) */
   double g[9], W[9];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) {

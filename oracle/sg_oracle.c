@@ -183,12 +183,12 @@ static void encode(const sg_weights *w, const double *f, int n, float *x) {
   free(a); free(b);
 }
 
-/* LSE over a row of length n of (c[j] + add[j]); canonical wave-strided sum */
+/* LSE over a row of length n of (c[j] + add[j]); canonical wave-strided-by-4 sum */
 static float row_lse(const float *c, const float *add, int n, float *tmp) {
   float m = -FLT_MAX;
   for (int j = 0; j < n; ++j) { tmp[j] = c[j] + add[j]; m = tmp[j] > m ? tmp[j] : m; }
   for (int j = 0; j < n; ++j) tmp[j] = om_exp(tmp[j] - m);
-  return m + om_log(om_wave_sum(tmp, n));
+  return m + om_log(om_wave_sum4(tmp, n));
 }
 
 /* log_optimal_transport + log_sinkhorn_iterations, src/super_glue.cpp:432-498

@@ -73,10 +73,87 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   const int aoff = g * W_STRIDE + px;
 
   const int nchunks = FUSE1A ? 1 : (a.Cin + 63) / 64;
+
+  // ---- register prefetch (issue early, commit to LDS late): weights of the next
+  // (chunk, tap) stage and, for TAPS==1, the next chunk's input rows fly while
+  // the MFMAs of the current stage run.
+  f32x4 wpf[4];
+  auto issue_w = [&](int ch, int tap) {
+    const int c0 = ch * 64;
+    const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
+    const float *wsrc = a.w + ((size_t)tap * a.Cin + c0) * a.Cout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      const int k = i >> 4, j = i & 15;
+      const int co = cout_base + 4 * j;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (k < kc) {
+        const float *sp = wsrc + (size_t)k * a.Cout + co;
+        if (co + 3 < a.Cout && ((a.Cout & 3) == 0)) {
+          v = *(const f32x4 *)sp;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (co + r < a.Cout) ? sp[r] : 0.0f;
+        }
+      }
+      wpf[u] = v;
+    }
+  };
+  auto commit_w = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      *(f32x4 *)(w_tile + (i >> 4) * W_STRIDE + 4 * (i & 15)) = wpf[u];
+    }
+  };
+  f32x4 ipf[8];  // TAPS==1 only: 128 rows x (kc/4) float4
+  auto issue_in = [&](int ch) {
+    const int c0 = ch * 64;
+    const int kc = (a.Cin - c0) < 64 ? (a.Cin - c0) : 64;
+    const int vpp = kc >> 2;                    // power of two (kc in {4,8,16,32,64})
+    const int vsh = 31 - __builtin_clz(vpp);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 256 * u;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (i < TH * TW * vpp) {
+        const int p = i >> vsh, j = i & (vpp - 1);
+        const int cc = c0 + 4 * j, row = x0 + p;
+        if (row < a.W) {
+          const float *src;
+          if (a.in2 && cc >= a.Cin1)
+            src = a.in2 + (size_t)b * a.in2_bstride + (size_t)row * a.in2_ld + a.in2_coff + (cc - a.Cin1);
+          else
+            src = (const float *)a.in + (size_t)b * a.in_bstride + (size_t)row * a.in_ld + a.in_coff + cc;
+          v = *(const f32x4 *)src;
+        }
+      }
+      ipf[u] = v;
+    }
+  };
+  auto commit_in = [&](int ch) {
+    const int c0 = ch * 64;
+    const int kc = (a.Cin - c0) < 64 ? (a.Cin - c0) : 64;
+    const int vpp = kc >> 2;
+    const int vsh = 31 - __builtin_clz(vpp);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 256 * u;
+      if (i < TH * TW * vpp) {
+        const int p = i >> vsh, j = i & (vpp - 1);
+        float *dst = in_tile + p * IN_STRIDE + 4 * j;
+        *(float2 *)dst = make_float2(ipf[u][0], ipf[u][1]);
+        *(float2 *)(dst + 2) = make_float2(ipf[u][2], ipf[u][3]);
+      }
+    }
+  };
+
+  issue_w(0, 0);
+  if (TAPS == 1) issue_in(0);
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * 64;
     const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
-    __syncthreads();  // previous chunk fully consumed
     if (FUSE1A) {
       // ---- fused conv1a: u8 patch -> f32 -> 3x3 conv (VALU fma chain) -> relu
       const uint8_t *img = (const uint8_t *)a.in + (size_t)b * a.in_bstride;
@@ -104,76 +181,67 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
         }
         in_tile[p * IN_STRIDE + c] = v;
       }
-    } else {
+    } else if (TAPS == 9) {
       // ---- stage the input tile chunk: each pixel's kc channels are contiguous
-      const int vec_per_pix = kc >> 2;  // float4 per pixel
+      // (the previous chunk's last barrier already freed in_tile)
+      const int vec_per_pix = kc >> 2;
+      const int vsh9 = 31 - __builtin_clz(vec_per_pix);
       const int total = PH * PW * vec_per_pix;
       for (int i = tid; i < total; i += 256) {
-        const int p = i / vec_per_pix, j = i - p * vec_per_pix;
+        const int p = i >> vsh9, j = i & (vec_per_pix - 1);
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         const int cc = c0 + 4 * j;
-        if (TAPS == 9) {
-          const int yy = y0 - 1 + p / PW, xx = x0 - 1 + p % PW;
-          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-            const float *src = (const float *)a.in + (size_t)b * a.in_bstride +
-                               ((size_t)yy * a.W + xx) * a.in_ld + a.in_coff + cc;
-            v = *(const f32x4 *)src;
-          }
-        } else {
-          const int row = x0 + p;
-          if (row < a.W) {
-            const float *src;
-            if (a.in2 && cc >= a.Cin1)
-              src = a.in2 + (size_t)b * a.in2_bstride + (size_t)row * a.in2_ld + a.in2_coff + (cc - a.Cin1);
-            else
-              src = (const float *)a.in + (size_t)b * a.in_bstride + (size_t)row * a.in_ld + a.in_coff + cc;
-            v = *(const f32x4 *)src;
-          }
+        const int yy = y0 - 1 + p / PW, xx = x0 - 1 + p % PW;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          const float *src = (const float *)a.in + (size_t)b * a.in_bstride +
+                             ((size_t)yy * a.W + xx) * a.in_ld + a.in_coff + cc;
+          v = *(const f32x4 *)src;
         }
         float *dst = in_tile + p * IN_STRIDE + 4 * j;  // 8-byte aligned
         *(float2 *)dst = make_float2(v[0], v[1]);
         *(float2 *)(dst + 2) = make_float2(v[2], v[3]);
       }
+    } else {
+      commit_in(ch);
     }
 
     for (int tap = 0; tap < TAPS; ++tap) {
-      if (tap > 0) __syncthreads();  // w_tile free again
-      // ---- stage weights [kc][64] of this (chunk, tap)
-      {
-        const float *wsrc = a.w + ((size_t)tap * a.Cin + c0) * a.Cout;
-        for (int i = tid; i < kc * 16; i += 256) {
-          const int k = i >> 4, j = i & 15;
-          const int co = cout_base + 4 * j;
-          f32x4 v;
-          const float *s = wsrc + (size_t)k * a.Cout + co;
-          if (co + 3 < a.Cout && ((a.Cout & 3) == 0)) {
-            v = *(const f32x4 *)s;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (co + r < a.Cout) ? s[r] : 0.0f;
-          }
-          *(f32x4 *)(w_tile + k * W_STRIDE + 4 * j) = v;
+      commit_w();
+      __syncthreads();  // in_tile + w_tile of this stage visible
+      {                 // prefetch the next stage
+        const bool last_tap = (tap + 1 == TAPS);
+        if (!last_tap) issue_w(ch, tap + 1);
+        else if (ch + 1 < nchunks) {
+          issue_w(ch + 1, 0);
+          if (TAPS == 1) issue_in(ch + 1);
         }
       }
-      __syncthreads();
       const int toff = (TAPS == 9) ? ((tap / 3) * PW + (tap % 3)) * IN_STRIDE : 0;
       const float *bp0 = in_tile + bpix[0] + toff;
       const float *bp1 = in_tile + bpix[1] + toff;
       const float *ap = w_tile + aoff;
-#pragma unroll 4
-      for (int k = 0; k < kc; k += 4) {
-        const float b0 = bp0[k], b1 = bp1[k];
-        const float a0 = ap[k * W_STRIDE], a1 = ap[k * W_STRIDE + 16], a2 = ap[k * W_STRIDE + 32],
-                    a3 = ap[k * W_STRIDE + 48];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, acc[2][0], 0, 0, 0);
-        acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b0, acc[3][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-        acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, acc[2][1], 0, 0, 0);
-        acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b1, acc[3][1], 0, 0, 0);
+#define URF_KSTEP(k)                                                                              \
+  {                                                                                               \
+    const float b0 = bp0[k], b1 = bp1[k];                                                         \
+    const float a0 = ap[(k) * W_STRIDE], a1 = ap[(k) * W_STRIDE + 16], a2 = ap[(k) * W_STRIDE + 32], \
+                a3 = ap[(k) * W_STRIDE + 48];                                                     \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);                 \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);                 \
+    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, acc[2][0], 0, 0, 0);                 \
+    acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b0, acc[3][0], 0, 0, 0);                 \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);                 \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);                 \
+    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, acc[2][1], 0, 0, 0);                 \
+    acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b1, acc[3][1], 0, 0, 0);                 \
+  }
+      if (kc == 64) {  // fast path: fully unrolled, LDS operand reads run ahead of the MFMAs
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) URF_KSTEP(k)
+      } else {
+        for (int k = 0; k < kc; k += 4) URF_KSTEP(k)
       }
+#undef URF_KSTEP
+      __syncthreads();  // every wave is done with w_tile (and in_tile after the last tap)
     }
   }
 

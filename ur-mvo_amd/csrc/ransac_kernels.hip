@@ -4,7 +4,8 @@
 // runs the in-tree routine EpipolarGeometry::_find_F / _normalize /
 // _compute_F21 / _check_F (src/epipolar_geometry.cc:161-205,735-780,247-283,
 // 372-449) with the deviations listed in DESIGN.md "RANSAC" (counter-hash
-// sampler, Jacobi eigen-solver in double, canonical wave-order float sums).
+// sampler, pivoted elimination + 3x3 Jacobi in double, canonical wave-order
+// float sums).
 //
 // Kernels: normalise (1 wave per point set) -> one thread per hypothesis
 // (8-point solve, double) -> one wave per hypothesis (score all matches) ->
@@ -46,77 +47,143 @@ __device__ void draw_set(uint32_t seed, int it, int n, int set[8]) {
 }
 
 #define JAC_SWEEPS 12
-__device__ void jacobi_sym(double *a, double *v, int n) {
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+// cyclic Jacobi on a symmetric 3x3 (double); fully unrolled -> registers
+__device__ __forceinline__ void jacobi_sym3(double *a, double *v) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[i * 3 + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < JAC_SWEEPS; ++sweep) {
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = a[p * n + q];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = a[p * 3 + q];
         if (fabs(apq) < 1e-300) continue;
-        const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+        const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
         const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
         const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          const double akp = a[k * n + p], akq = a[k * n + q];
-          a[k * n + p] = c * akp - s * akq;
-          a[k * n + q] = s * akp + c * akq;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+          a[k * 3 + p] = c * akp - s * akq;
+          a[k * 3 + q] = s * akp + c * akq;
         }
-        for (int k = 0; k < n; ++k) {
-          const double apk = a[p * n + k], aqk = a[q * n + k];
-          a[p * n + k] = c * apk - s * aqk;
-          a[q * n + k] = s * apk + c * aqk;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+          a[p * 3 + k] = c * apk - s * aqk;
+          a[q * 3 + k] = s * apk + c * aqk;
         }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = v[k * n + p], vkq = v[k * n + q];
-          v[k * n + p] = c * vkp - s * vkq;
-          v[k * n + q] = s * vkp + c * vkq;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = v[k * 3 + p], vkq = v[k * 3 + q];
+          v[k * 3 + p] = c * vkp - s * vkq;
+          v[k * 3 + q] = s * vkp + c * vkq;
         }
       }
   }
 }
-__device__ int argmin_diag(const double *a, int n) {
+
+// Null vector of the 8x9 design matrix by fully pivoted Gaussian elimination
+// (f64).  The matrix lives in LDS as A(r,c) = lds[(r*9+c)*64 + lane] so the
+// data-dependent row/column indices cost no scratch traffic and no bank
+// conflicts (the bank depends on the lane only).
+#define RA(r, c) lA[((r) * 9 + (c)) * 64]
+__device__ void null_vector_8x9(double *lA, int *lperm, double f[9]) {
+  for (int c = 0; c < 9; ++c) lperm[c * 64] = c;
+  int rank = 8;
+  for (int s = 0; s < 8; ++s) {
+    double best = 0.0;
+    int pr = -1, pc = -1;
+    for (int r = s; r < 8; ++r)
+      for (int c = s; c < 9; ++c) {
+        const double v = fabs(RA(r, c));
+        if (v > best) { best = v; pr = r; pc = c; }
+      }
+    if (pr < 0) { rank = s; break; }
+    if (pr != s)
+      for (int c = 0; c < 9; ++c) { const double t = RA(s, c); RA(s, c) = RA(pr, c); RA(pr, c) = t; }
+    if (pc != s) {
+      for (int r = 0; r < 8; ++r) { const double t = RA(r, s); RA(r, s) = RA(r, pc); RA(r, pc) = t; }
+      const int t = lperm[s * 64]; lperm[s * 64] = lperm[pc * 64]; lperm[pc * 64] = t;
+    }
+    const double piv = RA(s, s);
+    for (int r = s + 1; r < 8; ++r) {
+      const double m = RA(r, s) / piv;
+      RA(r, s) = 0.0;
+      for (int c = s + 1; c < 9; ++c) RA(r, c) = RA(r, c) - m * RA(s, c);
+    }
+  }
+  // back substitution; g reuses row 0.. of a second LDS strip: keep it in registers
+  double g[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) g[c] = (c == rank) ? 1.0 : 0.0;
+#pragma unroll
+  for (int s = 7; s >= 0; --s) {
+    if (s < rank) {
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c)
+        if (c > s) sum = sum + RA(s, c) * g[c];
+      g[s] = -sum / RA(s, s);
+    }
+  }
+  double ss = 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ss = ss + g[c] * g[c];
+  const double inv = 1.0 / sqrt(ss);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int pc = lperm[c * 64];
+    const double val = g[c] * inv;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (k == pc) f[k] = val;
+  }
+}
+
+__device__ __forceinline__ int argmin_diag3(const double *a) {
   int m = 0;
-  for (int i = 1; i < n; ++i) if (a[i * n + i] < a[m * n + m]) m = i;
+  if (a[4] < a[0]) m = 1;
+  if (a[8] < a[m * 3 + m]) m = 2;
   return m;
 }
 
-// _compute_F21 (:247-283): null vector of A (8x9) via Jacobi on A^T A, rank-2
-// projection F - (F v) v^T with v the weakest right-singular vector of F.
-__device__ void compute_F21(const float *p1, const float *p2, double Fn[9]) {
-  double A[8][9];
+// _compute_F21 (:247-283)
+__device__ void compute_F21(const float *p1, const float *p2, double *lA, int *lperm, double Fn[9]) {
   for (int i = 0; i < 8; ++i) {
     const float u1 = p1[2 * i], v1 = p1[2 * i + 1], u2 = p2[2 * i], v2 = p2[2 * i + 1];
-    A[i][0] = (double)(u2 * u1); A[i][1] = (double)(u2 * v1); A[i][2] = (double)u2;
-    A[i][3] = (double)(v2 * u1); A[i][4] = (double)(v2 * v1); A[i][5] = (double)v2;
-    A[i][6] = (double)u1;        A[i][7] = (double)v1;        A[i][8] = 1.0;
+    RA(i, 0) = (double)(u2 * u1); RA(i, 1) = (double)(u2 * v1); RA(i, 2) = (double)u2;
+    RA(i, 3) = (double)(v2 * u1); RA(i, 4) = (double)(v2 * v1); RA(i, 5) = (double)v2;
+    RA(i, 6) = (double)u1;        RA(i, 7) = (double)v1;        RA(i, 8) = 1.0;
   }
-  double ata[81], V[81];
-  for (int r = 0; r < 9; ++r)
-    for (int c = 0; c < 9; ++c) {
-      double s = 0.0;
-      for (int i = 0; i < 8; ++i) s = s + A[i][r] * A[i][c];
-      ata[r * 9 + c] = s;
-    }
-  jacobi_sym(ata, V, 9);
-  const int m = argmin_diag(ata, 9);
   double Fpre[9];
-  for (int k = 0; k < 9; ++k) Fpre[k] = V[k * 9 + m];
+  null_vector_8x9(lA, lperm, Fpre);
   double g[9], W[9];
+#pragma unroll
   for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       double s = 0.0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) s = s + Fpre[k * 3 + r] * Fpre[k * 3 + c];
       g[r * 3 + c] = s;
     }
-  jacobi_sym(g, W, 3);
-  const int m3 = argmin_diag(g, 3);
-  double vv[3] = {W[0 * 3 + m3], W[1 * 3 + m3], W[2 * 3 + m3]}, fv[3];
+  jacobi_sym3(g, W);
+  const int m3 = argmin_diag3(g);
+  double vv[3], fv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vv[k] = (m3 == 0) ? W[k * 3] : ((m3 == 1) ? W[k * 3 + 1] : W[k * 3 + 2]);
+#pragma unroll
   for (int r = 0; r < 3; ++r)
     fv[r] = (Fpre[r * 3 + 0] * vv[0] + Fpre[r * 3 + 1] * vv[1]) + Fpre[r * 3 + 2] * vv[2];
+#pragma unroll
   for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 3; ++c) Fn[r * 3 + c] = Fpre[r * 3 + c] - fv[r] * vv[c];
 }
+#undef RA
 
 __device__ void mat3_mul_f(const float *a, const float *b, float *o) {
   for (int i = 0; i < 3; ++i)
@@ -160,6 +227,8 @@ __global__ void __launch_bounds__(128) ransac_normalize_kernel(const int *nmatch
 __global__ void __launch_bounds__(64) ransac_hyp_kernel(const int *nmatch, const float *pn0, const float *pn1,
                                                         const float *T, uint32_t seed, int iters,
                                                         float *F /*[P][iters][9]*/) {
+  __shared__ double lA[72 * 64];
+  __shared__ int lperm[9 * 64];
   const int p = blockIdx.y, it = blockIdx.x * 64 + threadIdx.x;
   const int n = nmatch[p];
   if (it >= iters || n < 8) return;
@@ -172,7 +241,7 @@ __global__ void __launch_bounds__(64) ransac_hyp_kernel(const int *nmatch, const
     b[2 * j] = q1[2 * set[j]]; b[2 * j + 1] = q1[2 * set[j] + 1];
   }
   double Fn[9];
-  compute_F21(a, b, Fn);
+  compute_F21(a, b, lA + threadIdx.x, lperm + threadIdx.x, Fn);
   float Fnf[9], M[9], T2t[9];
   const float *T1 = T + ((size_t)p * 2) * 9, *T2 = T1 + 9;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2t[i * 3 + j] = T2[j * 3 + i];

@@ -63,9 +63,27 @@ __global__ void __launch_bounds__(256) sg_prep_slots_kernel(const float *const *
 //   each 16-block in the order 0,4,8,12,1,5,... (canonical).
 constexpr int KSTR = 66, VSTR = 68;
 
+// exp_c restricted to x <= 0 (softmax arguments): identical results to exp_c,
+// the upper clamp is dead and the 2^n scaling is one exact v_ldexp_f32.
+__device__ __forceinline__ float exp_c_nonpos(float x) {
+  float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = fma_rn(n, -0.693359375f, x);
+  r = fma_rn(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fma_rn(p, r, 1.3981999507e-3f);
+  p = fma_rn(p, r, 8.3334519073e-3f);
+  p = fma_rn(p, r, 4.1665795894e-2f);
+  p = fma_rn(p, r, 1.6666665459e-1f);
+  p = fma_rn(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = fma_rn(p, r2, r) + 1.0f;
+  const float v = __builtin_ldexpf(y, (int)n);
+  return x < -87.33654f ? 0.0f : v;
+}
+
 __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
                                                       int cross, float *o /*[img][NP][256]*/) {
-  __shared__ __attribute__((aligned(16))) float kv[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float kv[2][64 * VSTR];
   const int im = blockIdx.z, sm = cross ? (im ^ 1) : im;
   const int head = blockIdx.y;
   const int nq = counts[im], ns = counts[sm];
@@ -76,7 +94,33 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][N
   const float *qb = qkv + ((size_t)im * NP) * 768 + head * 64;
   const float *kb = qkv + ((size_t)sm * NP) * 768 + 256 + head * 64;
   const float *vb = qkv + ((size_t)sm * NP) * 768 + 512 + head * 64;
+  const int nchunk = (ns + 63) >> 6;
 
+  // staging: thread handles float4 #(tid&15) of keys (tid>>4) + 16u, u = 0..3
+  const int sj = tid & 15, sr = tid >> 4;
+  f32x4 pf[4];
+  auto issue = [&](const float *base, int ch) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = ch * 64 + sr + 16 * u;
+      pf[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (key < ns) pf[u] = *(const f32x4 *)(base + (size_t)key * 768 + 4 * sj);
+    }
+  };
+  auto commit_k = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float *dst = kv[buf] + (sr + 16 * u) * KSTR + 4 * sj;
+      *(float2 *)dst = make_float2(pf[u][0], pf[u][1]);
+      *(float2 *)(dst + 2) = make_float2(pf[u][2], pf[u][3]);
+    }
+  };
+  auto commit_v = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *(f32x4 *)(kv[buf] + (sr + 16 * u) * VSTR + 4 * sj) = pf[u];
+  };
+
+  issue(kb, 0);
   // Q fragment: B[k = g][col = px] = Q[q0 + 16*wave + px][4*s + g]
   float qreg[16];
   {
@@ -84,40 +128,41 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][N
 #pragma unroll
     for (int s = 0; s < 16; ++s) qreg[s] = qr[4 * s];
   }
+  commit_k(0);
+  __syncthreads();
+
   f32x4 sreg[64];
-  const int nchunk = (ns + 63) >> 6;
-  // ---------------- phase 1
+  // ---------------- phase 1: S^T = K Q^T, 4 key tiles in flight per k-step
 #pragma unroll
   for (int ch = 0; ch < 16; ++ch) {
     if (ch < nchunk) {
-      __syncthreads();
-      for (int i = tid; i < 64 * 16; i += 256) {  // stage K chunk [64 keys][64 d]
-        const int r = i >> 4, j = i & 15;
-        const int key = ch * 64 + r;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (key < ns) v = *(const f32x4 *)(kb + (size_t)key * 768 + 4 * j);
-        float *dst = kv + r * KSTR + 4 * j;
-        *(float2 *)dst = make_float2(v[0], v[1]);
-        *(float2 *)(dst + 2) = make_float2(v[2], v[3]);
+      if (ch + 1 < nchunk) issue(kb, ch + 1);
+      f32x4 acc[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      const float *ap = kv[ch & 1] + px * KSTR + g;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kt * 16 * KSTR + 4 * s], qreg[s], acc[kt], 0, 0, 0);
       }
-      __syncthreads();
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float *ap = kv + (kt * 16 + px) * KSTR + g;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], qreg[s], acc, 0, 0, 0);
         const int kbase = ch * 64 + kt * 16 + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (kbase + r < ns) ? acc[r] * 0.125f : -FLT_MAX;
-        sreg[ch * 4 + kt] = acc;
+        for (int r = 0; r < 4; ++r) acc[kt][r] = (kbase + r < ns) ? acc[kt][r] * 0.125f : -FLT_MAX;
+        sreg[ch * 4 + kt] = acc[kt];
       }
+      if (ch + 1 < nchunk) commit_k((ch + 1) & 1);
+      __syncthreads();
     } else {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) sreg[ch * 4 + kt] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     }
   }
-  // ---------------- softmax over keys (per query = per px; 4 lanes g share it)
+  issue(vb, 0);  // V chunk 0 flies while the row max is reduced
+  // ---------------- row max (per query = per px; the 4 lanes g share it)
   float m = -FLT_MAX;
 #pragma unroll
   for (int t = 0; t < 64; ++t)
@@ -125,52 +170,47 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][N
     for (int r = 0; r < 4; ++r) m = fmaxf(m, sreg[t][r]);
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
+  commit_v(0);
+  __syncthreads();
+  // ---------------- phase 2: p = exp_c(s - m) one tile ahead of its O^T += V^T P^T
   float part = 0.0f;
 #pragma unroll
-  for (int t = 0; t < 64; ++t) {
-    if (t * 16 < ns) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s = sreg[t][r];
-        const float p = (s == -FLT_MAX) ? 0.0f : exp_c(s - m);
-        sreg[t][r] = p;
-        part = part + p;
-      }
-    }
-  }
-  float l = part + __shfl_xor(part, 16, 64);
-  l = l + __shfl_xor(l, 32, 64);
-  // ---------------- phase 2
+  for (int r = 0; r < 4; ++r) { const float p = exp_c_nonpos(sreg[0][r] - m); sreg[0][r] = p; part = part + p; }
   f32x4 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int ch = 0; ch < 16; ++ch) {
     if (ch < nchunk) {
-      __syncthreads();
-      for (int i = tid; i < 64 * 16; i += 256) {  // stage V chunk [64 keys][64 d]
-        const int r = i >> 4, j = i & 15;
-        const int key = ch * 64 + r;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (key < ns) v = *(const f32x4 *)(vb + (size_t)key * 768 + 4 * j);
-        *(f32x4 *)(kv + r * VSTR + 4 * j) = v;
-      }
-      __syncthreads();
+      if (ch + 1 < nchunk) issue(vb, ch + 1);
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        if ((ch * 4 + kt) * 16 < ns) {
+        const int T = ch * 4 + kt;
+        if (T * 16 < ns) {
+          if (T + 1 < 64 && (T + 1) * 16 < ns) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = exp_c_nonpos(sreg[T + 1 < 64 ? T + 1 : 63][r] - m);
+              sreg[T + 1 < 64 ? T + 1 : 63][r] = p;
+              part = part + p;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pb = sreg[ch * 4 + kt][r];
-            const float *ap = kv + (kt * 16 + 4 * g + r) * VSTR + px;
+            const float pb = sreg[T][r];
+            const float *ap = kv[ch & 1] + (kt * 16 + 4 * g + r) * VSTR + px;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
               oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[dt * 16], pb, oacc[dt], 0, 0, 0);
           }
         }
       }
+      if (ch + 1 < nchunk) commit_v((ch + 1) & 1);
+      __syncthreads();
     }
   }
+  float l = part + __shfl_xor(part, 16, 64);
+  l = l + __shfl_xor(l, 32, 64);
   const int q = q0 + wave * 16 + px;
   float *op = o + ((size_t)im * NP + q) * 256 + head * 64 + 4 * g;
 #pragma unroll
@@ -257,33 +297,50 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 
 // One Sinkhorn half-iteration (src/super_glue.cpp:436-451, max-stabilised):
 //   out[r] = log_marg[r] - LSE_c( M[r][c] + add[c] ),  r < R, c < Cn
-// One wave per row; lane l holds columns l, l+64, ... (<= 17); the sum is the
-// canonical wave-strided sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
+// One wave per row.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
+// per row); `add` is staged once per workgroup in LDS; the sum is the canonical
+// wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
 template <bool ROWPASS>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
+  __shared__ __attribute__((aligned(16))) float sadd[LDC + 256];
   const int p = blockIdx.y;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
+  if (blockIdx.x * 4 >= R) return;
+  const float *ad = add + (size_t)p * LDC;
+  for (int i = threadIdx.x; i < (LDC + 256) / 4; i += 256) {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (4 * i < LDC) v = *(const f32x4 *)(ad + 4 * i);
+    *(f32x4 *)(sadd + 4 * i) = v;
+  }
+  __syncthreads();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const int lane = threadIdx.x & 63;
   const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)row * LDC;
-  const float *ad = add + (size_t)p * LDC;
-  float x[17];
+  f32x4 x[5];
   float m = -FLT_MAX;
 #pragma unroll
-  for (int t = 0; t < 17; ++t) {
-    const int c = lane + 64 * t;
-    x[t] = -FLT_MAX;
-    if (c < Cn) { x[t] = mr[c] + ad[c]; m = fmaxf(m, x[t]); }
+  for (int t = 0; t < 5; ++t) {
+    const int c = 256 * t + 4 * lane;
+    x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (c < Cn) {  // LDC = 1028 >= c + 4: the 16-byte load stays inside the row
+      const f32x4 mv = *(const f32x4 *)(mr + c);
+      const f32x4 av = *(const f32x4 *)(sadd + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (c + r < Cn) { x[t][r] = mv[r] + av[r]; m = fmaxf(m, x[t][r]); }
+    }
   }
   m = bfly64_max(m);
   float s = 0.0f;
 #pragma unroll
-  for (int t = 0; t < 17; ++t) {
-    const int c = lane + 64 * t;
-    if (c < Cn) s = s + exp_c(x[t] - m);
+  for (int t = 0; t < 5; ++t) {
+    const int c = 256 * t + 4 * lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < Cn) s = s + exp_c_nonpos(x[t][r] - m);
   }
   s = bfly64_sum(s);
   if (lane == 0) {
