@@ -87,52 +87,56 @@ def main():
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
     del stream
     slot_floats = U._lib.lib().urf_slot_bytes() // 4
-    ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)   # local slots, 3-deep ring
+    # feature slots of the last 3 global batches (ring): matching batch b needs the
+    # last slot of batch b-1 while SuperPoint already fills the slots of batch b+1
+    ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)
     gathered = [None] * NB
-    carry = torch.zeros((slot_floats,), dtype=torch.float32, device=dev)      # last frame of the previous batch
     torch.cuda.synchronize()
     F.set_profiling(True)
+    # SuperPoint and the matcher share ONE in-order HIP stream:
+    #   SP(b) -> match(b) -> SP(b+1) -> match(b+1) ...
+    # The host enqueues one step ahead and only waits (event) for the match lists
+    # it reads, so the GPU never idles and HIP-event stage times are not blurred by
+    # cross-stream contention.
+    pm.share_stream(sp)
 
     def sp_step(b):
         k = b % NB
         sp.infer_device(d_frames[k * BATCH].data_ptr(), BATCH, H, W, ring[k].data_ptr())
 
-    def pm_step(b):
-        """match the pairs this rank owns in global batch b; returns nothing (async)."""
+    def slots_of(b):
         k = b % NB
-        if world == 1:
-            allslots = ring[k]
-            base = 0
-        else:
-            allslots = gathered[k]
-            base = rank * BATCH
+        return (ring[k], 0) if world == 1 else (gathered[k], rank * BATCH)
+
+    def pm_step(b):
+        """enqueue the matching of the pairs this rank owns in global batch b"""
+        cur, base = slots_of(b)
+        prev_all = slots_of(b - 1)[0] if b > 0 else None
         s0, s1 = [], []
         for j in range(BATCH):
             g = base + j
-            prev = allslots[g - 1].data_ptr() if g > 0 else carry.data_ptr()
-            s0.append(prev)
-            s1.append(allslots[g].data_ptr())
+            if g > 0:
+                s0.append(cur[g - 1].data_ptr())
+            elif prev_all is not None:
+                s0.append(prev_all[-1].data_ptr())      # globally last frame of the previous batch
+            else:
+                s0.append(cur[g].data_ptr())            # very first frame of the stream: matched with itself
+            s1.append(cur[g].data_ptr())
         pm.match_device_async(s0, s1, True)
 
     sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
     n_matches = []
 
     def one_step(b, record):
-        """steady state: PM(b) on the pm stream overlaps SP(b+1) on the sp stream"""
-        k = b % NB
         if world > 1:
-            gathered[k] = D.all_gather_slots(ring[k], world)      # RCCL over xGMI
+            sp.sync()                                               # SP(b) complete
+            gathered[b % NB] = D.all_gather_slots(ring[b % NB], world)   # RCCL over xGMI
             torch.cuda.synchronize()
         pm_step(b)
         sp_step(b + 1)
-        sp.sync()
-        res = pm.fetch(BATCH)
-        # carry = globally last slot of batch b (for pair (last, first) of batch b+1)
-        src = gathered[k][-1] if world > 1 else ring[k][-1]
-        carry.copy_(src)
-        torch.cuda.synchronize()
+        res = pm.fetch(BATCH)              # waits for match(b) only; SP(b+1) keeps the GPU busy
         if record:
-            s = sp.stage_ms()
+            s = sp.stage_ms(previous=True)  # SP(b), complete since match(b) is
             p = pm.stage_ms()
             sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1])
             pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
@@ -140,17 +144,18 @@ def main():
             n_matches.append(sum(len(r) for r in res))
         return res
 
-    # prologue: SP(0) so that the loop body is exactly one SP + one PM per step
+    # prologue: SP(0) so that the loop body is exactly one match + one SP per step
     sp_step(0)
-    sp.sync()
     for b in range(args.warmup):
         one_step(b, False)
+    sp.sync()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in range(args.warmup, args.warmup + args.steps):
         one_step(b, True)
+    sp.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -159,7 +164,7 @@ def main():
     fps = total_frames / dt
 
     if rank == 0:
-        kp = [int(F.slot_to_host(ring[b % NB][j].data_ptr()).shape[0]) for b in range(1) for j in range(BATCH)]
+        kp = [int(F.slot_to_host(ring[0][j].data_ptr()).shape[0]) for j in range(BATCH)]
         n_avg = float(np.mean(kp))
         # ---- roofline of the dominant kernel (largest summed device time per step)
         per_step = {

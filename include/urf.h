@@ -137,6 +137,11 @@ int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0,
                            const void *const *d_slots1, int outlier_rejection);
 int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
 int urf_pm_sync(urf_pm *h);
+/* Run this matcher on the SuperPoint handle's stream (same device): SP(b),
+ * match(b), SP(b+1) ... then execute in order on one HIP stream, the host only
+ * waits in urf_pm_fetch() for the batch it reads.  `sp` must outlive `h`. */
+int urf_pm_share_stream(urf_pm *h, urf_sp *sp);
+void *urf_sp_stream(urf_sp *h);
 
 /* EpipolarGeometry::_find_F, src/epipolar_geometry.cc:161-205: 8-point RANSAC
  * on n pixel correspondences (host arrays of x,y pairs).  Returns 0;

@@ -40,6 +40,8 @@ struct urf_pm {
   int device = 0, maxP = 1, iters = 100, r_iters = 200;
   float r_sigma = 1.0f;
   hipStream_t st = nullptr;
+  bool own_stream = true;
+  hipEvent_t ev_done = nullptr;
   bool built = false;
   float *d_w = nullptr;
   size_t kw[5], kb[5];
@@ -100,6 +102,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_CHECK(!h->built, "urf_pm_build: already built");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  URF_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   std::vector<float> host;
   auto put = [&](const float *src, size_t n) {
     size_t off = align_up(host.size(), 64);
@@ -217,7 +220,8 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 18; ++i) { (void)hipEventDestroy(h->ev_attn[i][0]); (void)hipEventDestroy(h->ev_attn[i][1]); }
-    (void)hipStreamDestroy(h->st);
+    if (h->own_stream) (void)hipStreamDestroy(h->st);
+    (void)hipEventDestroy(h->ev_done);
   }
   delete h;
 }
@@ -390,7 +394,7 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   URF_CHECK(P >= 1 && P <= h->maxP, "pairs %d outside [1, %d]", P, h->maxP);
   URF_CHECK(d_slots0 && d_slots1, "urf_match_device: null pointer");
   URF_HIP(hipSetDevice(h->device));
-  URF_HIP(hipStreamSynchronize(h->st));  // the pinned pointer table may still be in flight
+  URF_HIP(hipEventSynchronize(h->ev_done));  // previous batch (pinned pointer table, result buffers) consumed
   for (int p = 0; p < P; ++p) {
     h->h_slotptrs[2 * p] = (const float *)d_slots0[p];
     h->h_slotptrs[2 * p + 1] = (const float *)d_slots1[p];
@@ -403,6 +407,7 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   if (pm_pipeline(h, P, false, outlier_rejection != 0)) return -1;
   URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipEventRecord(h->ev_done, h->st));
   return 0;
 }
 
@@ -415,7 +420,10 @@ extern "C" int urf_pm_sync(urf_pm *h) {
 }
 
 extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
-  if (urf_pm_sync(h)) return -1;
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
+  pm_collect_times(h);
   URF_CHECK(P >= 1 && P <= h->maxP && out && nout, "urf_pm_fetch: bad argument");
   for (int p = 0; p < P; ++p) {
     const int n = h->h_n[p];
@@ -461,4 +469,19 @@ extern "C" int urf_pm_stage_ms(urf_pm *h, float *ms, int n) {
   URF_CHECK(h->ev_valid, "no timed call yet (urf_set_profiling(1) before the call)");
   for (int i = 0; i < n && i <= PT_COUNT; ++i) ms[i] = h->stage_ms[i];
   return PT_COUNT + 1;
+}
+
+// Put this matcher on the SuperPoint handle's stream: SP(b) -> match(b) -> SP(b+1)
+// then run in order on ONE stream with no host synchronisation in between.
+extern "C" void *urf_sp_stream(urf_sp *h);
+extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
+  URF_CHECK(h && h->built && sp, "urf_pm_share_stream: handles must be built");
+  void *st = urf_sp_stream(sp);
+  URF_CHECK(st, "urf_pm_share_stream: SuperPoint handle is not built");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamSynchronize(h->st));
+  if (h->own_stream) (void)hipStreamDestroy(h->st);
+  h->st = (hipStream_t)st;
+  h->own_stream = false;
+  return 0;
 }

@@ -76,8 +76,10 @@ struct urf_sp {
   // last call geometry (debug taps)
   int lastH = 0, lastW = 0, lastB = 0;
   // timing
-  hipEvent_t ev[ST_COUNT + 1];
-  bool ev_valid = false;
+  hipEvent_t evs[2][ST_COUNT + 1];  // two sets: the previous call's times stay readable
+  hipEvent_t *ev = nullptr;          // set used by the call being enqueued
+  int ev_cur = 0;
+  int ev_calls = 0;
   float stage_ms[ST_COUNT];
 };
 
@@ -206,7 +208,9 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_HIP(hipHostMalloc((void **)&h->h_img, B * H * W, hipHostMallocDefault));
   URF_HIP(hipHostMalloc((void **)&h->h_feat, B * (size_t)kCap * 259 * sizeof(double), hipHostMallocDefault));
   URF_HIP(hipHostMalloc((void **)&h->h_n, B * sizeof(int), hipHostMallocDefault));
-  for (int i = 0; i <= ST_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
+  for (int k = 0; k < 2; ++k)
+    for (int i = 0; i <= ST_COUNT; ++i) URF_HIP(hipEventCreate(&h->evs[k][i]));
+  h->ev = h->evs[0];
   h->built = true;
   return 0;
 }
@@ -261,7 +265,8 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
     (void)hipHostFree(h->h_n);
-    for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->evs[k][i]);
     (void)hipStreamDestroy(h->st);
   }
   delete h;
@@ -352,15 +357,13 @@ static int sp_check_dims(urf_sp *h, int B, int rows, int cols) {
   return 0;
 }
 
-static void sp_collect_times(urf_sp *h) {
+static void sp_flip_events(urf_sp *h) {
   if (!urf::g_profiling) return;
-  for (int i = 0; i < ST_COUNT; ++i) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0.0f;
-    h->stage_ms[i] = ms;
-  }
-  h->ev_valid = true;
+  h->ev_cur ^= 1;
+  h->ev = h->evs[h->ev_cur];
+  h->ev_calls++;
 }
+static void sp_collect_times(urf_sp *) {}
 
 extern "C" int urf_sp_infer_batch(urf_sp *h, int B, const uint8_t *const *imgs, int rows, int cols, size_t step,
                                   double *feat, int cap, int *Kout) {
@@ -371,6 +374,7 @@ extern "C" int urf_sp_infer_batch(urf_sp *h, int B, const uint8_t *const *imgs, 
   for (int b = 0; b < B; ++b)
     for (int y = 0; y < rows; ++y) memcpy(h->h_img + b * fsz + (size_t)y * cols, imgs[b] + (size_t)y * step, cols);
   const bool prof = urf::g_profiling != 0;
+  sp_flip_events(h);
   if (prof) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   URF_HIP(hipMemcpyAsync(h->d_img, h->h_img, B * fsz, hipMemcpyHostToDevice, h->st));
   if (sp_pipeline(h, B, h->d_img, rows, cols, nullptr, h->d_feat, h->d_slots)) return -1;
@@ -402,6 +406,7 @@ extern "C" int urf_sp_infer(urf_sp *h, const uint8_t *img, int rows, int cols, s
   URF_HIP(hipMemcpyAsync(h->d_img, h->h_img, fsz, hipMemcpyHostToDevice, h->st));
   URF_HIP(hipMemcpyAsync(h->d_usermask, m.data(), m.size(), hipMemcpyHostToDevice, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
+  sp_flip_events(h);
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   if (sp_pipeline(h, 1, h->d_img, rows, cols, h->d_usermask, h->d_feat, h->d_slots)) return -1;
   URF_HIP(hipMemcpyAsync(h->h_n, h->kp_n, sizeof(int), hipMemcpyDeviceToHost, h->st));
@@ -419,6 +424,7 @@ extern "C" int urf_sp_infer_device(urf_sp *h, int B, const uint8_t *d_imgs, int 
   if (sp_check_dims(h, B, rows, cols)) return -2;
   URF_CHECK(d_imgs && d_slots, "urf_sp_infer_device: null pointer");
   URF_HIP(hipSetDevice(h->device));
+  sp_flip_events(h);
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   if (sp_pipeline(h, B, d_imgs, rows, cols, nullptr, nullptr, (float *)d_slots)) return -1;
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
@@ -475,9 +481,23 @@ extern "C" int urf_sp_debug_tensor(urf_sp *h, int which, float *out, size_t n) {
   return 0;
 }
 
+// n > 0: stage times of the LATEST call (it must have completed);
+// n < 0: of the call before it (|n| entries) -- readable while the latest call
+// is still running on the stream.
 extern "C" int urf_sp_stage_ms(urf_sp *h, float *ms, int n) {
-  URF_CHECK(h && ms, "urf_sp_stage_ms: null");
-  URF_CHECK(h->ev_valid, "no timed call yet (urf_set_profiling(1) before the call)");
-  for (int i = 0; i < n && i < ST_COUNT; ++i) ms[i] = h->stage_ms[i];
+  URF_CHECK(h && ms && h->built, "urf_sp_stage_ms: bad handle");
+  const int want_prev = n < 0;
+  const int cnt = n < 0 ? -n : n;
+  URF_CHECK(h->ev_calls >= (want_prev ? 2 : 1), "no timed call yet (urf_set_profiling(1) before the call)");
+  URF_HIP(hipSetDevice(h->device));
+  hipEvent_t *e = h->evs[want_prev ? (h->ev_cur ^ 1) : h->ev_cur];
+  for (int i = 0; i < cnt && i < ST_COUNT; ++i) {
+    float t = 0.0f;
+    hipError_t rc = hipEventElapsedTime(&t, e[i], e[i + 1]);
+    URF_CHECK(rc == hipSuccess, "stage %d of the requested call has not completed: %s", i, hipGetErrorString(rc));
+    ms[i] = t;
+  }
   return ST_COUNT;
 }
+
+extern "C" void *urf_sp_stream(urf_sp *h) { return h && h->built ? (void *)h->st : nullptr; }

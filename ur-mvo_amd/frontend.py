@@ -112,9 +112,11 @@ class SuperPoint:
         check(_lib.lib().urf_sp_debug_tensor(self._h, which, _p(out), C.c_size_t(out.size)), "debug_tensor")
         return out
 
-    def stage_ms(self):
+    def stage_ms(self, previous=False):
+        """HIP-event stage times of the latest call, or (previous=True) of the call
+        before it, which stays readable while the latest one is still running."""
         ms = (C.c_float * 32)()
-        n = check(_lib.lib().urf_sp_stage_ms(self._h, ms, 32), "stage_ms")
+        n = check(_lib.lib().urf_sp_stage_ms(self._h, ms, -32 if previous else 32), "stage_ms")
         return [ms[i] for i in range(n)]
 
     def save_engine(self, blob=None):
@@ -225,6 +227,11 @@ class PointMatching(_PM):
 
     def sync(self):
         check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
+
+    def share_stream(self, superpoint):
+        """run on the SuperPoint handle's HIP stream (in-order SP -> match pipeline)"""
+        check(_lib.lib().urf_pm_share_stream(self._h, superpoint._h), "urf_pm_share_stream")
+        self._sp_keepalive = superpoint
 
     def find_F(self, pts0, pts1):
         p0 = np.ascontiguousarray(pts0, np.float32)
