@@ -91,8 +91,10 @@ static void linear(const float *X, int n, int cin, const float *W, const float *
  *   keys are visited in 16-blocks; inside a block in the order 4j+r for r=0..3,
  *   j=0..3 (0,4,8,12,1,5,...): the order in which an MFMA accumulator tile is
  *   consumed as the next MFMA's operand.
- *   l_i = (P0+P1)+(P2+P3), P_g = seq_{t,r} p[16t+4g+r]
- *   o_id = (chain_{t,r,j} fma(p[16t+4j+r], v[16t+4j+r][d], 0)) / l_i             */
+ *   per key half H in {[0,512), [512,1024)}:
+ *     l_H = (P0+P1)+(P2+P3), P_g = seq_{t,r} p[16t+4g+r]
+ *     a_H[d] = chain_{t,r,j} fma(p[16t+4j+r], v[16t+4j+r][d], 0)
+ *   o_id = (a_A[d] + a_B[d]) / (l_A + l_B)                                        */
 static void attention(const float *q, int nq, const float *k, const float *v, int ns,
                       float *o) {
   const int nblk = (ns + 15) / 16;
@@ -117,23 +119,32 @@ static void attention(const float *q, int nq, const float *k, const float *v, in
         for (int j = 0; j < ns; ++j) { s[j] = s[j] * 0.125f; m = s[j] > m ? s[j] : m; }
         for (int j = 0; j < ns; ++j) s[j] = om_exp(s[j] - m);
         for (int j = ns; j < nblk * 16; ++j) s[j] = 0.0f;
-        float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int t = 0; t < nblk; ++t)
-          for (int g = 0; g < 4; ++g)
-            for (int r = 0; r < 4; ++r) P[g] = P[g] + s[16 * t + 4 * g + r];
-        const float l = (P[0] + P[1]) + (P[2] + P[3]);
-        float acc[DH];
-        for (int d = 0; d < DH; ++d) acc[d] = 0.0f;
-        for (int t = 0; t < nblk; ++t)
-          for (int r = 0; r < 4; ++r)
-            for (int j4 = 0; j4 < 4; ++j4) {
-              const int key = 16 * t + 4 * j4 + r;
-              if (key >= ns) continue;
-              const float p = s[key];
-              const float *vr = v + (size_t)key * D + h * DH;
+        /* keys [0,512) and [512,1024) are reduced separately (two waves of the
+           GPU kernel) and combined once: l = lA + lB, o = (accA + accB) / l */
+        float lh[2], acch[2][DH];
+        for (int half = 0; half < 2; ++half) {
+          const int t0 = 32 * half, t1 = nblk < 32 * (half + 1) ? nblk : 32 * (half + 1);
+          float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int t = t0; t < t1; ++t)
+            for (int g = 0; g < 4; ++g)
+              for (int r = 0; r < 4; ++r) P[g] = P[g] + s[16 * t + 4 * g + r];
+          lh[half] = (P[0] + P[1]) + (P[2] + P[3]);
+          float *acc = acch[half];
+          for (int d = 0; d < DH; ++d) acc[d] = 0.0f;
+          for (int t = t0; t < t1; ++t)
+            for (int r = 0; r < 4; ++r)
+              for (int j4 = 0; j4 < 4; ++j4) {
+                const int key = 16 * t + 4 * j4 + r;
+                if (key >= ns) continue;
+                const float p = s[key];
+                const float *vr = v + (size_t)key * D + h * DH;
 #pragma omp simd
-              for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(p, vr[d], acc[d]);
-            }
+                for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(p, vr[d], acc[d]);
+              }
+        }
+        const float l = lh[0] + lh[1];
+        float acc[DH];
+        for (int d = 0; d < DH; ++d) acc[d] = acch[0][d] + acch[1][d];
         for (int d = 0; d < DH; ++d) o[(size_t)i * D + h * DH + d] = acc[d] / l;
       }
       free(s);

@@ -81,28 +81,39 @@ __device__ __forceinline__ float exp_c_nonpos(float x) {
   return x < -87.33654f ? 0.0f : v;
 }
 
-__global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
+// 512-thread workgroup = 64 queries x 1 head: wave w handles query tile (w & 3)
+// against key half (w >> 2): keys [0,512) or [512,1024).  The two waves of a
+// query tile share a SIMD (2 waves/SIMD hide each other's LDS/barrier stalls);
+// their partial results are combined once: l = lA + lB, O = (OA + OB) / l.
+constexpr int KHALF = 512;   // keys per half (8 chunks of 64)
+__global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
                                                       int cross, float *o /*[img][NP][256]*/) {
-  __shared__ __attribute__((aligned(16))) float kv[2][64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float kv[2][2][64 * VSTR];  // [double buffer][half][chunk]
+  __shared__ float s_max[8][16];
+  __shared__ float s_l[4][16];
   const int im = blockIdx.z, sm = cross ? (im ^ 1) : im;
   const int head = blockIdx.y;
   const int nq = counts[im], ns = counts[sm];
   const int q0 = blockIdx.x * 64;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = wave & 3, kh = wave >> 2;
   const int px = lane & 15, g = lane >> 4;
   const float *qb = qkv + ((size_t)im * NP) * 768 + head * 64;
   const float *kb = qkv + ((size_t)sm * NP) * 768 + 256 + head * 64;
   const float *vb = qkv + ((size_t)sm * NP) * 768 + 512 + head * 64;
-  const int nchunk = (ns + 63) >> 6;
+  const int nsA = ns < KHALF ? ns : KHALF;              // keys in half A
+  const int nrounds = (nsA + 63) >> 6;                  // chunks of half A (>= chunks of half B)
+  const int kbase_h = kh * KHALF;                       // first key of this wave's half
 
-  // staging: thread handles float4 #(tid&15) of keys (tid>>4) + 16u, u = 0..3
-  const int sj = tid & 15, sr = tid >> 4;
+  // staging: 512 threads, thread -> (half sh, key row sr + 16u, float4 sj)
+  const int sh = tid >> 8, st = tid & 255;
+  const int sj = st & 15, sr = st >> 4;
   f32x4 pf[4];
   auto issue = [&](const float *base, int ch) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int key = ch * 64 + sr + 16 * u;
+      const int key = sh * KHALF + ch * 64 + sr + 16 * u;
       pf[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (key < ns) pf[u] = *(const f32x4 *)(base + (size_t)key * 768 + 4 * sj);
     }
@@ -110,37 +121,36 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][N
   auto commit_k = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      float *dst = kv[buf] + (sr + 16 * u) * KSTR + 4 * sj;
+      float *dst = kv[buf][sh] + (sr + 16 * u) * KSTR + 4 * sj;
       *(float2 *)dst = make_float2(pf[u][0], pf[u][1]);
       *(float2 *)(dst + 2) = make_float2(pf[u][2], pf[u][3]);
     }
   };
   auto commit_v = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *(f32x4 *)(kv[buf] + (sr + 16 * u) * VSTR + 4 * sj) = pf[u];
+    for (int u = 0; u < 4; ++u) *(f32x4 *)(kv[buf][sh] + (sr + 16 * u) * VSTR + 4 * sj) = pf[u];
   };
 
   issue(kb, 0);
-  // Q fragment: B[k = g][col = px] = Q[q0 + 16*wave + px][4*s + g]
   float qreg[16];
   {
-    const float *qr = qb + (size_t)(q0 + wave * 16 + px) * 768 + g;
+    const float *qr = qb + (size_t)(q0 + qt * 16 + px) * 768 + g;
 #pragma unroll
     for (int s = 0; s < 16; ++s) qreg[s] = qr[4 * s];
   }
   commit_k(0);
   __syncthreads();
 
-  f32x4 sreg[64];
-  // ---------------- phase 1: S^T = K Q^T, 4 key tiles in flight per k-step
+  f32x4 sreg[32];
+  // ---------------- phase 1: S^T = K Q^T over this wave's key half
 #pragma unroll
-  for (int ch = 0; ch < 16; ++ch) {
-    if (ch < nchunk) {
-      if (ch + 1 < nchunk) issue(kb, ch + 1);
+  for (int ch = 0; ch < 8; ++ch) {
+    if (ch < nrounds) {
+      if (ch + 1 < nrounds) issue(kb, ch + 1);
       f32x4 acc[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      const float *ap = kv[ch & 1] + px * KSTR + g;
+      const float *ap = kv[ch & 1][kh] + px * KSTR + g;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -149,76 +159,93 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const float *qkv /*[img][N
       }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const int kbase = ch * 64 + kt * 16 + 4 * g;
+        const int kb0 = kbase_h + ch * 64 + kt * 16 + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[kt][r] = (kbase + r < ns) ? acc[kt][r] * 0.125f : -FLT_MAX;
+        for (int r = 0; r < 4; ++r) acc[kt][r] = (kb0 + r < ns) ? acc[kt][r] * 0.125f : -FLT_MAX;
         sreg[ch * 4 + kt] = acc[kt];
       }
-      if (ch + 1 < nchunk) commit_k((ch + 1) & 1);
+      if (ch + 1 < nrounds) commit_k((ch + 1) & 1);
       __syncthreads();
     } else {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) sreg[ch * 4 + kt] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     }
   }
-  issue(vb, 0);  // V chunk 0 flies while the row max is reduced
-  // ---------------- row max (per query = per px; the 4 lanes g share it)
+  issue(vb, 0);
+  // ---------------- row max over both halves
   float m = -FLT_MAX;
 #pragma unroll
-  for (int t = 0; t < 64; ++t)
+  for (int t = 0; t < 32; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) m = fmaxf(m, sreg[t][r]);
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (g == 0) s_max[wave][px] = m;
   commit_v(0);
   __syncthreads();
+  m = fmaxf(m, s_max[wave ^ 4][px]);
   // ---------------- phase 2: p = exp_c(s - m) one tile ahead of its O^T += V^T P^T
+  const int nsl = ns - kbase_h;  // keys of this half (may be <= 0)
   float part = 0.0f;
+  if (nsl > 0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { const float p = exp_c_nonpos(sreg[0][r] - m); sreg[0][r] = p; part = part + p; }
+    for (int r = 0; r < 4; ++r) { const float p = exp_c_nonpos(sreg[0][r] - m); sreg[0][r] = p; part = part + p; }
+  }
   f32x4 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int ch = 0; ch < 16; ++ch) {
-    if (ch < nchunk) {
-      if (ch + 1 < nchunk) issue(vb, ch + 1);
+  for (int ch = 0; ch < 8; ++ch) {
+    if (ch < nrounds) {
+      if (ch + 1 < nrounds) issue(vb, ch + 1);
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const int T = ch * 4 + kt;
-        if (T * 16 < ns) {
-          if (T + 1 < 64 && (T + 1) * 16 < ns) {
+        if (T * 16 < nsl) {
+          if (T + 1 < 32 && (T + 1) * 16 < nsl) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p = exp_c_nonpos(sreg[T + 1 < 64 ? T + 1 : 63][r] - m);
-              sreg[T + 1 < 64 ? T + 1 : 63][r] = p;
+              const float p = exp_c_nonpos(sreg[T + 1 < 32 ? T + 1 : 31][r] - m);
+              sreg[T + 1 < 32 ? T + 1 : 31][r] = p;
               part = part + p;
             }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pb = sreg[T][r];
-            const float *ap = kv[ch & 1] + (kt * 16 + 4 * g + r) * VSTR + px;
+            const float *ap = kv[ch & 1][kh] + (kt * 16 + 4 * g + r) * VSTR + px;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
               oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[dt * 16], pb, oacc[dt], 0, 0, 0);
           }
         }
       }
-      if (ch + 1 < nchunk) commit_v((ch + 1) & 1);
+      if (ch + 1 < nrounds) commit_v((ch + 1) & 1);
       __syncthreads();
     }
   }
   float l = part + __shfl_xor(part, 16, 64);
   l = l + __shfl_xor(l, 32, 64);
-  const int q = q0 + wave * 16 + px;
-  float *op = o + ((size_t)im * NP + q) * 256 + head * 64 + 4 * g;
+  // ---------------- combine the two halves: O = (OA + OB) / (lA + lB)
+  float *xo = &kv[0][0][0] + qt * (64 * 68);   // 64 lanes x 16 floats (+pad) per query tile
+  if (kh == 1) {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    f32x4 v;
+    for (int dt = 0; dt < 4; ++dt) *(f32x4 *)(xo + lane * 68 + 4 * dt) = oacc[dt];
+    if (g == 0) s_l[qt][px] = l;
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const float lt = l + s_l[qt][px];
+    const int q = q0 + qt * 16 + px;
+    float *op = o + ((size_t)im * NP + q) * 256 + head * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r] / l;
-    *(f32x4 *)(op + dt * 16) = v;
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 ob = *(const f32x4 *)(xo + lane * 68 + 4 * dt);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (oacc[dt][r] + ob[r]) / lt;
+      *(f32x4 *)(op + dt * 16) = v;
+    }
   }
 }
 
@@ -476,7 +503,7 @@ int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int hei
   return 0;
 }
 int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(attn_kernel, dim3(NP / 64, 4, nimg), dim3(256), 0, st, qkv, counts, cross, o);
+  hipLaunchKernelGGL(attn_kernel, dim3(NP / 64, 4, nimg), dim3(512), 0, st, qkv, counts, cross, o);
   URF_HIP(hipGetLastError());
   return 0;
 }
