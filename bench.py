@@ -62,11 +62,19 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    # URF_BENCH_SHARED_GPU=1 is a test rig: all ranks on cuda:0 with gloo, to
+    # exercise the N>1 control flow on a 1-GPU box (numbers are meaningless).
+    shared_gpu = os.environ.get("URF_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     U = load_pkg()
     F, synth, D = U.frontend, U.synth, U.dist
@@ -152,6 +160,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    checks = []
     t0 = time.perf_counter()
     for b in range(args.warmup, args.warmup + args.steps):
         one_step(b, True)

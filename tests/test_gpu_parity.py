@@ -278,3 +278,23 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     got = [tuple(l.split()) for l in out[1:]]
     assert [(int(a), int(b)) for a, b, _ in got] == [(q, t) for q, t, _ in m]
     assert np.allclose([float(c) for _, _, c in got], [d for _, _, d in m], rtol=0, atol=1e-7)
+
+
+def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
+    """bench.py --gpus 2 with both ranks on cuda:0 (gloo): exercises the frame
+    sharding, the slot all-gather and the cross-rank pairs.  Every pair of the
+    single synthetic stream must still find its ~700 true matches."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, URF_BENCH_SHARED_GPU="1")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+         "--warmup", "1"], env=env, text=True, stderr=subprocess.DEVNULL)
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert d["matches_per_step"] > 8 * 600          # rank 0's 8 pairs, incl. the pair that crosses the batch seam

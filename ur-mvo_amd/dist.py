@@ -34,6 +34,12 @@ def all_gather_slots(local_slots, world):
         return local_slots
     out = torch.empty((world * local_slots.shape[0],) + tuple(local_slots.shape[1:]),
                       dtype=local_slots.dtype, device=local_slots.device)
+    if dist.get_backend() == "gloo" and local_slots.is_cuda:
+        # test rig only (several ranks sharing one GPU): stage through the host
+        tmp = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(tmp, local_slots.contiguous().cpu())
+        out.copy_(tmp)
+        return out
     dist.all_gather_into_tensor(out, local_slots.contiguous())
     return out
 
@@ -41,6 +47,8 @@ def all_gather_slots(local_slots, world):
 def max_over_ranks(value, device, world):
     if world == 1:
         return value
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
