@@ -14,6 +14,7 @@ namespace urf {
 extern int g_profiling;
 int weights_load(const char *path, int kind, std::vector<float> &out);
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
+int launch_gemm128(const ConvArgs &a, int batch, hipStream_t st);
 int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int height, int *counts, float *kin,
                          float *kxy, float *x, hipStream_t st);
 int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st);
@@ -238,6 +239,7 @@ static int sg_linear(urf_pm *h, int nimg, const float *in, int in_ld, int cin, c
   a.res = res; a.res_ld = out_ld; a.res_bstride = (long)NP * out_ld;
   a.relu = relu ? 1 : 0;
   a.counts = h->counts;
+  if ((cout % 128) == 0 && cout >= 512 && (cin % 64) == 0 && !res) return launch_gemm128(a, nimg, h->st);
   return launch_conv(a, 1, false, false, nimg, h->st);
 }
 
