@@ -149,6 +149,19 @@ void *urf_sp_stream(urf_sp *h);
 int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n,
                       uint8_t *inliers, float *F21, float *score);
 
+/* EpipolarGeometry(K, sigma, iterations) + reconstruct(vKeys1, vKeys2,
+ * vMatches12, T21, vP3D, vbTriangulated), include/epipolar_geometry.h:20-40,
+ * src/epipolar_geometry.cc:18-98 (monocular initialisation, src/tracking.cc:559).
+ * keys: n x (x,y) pixel coordinates; matches12[n1] = index into keys2 or -1.
+ * T21: 4x4 row-major, P3D: n1 x 3, triangulated: n1 bytes; *model: 0 = the
+ * homography won, 1 = the fundamental matrix; scores[2] = {SH, SF}.
+ * Returns 1 if the initialisation is accepted, 0 if not, <0 on error.  The
+ * explicit seed replaces the process-global srand(0) (:100-112). */
+typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; } urf_epi_config;
+int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
+                             const float *keys2, int n2, const int *matches12, float *T21,
+                             float *P3D, uint8_t *triangulated, int *model, float *scores);
+
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */
 int urf_sp_stage_ms(urf_sp *h, float *ms, int n);   /* ms[i]: last call's stage times */

@@ -18,6 +18,9 @@ struct Mat {  // 8-bit single-channel view, like cv::Mat(rows, cols, CV_8UC1, da
   Mat(int r, int c, int /*type*/, void *d, size_t s = 0) : rows(r), cols(c), step(s ? s : (size_t)c), data((unsigned char *)d) {}
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
 };
+struct Point2f { float x = 0, y = 0; };
+struct Point3f { float x = 0, y = 0, z = 0; Point3f() = default; Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
+struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
 struct DMatch {
   int queryIdx = -1, trainIdx = -1, imgIdx = -1;
   float distance = 0;
@@ -45,10 +48,12 @@ class Matrix {  // column-major R x n (R fixed) or n x 1 vector storage
   T &operator[](long i) { return d_[(size_t)i]; }
   const T &operator[](long i) const { return d_[(size_t)i]; }
  private:
-  long rows_ = (R > 0 ? R : 0), cols_ = 0;
-  std::vector<T> d_;
+  long rows_ = (R > 0 ? R : 0), cols_ = (C > 0 ? C : 0);
+  std::vector<T> d_ = std::vector<T>((size_t)((R > 0 && C > 0) ? R * C : 0));
 };
 typedef Matrix<int, Dynamic, 1> VectorXi;
 typedef Matrix<double, Dynamic, 1> VectorXd;
+typedef Matrix<float, 3, 3> Matrix3f;
+typedef Matrix<float, 4, 4> Matrix4f;
 }  // namespace Eigen
 #endif

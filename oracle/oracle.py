@@ -221,3 +221,23 @@ def fma_gemm(A, B, C0=None):
         C0 = np.ascontiguousarray(C0, np.float32)
     lib().o_fma_gemm(_p(A), _p(B), _p(C0), M, N, K, _p(out))
     return out
+
+
+class EpiConfig(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32)]
+
+
+def epi_reconstruct(K, keys1, keys2, matches12, sigma=1.0, iterations=200, seed=0):
+    """EpipolarGeometry::reconstruct.  Returns (ok, T21[4,4], P3D[n1,3], tri[n1], model, (SH, SF))."""
+    cfg = EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed)
+    k1 = np.ascontiguousarray(keys1, np.float32)
+    k2 = np.ascontiguousarray(keys2, np.float32)
+    m = np.ascontiguousarray(matches12, np.int32)
+    n1, n2 = k1.shape[0], k2.shape[0]
+    T = np.zeros(16, np.float32)
+    P = np.zeros((n1, 3), np.float32)
+    tri = np.zeros(n1, np.uint8)
+    model = C.c_int(-1)
+    sc = np.zeros(2, np.float32)
+    ok = lib().oepi_reconstruct(C.byref(cfg), _p(k1), n1, _p(k2), n2, _p(m), _p(T), _p(P), _p(tri), C.byref(model), _p(sc))
+    return bool(ok), T.reshape(4, 4), P, tri, model.value, (float(sc[0]), float(sc[1]))

@@ -110,6 +110,14 @@ int omatch_points(const float *sg_blob, const osg_config *cfg,
                   const double *f1, int n1, int outlier_rejection,
                   o_dmatch *out, int cap);
 
+/* EpipolarGeometry::reconstruct src/epipolar_geometry.cc:18-98 (mono init).
+ * keys: n x (x,y) pixel coords; matches12[n1]: index into keys2 or -1.
+ * T21: 4x4 row-major; P3D: n1 x 3; tri: n1 flags; model: 0 = H, 1 = F;
+ * scores[2] = {SH, SF}.  Returns 1 when the initialisation is accepted. */
+typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; } oepi_config;
+int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
+                     const int *matches12, float *T21, float *P3D, uint8_t *tri, int *model, float *scores);
+
 /* canonical math probes (tests) */
 float o_exp(float x);
 float o_log(float x);

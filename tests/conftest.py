@@ -65,3 +65,29 @@ def make_features(rng, n, planted_from=None, m=0, shift=3):
         f[:m, 3:] = planted_from[:m, 3:]
         f[:m, 1:3] = planted_from[:m, 1:3] + shift
     return f
+
+
+def two_view_scene(seed=0, n=400, noise=0.0, outliers=40, unmatched=30, planar=False, motion=1.0, tilt=0.0, jitter=0.02):
+    """synthetic calibrated two-view scene: K, keys1, keys2 (shuffled), matches12."""
+    rng = np.random.default_rng(seed)
+    xs, ys = rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n)
+    z = 6 + tilt * xs + jitter * rng.standard_normal(n) if planar else rng.uniform(4, 9, n)
+    X = np.c_[xs, ys, z]
+    K = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1.0]], np.float32)
+    th = 0.06 * motion
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([0.5, 0.03, 0.05]) * motion
+    p0 = (K @ X.T).T
+    p0 = p0[:, :2] / p0[:, 2:]
+    p1 = (K @ (R @ X.T + t[:, None])).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    p1 = p1 + rng.normal(0, noise, p1.shape) if noise else p1
+    perm = rng.permutation(n)
+    k2 = p1[perm]
+    m = np.argsort(perm).astype(np.int32)
+    if outliers:
+        bad = rng.choice(n, outliers, replace=False)
+        m[bad] = rng.integers(0, n, outliers)
+    if unmatched:
+        m[rng.choice(n, unmatched, replace=False)] = -1
+    return K, p0.astype(np.float32), k2.astype(np.float32), m, R, t

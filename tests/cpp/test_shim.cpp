@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "epipolar_geometry.h"
 #include "point_matching.h"
 #include "super_point.h"
 
@@ -37,5 +38,10 @@ int main(int argc, char **argv) {
   const int n = point_matching->MatchingPoints(features0, features1, matches, true);                   // tracking.cc:354
   printf("K0=%ld K1=%ld matches=%d\n", (long)features0.cols(), (long)features1.cols(), n);
   for (int i = 0; i < n; ++i) printf("%d %d %.9g\n", matches[i].queryIdx, matches[i].trainIdx, matches[i].distance);
+  // EpipolarGeometry compiles against the same handle (mono init, src/tracking.cc:52-55,559)
+  Eigen::Matrix3f Kc;
+  Kc(0, 0) = 500; Kc(0, 1) = 0; Kc(0, 2) = 320; Kc(1, 0) = 0; Kc(1, 1) = 500; Kc(1, 2) = 240; Kc(2, 0) = 0; Kc(2, 1) = 0; Kc(2, 2) = 1;
+  EpipolarGeometry eg(Kc, 1.0, 200);
+  (void)eg;
   return 0;
 }

@@ -298,3 +298,24 @@ def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["matches_per_step"] > 8 * 600          # rank 0's 8 pairs, incl. the pair that crosses the batch seam
+
+
+@pytest.mark.parametrize("kw,its", [(dict(seed=0, noise=0.0, outliers=40), 200), (dict(seed=2, noise=0.3, outliers=40), 200),
+                                    (dict(seed=1, planar=True, outliers=20), 200),
+                                    (dict(seed=33, planar=True, outliers=10, noise=0.1), 5),     # homography branch
+                                    (dict(seed=5, noise=0.1, outliers=60, motion=2.0), 200)])
+def test_epipolar_reconstruct_bit_exact_vs_oracle(F, O, pm, kw, its):
+    """EpipolarGeometry::reconstruct: GPU RANSAC searches + host tail vs the oracle"""
+    from conftest import two_view_scene
+    K, k1, k2, m, R, t = two_view_scene(**kw)
+    eg = F.EpipolarGeometry(pm, K, 1.0, its, seed=0)
+    ok, T, P, tri, model, sc = eg.reconstruct(k1, k2, m)
+    ook, oT, oP, otri, omodel, osc = O.epi_reconstruct(K, k1, k2, m, iterations=its)
+    if kw.get("seed") == 33:
+        assert model == 0
+    if kw.get("seed") == 0:
+        assert ok and model == 1 and np.abs(T[:3, :3] - R).max() < 1e-3
+    assert (ok, model, sc) == (ook, omodel, osc)
+    assert np.array_equal(T, oT) and np.array_equal(tri, otri) and np.array_equal(P, oP)
+    ok7, *_ = eg.reconstruct(k1[:7], k2, np.arange(7, dtype=np.int32))
+    assert not ok7

@@ -218,3 +218,25 @@ def test_match_points_end_to_end_on_planted_pairs(O, sg_blob):
     assert set(rej) <= set(raw) and len([m for m in rej if m[0] == m[1]]) >= 50
     assert all(0.0 <= m[2] <= 0.5 for m in raw)          # distance = 1 - mscore, mscore > 0.5
     assert O.match_points(sg_blob, cfg, rc, f0[:0], f1, True) == []     # empty side
+
+
+def test_epipolar_reconstruct_recovers_the_motion(O):
+    """oracle EpipolarGeometry::reconstruct on synthetic calibrated scenes"""
+    from conftest import two_view_scene
+    K, k1, k2, m, R, t = two_view_scene(seed=0, noise=0.0, outliers=40)
+    ok, T, P, tri, model, (SH, SF) = O.epi_reconstruct(K, k1, k2, m)
+    assert ok and model == 1 and SF > SH                       # general scene -> fundamental matrix
+    assert np.abs(T[:3, :3] - R).max() < 1e-3
+    tn = T[:3, 3] / np.linalg.norm(T[:3, 3])
+    assert np.abs(tn - t / np.linalg.norm(t)).max() < 1e-2
+    good = np.nonzero(tri)[0]
+    assert len(good) > 300 and (P[good, 2] > 0).all()
+    # a plane: H and F explain the data equally well (RH ~ 0.5); with few iterations
+    # the degenerate 8-point F hypotheses lose and the homography branch runs
+    K, k1, k2, m, R, t = two_view_scene(seed=33, planar=True, outliers=10, noise=0.1)
+    ok, T, P, tri, model, (SH, SF) = O.epi_reconstruct(K, k1, k2, m, iterations=5)
+    assert model == 0 and 0.5 < SH / (SH + SF) < 0.55
+    assert not ok                       # low parallax, two-fold ambiguity: rejected (:722-729)
+    # too few matches
+    ok, *_ = O.epi_reconstruct(K, k1[:7], k2, np.arange(7, dtype=np.int32))
+    assert not ok

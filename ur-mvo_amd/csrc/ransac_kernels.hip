@@ -374,6 +374,175 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const int *nmatch, 
   if (i == 0) nout[p] = tot;
 }
 
+// ======================================================================
+// EpipolarGeometry::reconstruct support (mono initialisation,
+// src/epipolar_geometry.cc:18-98): normalisation over ALL keypoints, the
+// homography hypotheses (_compute_H21 :207-245) and their scores (_check_H
+// :285-370).  The F hypotheses/scores reuse the kernels above.
+// ======================================================================
+__global__ void __launch_bounds__(128) epi_normalize_kernel(const float *keys1, int n1, const float *keys2, int n2,
+                                                            const float *pts0, const float *pts1, int nm, float *pn0,
+                                                            float *pn1, float *T /*[2][9]*/) {
+  __shared__ float st[2][4];
+  const int which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float *keys = which ? keys2 : keys1;
+  const int n = which ? n2 : n1;
+  const float meanX = wave_sum_strided(keys, 2, n, lane) / (float)n;
+  const float meanY = wave_sum_strided(keys + 1, 2, n, lane) / (float)n;
+  float ax = 0.0f, ay = 0.0f;
+  for (int i = lane; i < n; i += 64) { ax = ax + fabsf(keys[2 * i] - meanX); ay = ay + fabsf(keys[2 * i + 1] - meanY); }
+  const float dX = bfly64_sum(ax) / (float)n, dY = bfly64_sum(ay) / (float)n;
+  const float sX = (float)(1.0 / (double)dX), sY = (float)(1.0 / (double)dY);
+  if (lane == 0) {
+    float *t = T + which * 9;
+    for (int k = 0; k < 9; ++k) t[k] = 0.0f;
+    t[0] = sX; t[4] = sY; t[2] = -meanX * sX; t[5] = -meanY * sY; t[8] = 1.0f;
+    st[which][0] = meanX; st[which][1] = meanY; st[which][2] = sX; st[which][3] = sY;
+  }
+  __syncthreads();
+  const float *pts = which ? pts1 : pts0;
+  float *pn = which ? pn1 : pn0;
+  for (int i = lane; i < nm; i += 64) {
+    pn[2 * i] = (pts[2 * i] - st[which][0]) * st[which][2];
+    pn[2 * i + 1] = (pts[2 * i + 1] - st[which][1]) * st[which][3];
+  }
+}
+
+__device__ void mat3_inv_f(const float *m, float *o) {  // cofactor inverse, float
+  const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = (a * A + b * B) + c * C;
+  const float id = 1.0f / det;
+  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+  o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+  o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+
+// cyclic Jacobi on a symmetric 9x9 held in LDS: a(i,j) = la[(i*9+j)*32 + lane32]
+#define JA(i, j) la[((i) * 9 + (j)) * 32]
+#define JV(i, j) lv[((i) * 9 + (j)) * 32]
+__device__ void jacobi9_lds(double *la, double *lv) {
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) JV(i, j) = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < JAC_SWEEPS; ++sweep) {
+    for (int p = 0; p < 8; ++p)
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = JA(p, q);
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (JA(q, q) - JA(p, p)) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 9; ++k) {
+          const double akp = JA(k, p), akq = JA(k, q);
+          JA(k, p) = c * akp - s * akq;
+          JA(k, q) = s * akp + c * akq;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double apk = JA(p, k), aqk = JA(q, k);
+          JA(p, k) = c * apk - s * aqk;
+          JA(q, k) = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double vkp = JV(k, p), vkq = JV(k, q);
+          JV(k, p) = c * vkp - s * vkq;
+          JV(k, q) = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+__global__ void __launch_bounds__(32) epi_hyp_h_kernel(const float *pn0, const float *pn1, int nm, const float *T,
+                                                       uint32_t seed, int iters, float *H /*[iters][18]: H21 | H12*/) {
+  __shared__ double la[81 * 32];
+  __shared__ double lv[81 * 32];
+  const int it = blockIdx.x * 32 + threadIdx.x;
+  if (it >= iters || nm < 8) return;
+  double *a = la + threadIdx.x, *v = lv + threadIdx.x;
+  int set[8];
+  draw_set(seed, it, nm, set);
+  // A^T A of the 16x9 DLT system, accumulated row pair by row pair in source order
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) a[(r * 9 + c) * 32] = 0.0;
+  double rows[16][9];
+  for (int i = 0; i < 8; ++i) {
+    const float u1 = pn0[2 * set[i]], v1 = pn0[2 * set[i] + 1], u2 = pn1[2 * set[i]], v2 = pn1[2 * set[i] + 1];
+    double *r0 = rows[2 * i], *r1 = rows[2 * i + 1];
+    r0[0] = 0.0; r0[1] = 0.0; r0[2] = 0.0; r0[3] = (double)(-u1); r0[4] = (double)(-v1); r0[5] = -1.0;
+    r0[6] = (double)(v2 * u1); r0[7] = (double)(v2 * v1); r0[8] = (double)v2;
+    r1[0] = (double)u1; r1[1] = (double)v1; r1[2] = 1.0; r1[3] = 0.0; r1[4] = 0.0; r1[5] = 0.0;
+    r1[6] = (double)(-u2 * u1); r1[7] = (double)(-u2 * v1); r1[8] = (double)(-u2);
+  }
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      double s = 0.0;
+      for (int i = 0; i < 16; ++i) s = s + rows[i][r] * rows[i][c];
+      a[(r * 9 + c) * 32] = s;
+    }
+  jacobi9_lds(a, v);
+  int m = 0;
+  for (int i = 1; i < 9; ++i)
+    if (a[(i * 9 + i) * 32] < a[(m * 9 + m) * 32]) m = i;
+  float Hn[9], M[9], T2inv[9], H21[9], H12[9];
+  for (int k = 0; k < 9; ++k) Hn[k] = (float)v[(k * 9 + m) * 32];
+  mat3_inv_f(T + 9, T2inv);
+  mat3_mul_f(T2inv, Hn, M);
+  mat3_mul_f(M, T, H21);
+  mat3_inv_f(H21, H12);
+  float *ho = H + (size_t)it * 18;
+  for (int k = 0; k < 9; ++k) { ho[k] = H21[k]; ho[9 + k] = H12[k]; }
+}
+#undef JA
+#undef JV
+
+__device__ __forceinline__ bool check_pair_h(const float *H21, const float *H12, float u1, float v1, float u2, float v2,
+                                             float invSigmaSquare, float &score) {
+  const float th = 5.991f;
+  bool bIn = true;
+  const float w2in1inv = (float)(1.0 / (double)((H12[6] * u2 + H12[7] * v2) + H12[8]));
+  const float u2in1 = ((H12[0] * u2 + H12[1] * v2) + H12[2]) * w2in1inv;
+  const float v2in1 = ((H12[3] * u2 + H12[4] * v2) + H12[5]) * w2in1inv;
+  const float squareDist1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+  const float chiSquare1 = squareDist1 * invSigmaSquare;
+  if (chiSquare1 > th) bIn = false; else score = score + (th - chiSquare1);
+  const float w1in2inv = (float)(1.0 / (double)((H21[6] * u1 + H21[7] * v1) + H21[8]));
+  const float u1in2 = ((H21[0] * u1 + H21[1] * v1) + H21[2]) * w1in2inv;
+  const float v1in2 = ((H21[3] * u1 + H21[4] * v1) + H21[5]) * w1in2inv;
+  const float squareDist2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+  const float chiSquare2 = squareDist2 * invSigmaSquare;
+  if (chiSquare2 > th) bIn = false; else score = score + (th - chiSquare2);
+  return bIn;
+}
+
+__global__ void __launch_bounds__(256) epi_score_h_kernel(const float *pts0, const float *pts1, int nm, const float *H,
+                                                          float sigma, int iters, float *score) {
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (it >= iters || nm < 8) return;
+  float Hl[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) Hl[k] = H[(size_t)it * 18 + k];
+  const float invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));
+  float sc = 0.0f;
+  for (int i = lane; i < nm; i += 64)
+    check_pair_h(Hl, Hl + 9, pts0[2 * i], pts0[2 * i + 1], pts1[2 * i], pts1[2 * i + 1], invSigmaSquare, sc);
+  sc = bfly64_sum(sc);
+  if (lane == 0) score[it] = sc;
+}
+
+// both model searches for one image pair; everything on `st`
+int launch_epipolar_search(const float *keys1, int n1, const float *keys2, int n2, const float *pts0, const float *pts1,
+                           const int *d_nm, int nm, float *pn0, float *pn1, float *T, float *F, float *scoreF,
+                           float *H, float *scoreH, uint32_t seed, int iters, float sigma, hipStream_t st) {
+  hipLaunchKernelGGL(epi_normalize_kernel, dim3(1), dim3(128), 0, st, keys1, n1, keys2, n2, pts0, pts1, nm, pn0, pn1, T);
+  hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, 1), dim3(64), 0, st, d_nm, pn0, pn1, T, seed, iters, F);
+  hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, 1), dim3(256), 0, st, d_nm, pts0, pts1, F, sigma, iters,
+                     scoreF);
+  hipLaunchKernelGGL(epi_hyp_h_kernel, dim3((iters + 31) / 32), dim3(32), 0, st, pn0, pn1, nm, T, seed, iters, H);
+  hipLaunchKernelGGL(epi_score_h_kernel, dim3((iters + 3) / 4), dim3(256), 0, st, pts0, pts1, nm, H, sigma, iters,
+                     scoreH);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *pn0, float *pn1, float *T, float *F,
                   float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
                   int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st) {

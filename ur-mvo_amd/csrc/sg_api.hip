@@ -487,3 +487,6 @@ extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
   h->own_stream = false;
   return 0;
 }
+
+extern "C" void *urf_pm_stream_(urf_pm *h) { return h && h->built ? (void *)h->st : nullptr; }
+extern "C" int urf_pm_device_(urf_pm *h) { return h ? h->device : 0; }

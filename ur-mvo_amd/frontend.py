@@ -244,6 +244,31 @@ class PointMatching(_PM):
         return float(s.value), inl[:n], F.reshape(3, 3)
 
 
+class EpipolarGeometry:
+    """EpipolarGeometry (include/epipolar_geometry.h:20-40 of UR-MVO): two-view
+    initialisation.  Runs on the matcher's device/stream (pass a built
+    PointMatching or SuperGlue object)."""
+
+    def __init__(self, matcher, K, sigma=1.0, iterations=200, seed=0):
+        self._m = matcher
+        self._cfg = _lib.EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed)
+
+    def reconstruct(self, vKeys1, vKeys2, vMatches12):
+        """-> (ok, T21[4,4], vP3D[n1,3], vbTriangulated[n1], model, (SH, SF))"""
+        k1 = np.ascontiguousarray(vKeys1, np.float32)
+        k2 = np.ascontiguousarray(vKeys2, np.float32)
+        m = np.ascontiguousarray(vMatches12, np.int32)
+        n1, n2 = k1.shape[0], k2.shape[0]
+        T = np.zeros(16, np.float32)
+        P = np.zeros((max(n1, 1), 3), np.float32)
+        tri = np.zeros(max(n1, 1), np.uint8)
+        model = C.c_int(-1)
+        sc = np.zeros(2, np.float32)
+        rc = check(_lib.lib().urf_epipolar_reconstruct(self._m._h, C.byref(self._cfg), _p(k1), n1, _p(k2), n2, _p(m),
+                                                       _p(T), _p(P), _p(tri), C.byref(model), _p(sc)), "reconstruct")
+        return bool(rc), T.reshape(4, 4), P[:n1], tri[:n1], model.value, (float(sc[0]), float(sc[1]))
+
+
 def slot_to_host(d_slot_ptr):
     feat = np.zeros((CAP, 259), np.float64)
     K = C.c_int(0)
