@@ -234,9 +234,31 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, acc[2][1], 0, 0, 0);                 \
     acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b1, acc[3][1], 0, 0, 0);                 \
   }
-      if (kc == 64) {  // fast path: fully unrolled, LDS operand reads run ahead of the MFMAs
+      if (kc == 64) {
+        // fast path: fully unrolled and software-pipelined by hand -- the LDS
+        // operand reads of k-step k+1 are issued before the 8 MFMAs of k-step k
+        // (two register sets), so their latency hides behind 256 MFMA cycles.
+        float pa[2][4], pb[2][2];
+#define URF_LOAD(set, k)                                                               \
+  {                                                                                    \
+    pb[set][0] = bp0[k]; pb[set][1] = bp1[k];                                          \
+    pa[set][0] = ap[(k) * W_STRIDE]; pa[set][1] = ap[(k) * W_STRIDE + 16];             \
+    pa[set][2] = ap[(k) * W_STRIDE + 32]; pa[set][3] = ap[(k) * W_STRIDE + 48];        \
+  }
+        URF_LOAD(0, 0)
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) URF_KSTEP(k)
+        for (int ks = 0; ks < 16; ++ks) {
+          const int cur = ks & 1;
+          if (ks + 1 < 16) URF_LOAD(cur ^ 1, 4 * (ks + 1))
+          __builtin_amdgcn_sched_barrier(0);  // next step's DS reads are issued before this step's MFMAs
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              acc[m][r2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][m], pb[cur][r2], acc[m][r2], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#undef URF_LOAD
       } else {
         for (int k = 0; k < kc; k += 4) URF_KSTEP(k)
       }

@@ -87,19 +87,28 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(ConvArgs a) {
     commit();
     __syncthreads();
     if (ch + 1 < nchunks) issue(ch + 1);
+    // software pipeline: operand reads of k-step ks+1 are issued before the 16
+    // MFMAs of k-step ks (two register sets, pinned with sched_barrier)
+    float pa[2][4], pb[2][4];
+#define G_LOAD(set, k)                                                        \
+  {                                                                           \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) pa[set][m] = ap[(k) * G_W_STRIDE + 16 * m];      \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) pb[set][r] = bp[r * 16 * G_IN_STRIDE + (k)];     \
+  }
+    G_LOAD(0, 0)
 #pragma unroll
-    for (int k = 0; k < 64; k += 4) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) av[m] = ap[k * G_W_STRIDE + 16 * m];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = bp[r * 16 * G_IN_STRIDE + k];
+    for (int ks = 0; ks < 16; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < 16) G_LOAD(cur ^ 1, 4 * (ks + 1))
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[r], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][m], pb[cur][r], acc[m][r], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef G_LOAD
     __syncthreads();
   }
 

@@ -151,11 +151,23 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][N
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       const float *ap = kv[ch & 1][kh] + px * KSTR + g;
+      {  // software pipeline over the 16 k-steps: reads of step s+1 before the MFMAs of step s
+        float ka[2][4];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
+        for (int kt = 0; kt < 4; ++kt) ka[0][kt] = ap[kt * 16 * KSTR];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kt * 16 * KSTR + 4 * s], qreg[s], acc[kt], 0, 0, 0);
+        for (int s = 0; s < 16; ++s) {
+          const int cur = s & 1;
+          if (s + 1 < 16) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) ka[cur ^ 1][kt] = ap[kt * 16 * KSTR + 4 * (s + 1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[cur][kt], qreg[s], acc[kt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
