@@ -98,6 +98,10 @@ typedef struct {
   int ransac_iterations;      /* 0 -> 200 */
   float ransac_sigma;         /* 0 -> 1.0 */
   uint32_t ransac_seed;
+  /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the 18 GNN
+   * layers run on the f16 matrix core with split operands (fp32-equivalent
+   * accuracy, not bit-reproducible) */
+  int precision;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -171,6 +175,9 @@ int urf_set_profiling(int enable);
 /* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);
+/* split-f16 GEMM probe (fast precision mode): Y = X W + bias, avg ms over reps */
+int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
+                     int reps, float *ms_out, int device);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
 
 #ifdef __cplusplus

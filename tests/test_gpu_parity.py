@@ -319,3 +319,35 @@ def test_epipolar_reconstruct_bit_exact_vs_oracle(F, O, pm, kw, its):
     assert np.array_equal(T, oT) and np.array_equal(tri, otri) and np.array_equal(P, oP)
     ok7, *_ = eg.reconstruct(k1[:7], k2, np.arange(7, dtype=np.int32))
     assert not ok7
+
+
+# ------------------------------------------------ fast precision mode (split-f16)
+def test_split_f16_gemm_is_fp32_accurate(F):
+    rng = np.random.default_rng(0)
+    for (M, N, K) in [(300, 128, 64), (1000, 256, 512), (2000, 768, 256)]:
+        X = (rng.standard_normal((M, K)) * 3).astype(np.float32)
+        W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        Y, _ = F.probe_h2gemm(X, W, b, reps=1)
+        ref = X.astype(np.float64) @ W.astype(np.float64) + b
+        assert np.abs(Y - ref).max() <= 4e-6 * np.abs(ref).max()      # same class as an fp32 GEMM
+
+
+@pytest.mark.parametrize("n0,n1,seed", [(17, 130, 1), (300, 257, 3), (1000, 1024, 4)])
+def test_fast_mode_superglue_matches_exact_mode(F, O, sg_blob, n0, n1, seed):
+    """precision=1 (GNN on the f16 matrix core, split operands) against the exact
+    mode: log-assignment within the north_star tolerance 1e-3, identical matches."""
+    rng = np.random.default_rng(seed)
+    f0 = make_features(rng, n0)
+    f1 = make_features(rng, n1, planted_from=f0, m=min(n0, n1) // 2)
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
+    ex = F.SuperGlue(F.SuperGlueConfig())
+    fa = F.SuperGlue(F.SuperGlueConfig(), precision=1)
+    assert ex.build(sg_blob) and fa.build(sg_blob)
+    i0, i1, m0, m1, Z = ex.infer(nf0, nf1, want_scores=True)
+    j0, j1, q0, q1, Zf = fa.infer(nf0, nf1, want_scores=True)
+    assert np.abs(Zf - Z).max() < 1e-3
+    conf = m0 > 0.6                                          # matches away from the 0.5 threshold
+    assert np.array_equal(i0[conf], j0[conf])
+    assert (i0 != j0).sum() <= max(1, n0 // 200) and (i1 != j1).sum() <= max(1, n1 // 200)
+    assert np.abs(q0 - m0).max() < 1e-3

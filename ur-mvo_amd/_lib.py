@@ -18,7 +18,7 @@ SYMBOLS = [
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
     "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_sync",
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
-    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct",
+    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm",
 ]
 
 
@@ -30,7 +30,8 @@ class SPConfig(C.Structure):
 class SGConfig(C.Structure):
     _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("matching_threshold", C.c_double),
                 ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
-                ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32)]
+                ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
+                ("precision", C.c_int)]
 
 
 class EpiConfig(C.Structure):

@@ -3,7 +3,7 @@
 // and PointMatching::MatchingPoints (src/point_matching.cc:14-61): persistent
 // arena, weight repack (fused QKV), one HIP stream, batched pairs.
 #include "../../include/urf.h"
-#include "urf_common.h"
+#include "h2.h"
 
 #include <math.h>
 #include <string.h>
@@ -49,6 +49,13 @@ struct urf_pm {
   struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2; } L[18];
   size_t wf, bf;
   float bin_score = 1.0f;
+  // fast precision mode (split-f16 MFMA): transposed weights as hi/lo f16 planes
+  int precision = 0;
+  _Float16 *d_wh = nullptr, *d_wl = nullptr;
+  struct { size_t qk, v, m, w1, w2; } H[18];
+  size_t hwf = 0;
+  _Float16 *xh = nullptr, *xl = nullptr, *qkh = nullptr, *qkl = nullptr, *vth = nullptr, *vtl = nullptr, *oh = nullptr,
+           *ol = nullptr, *mh = nullptr, *ml = nullptr, *hh = nullptr, *hl = nullptr;
   // activations
   int *counts = nullptr;
   float *kin = nullptr, *kxy = nullptr, *x = nullptr, *tA = nullptr, *tB = nullptr, *qkv = nullptr, *o = nullptr,
@@ -93,6 +100,8 @@ extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
   h->iters = cfg->sinkhorn_iterations > 0 ? cfg->sinkhorn_iterations : 100;
   h->r_iters = cfg->ransac_iterations > 0 ? cfg->ransac_iterations : 200;
   h->r_sigma = cfg->ransac_sigma > 0 ? cfg->ransac_sigma : 1.0f;
+  h->precision = cfg->precision;
+  URF_CHECK(h->precision == 0 || h->precision == 1, "precision must be 0 (exact fp32) or 1 (fast split-f16)");
   *out = h;
   return 0;
 }
@@ -151,6 +160,46 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_HIP(hipMemcpy(h->d_w, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
 
   const size_t P = h->maxP, NI = 2 * P;
+  if (h->precision == 1) {
+    // W^T [cout][cin] as (hi, lo) f16 planes for h2gemm
+    std::vector<_Float16> wh, wl;
+    auto putT = [&](const float *w, int cin, int cout) {  // w: [cin][cout] fp32
+      const size_t off = wh.size();
+      wh.resize(off + (size_t)cin * cout);
+      wl.resize(off + (size_t)cin * cout);
+      for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+          const float v = w[(size_t)c * cout + o];
+          const _Float16 hi = (_Float16)v;
+          wh[off + (size_t)o * cin + c] = hi;
+          wl[off + (size_t)o * cin + c] = (_Float16)(v - (float)hi);
+        }
+      return off;
+    };
+    const float *q = blob + 109376;  // first GNN layer (after the keypoint encoder)
+    for (int l = 0; l < SG_LAYERS; ++l) {
+      const float *wq = q, *wk = wq + 65536 + 256, *wv = wk + 65536 + 256, *wm = wv + 65536 + 256;
+      const float *w1 = wm + 65536 + 256, *w2 = w1 + 262144 + 512;
+      q = w2 + 131072 + 256;
+      h->H[l].qk = putT(wq, 256, 256);
+      putT(wk, 256, 256);                 // rows 256..511 of the fused [512][256] matrix
+      h->H[l].v = putT(wv, 256, 256);
+      h->H[l].m = putT(wm, 256, 256);
+      h->H[l].w1 = putT(w1, 512, 512);
+      h->H[l].w2 = putT(w2, 512, 256);
+    }
+    h->hwf = putT(q, 256, 256);
+    URF_HIP(hipMalloc((void **)&h->d_wh, wh.size() * 2));
+    URF_HIP(hipMalloc((void **)&h->d_wl, wl.size() * 2));
+    URF_HIP(hipMemcpy(h->d_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+    URF_HIP(hipMemcpy(h->d_wl, wl.data(), wl.size() * 2, hipMemcpyHostToDevice));
+    if (dalloc(&h->xh, NI * NP * 256) || dalloc(&h->xl, NI * NP * 256)) return -1;
+    if (dalloc(&h->qkh, NI * NP * 512) || dalloc(&h->qkl, NI * NP * 512)) return -1;
+    if (dalloc(&h->vth, NI * NP * 256) || dalloc(&h->vtl, NI * NP * 256)) return -1;
+    if (dalloc(&h->oh, NI * NP * 256) || dalloc(&h->ol, NI * NP * 256)) return -1;
+    if (dalloc(&h->mh, NI * NP * 256) || dalloc(&h->ml, NI * NP * 256)) return -1;
+    if (dalloc(&h->hh, NI * NP * 512) || dalloc(&h->hl, NI * NP * 512)) return -1;
+  }
   if (dalloc(&h->counts, NI)) return -1;
   if (dalloc(&h->kin, NI * NP * 4)) return -1;
   if (dalloc(&h->kxy, NI * NP * 2)) return -1;
@@ -211,7 +260,8 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
-    void *bufs[] = {h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
+    void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->mh, h->ml, h->hh, h->hl,
+                    h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs};
@@ -243,6 +293,52 @@ static int sg_linear(urf_pm *h, int nimg, const float *in, int in_ld, int cin, c
   return launch_conv(a, 1, false, false, nimg, h->st);
 }
 
+// fast mode linear layer: split-f16 GEMM over all 2P images
+static int h2_linear(urf_pm *h, int nimg, const _Float16 *xh, const _Float16 *xl, int ldx, int cin, const _Float16 *x2h,
+                     const _Float16 *x2l, int ldx2, int cin1, size_t w, size_t bias, int cout, float *out, _Float16 *oh,
+                     _Float16 *ol, int ld_out, bool relu, const float *res, bool transposed) {
+  H2Args a = {};
+  a.xh = xh; a.xl = xl; a.ldx = ldx; a.x_bstride = (long)NP * ldx;
+  a.x2h = x2h; a.x2l = x2l; a.ldx2 = ldx2; a.x2_bstride = (long)NP * ldx2; a.Cin1 = cin1;
+  a.rows = NP; a.Cin = cin;
+  a.wh = h->d_wh + w; a.wl = h->d_wl + w; a.bias = h->d_w + bias; a.Cout = cout;
+  a.relu = relu ? 1 : 0; a.res = res; a.counts = h->counts;
+  if (transposed) {
+    a.ohT = oh; a.olT = ol; a.ldT = NP; a.outT_bstride = (long)cout * NP;
+  } else {
+    a.out = out; a.oh = oh; a.ol = ol; a.ld_out = ld_out; a.out_bstride = (long)NP * ld_out;
+  }
+  return launch_h2gemm(a, nimg, h->st);
+}
+
+// the 18 GNN layers in the fast precision mode
+static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
+  hipStream_t st = h->st;
+  if (launch_split(h->x, (size_t)NI * NP * 256, h->xh, h->xl, st)) return -1;
+  for (int l = 0; l < SG_LAYERS; ++l) {
+    // Q | K (token-major) and V^T ([d][token]) projections
+    if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->H[l].qk, h->L[l].bqkv, 512, nullptr, h->qkh,
+                  h->qkl, 512, false, nullptr, false))
+      return -1;
+    if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->H[l].v, h->L[l].bqkv + 512, 256, nullptr,
+                  h->vth, h->vtl, 0, false, nullptr, true))
+      return -1;
+    if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
+    if (launch_attn_h2(h->qkh, h->qkl, h->vth, h->vtl, h->counts, l & 1, h->oh, h->ol, NI, st)) return -1;
+    if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
+    if (h2_linear(h, NI, h->oh, h->ol, 256, 256, nullptr, nullptr, 0, 0, h->H[l].m, h->L[l].bm, 256, nullptr, h->mh, h->ml,
+                  256, false, nullptr, false))
+      return -1;
+    if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->mh, h->ml, 256, 256, h->H[l].w1, h->L[l].b1, 512, nullptr, h->hh,
+                  h->hl, 512, true, nullptr, false))
+      return -1;
+    if (h2_linear(h, NI, h->hh, h->hl, 512, 512, nullptr, nullptr, 0, 0, h->H[l].w2, h->L[l].b2, 256, h->x, h->xh, h->xl,
+                  256, false, h->x, false))
+      return -1;
+  }
+  return 0;
+}
+
 // the whole matching pipeline for P pairs whose inputs (counts, kin, kxy, x) are in place
 static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   hipStream_t st = h->st;
@@ -257,6 +353,9 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   if (sg_linear(h, NI, h->tA, 256, 128, nullptr, 0, 0, h->kw[3], h->kb[3], 256, h->tB, 256, true, nullptr)) return -1;
   if (sg_linear(h, NI, h->tB, 256, 256, nullptr, 0, 0, h->kw[4], h->kb[4], 256, h->x, 256, false, h->x)) return -1;
   mark(PT_GNN);
+  if (h->precision == 1) {
+    if (pm_gnn_fast(h, NI, prof)) return -1;
+  } else
   for (int l = 0; l < SG_LAYERS; ++l) {
     if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->L[l].wqkv, h->L[l].bqkv, 768, h->qkv, 768, false, nullptr))
       return -1;
@@ -271,7 +370,11 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
       return -1;
   }
   mark(PT_SCORE);
-  if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
+  if (h->precision == 1) {
+    if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->hwf, h->bf, 256, h->mdesc, nullptr, nullptr, 256, false,
+                  nullptr, false))
+      return -1;
+  } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
   if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, st)) return -1;

@@ -143,10 +143,10 @@ PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac
 
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
-                 ransac_sigma=1.0, ransac_seed=0):
+                 ransac_sigma=1.0, ransac_seed=0, precision=0):
         self.cfg = cfg
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
-                           max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed)
+                           max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 
@@ -286,6 +286,19 @@ def probe_fma_gemm(A, B, bias=None, device=0):
         bias = np.ascontiguousarray(bias, np.float32)
     check(_lib.lib().urf_probe_fma_gemm(_p(A), _p(B), _p(bias), M, N, K, _p(out), device), "probe_fma_gemm")
     return out
+
+
+def probe_h2gemm(X, W, bias=None, reps=10, device=0):
+    X = np.ascontiguousarray(X, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, K = X.shape
+    N = W.shape[1]
+    Y = np.zeros((M, N), np.float32)
+    ms = C.c_float(0)
+    if bias is not None:
+        bias = np.ascontiguousarray(bias, np.float32)
+    check(_lib.lib().urf_probe_h2gemm(_p(X), _p(W), _p(bias), M, N, K, _p(Y), reps, C.byref(ms), device), "probe_h2gemm")
+    return Y, float(ms.value)
 
 
 def probe_math(x, device=0):
