@@ -42,6 +42,10 @@ typedef struct {
   int max_height, max_width;  /* arena is sized for these at build(); 0 -> 1500 (profile max, src/super_point.cpp:55-60) */
   int max_batch;              /* frames per urf_sp_infer_batch call; 0 -> 1 */
   int device;                 /* HIP device ordinal */
+  /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the eight
+   * 3x3 convolutions run on the f16 matrix core with split operands
+   * (fp32-equivalent accuracy, not bit-reproducible) */
+  int precision;
 } urf_sp_config;
 
 typedef struct urf_sp urf_sp;

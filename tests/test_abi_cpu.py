@@ -27,7 +27,7 @@ def test_no_gpu_fails_loudly_not_silently(U):
     L = U._lib.lib()
     if L.urf_device_count() > 0:
         pytest.skip("GPU present")
-    cfg = U._lib.SPConfig(1000, 0.0005, 4, 480, 640, 1, 0)
+    cfg = U._lib.SPConfig(1000, 0.0005, 4, 480, 640, 1, 0, 0)
     h = C.c_void_p()
     rc = L.urf_sp_create(C.byref(cfg), C.byref(h))
     assert rc < 0 and not h.value

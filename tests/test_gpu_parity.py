@@ -351,3 +351,31 @@ def test_fast_mode_superglue_matches_exact_mode(F, O, sg_blob, n0, n1, seed):
     assert np.array_equal(i0[conf], j0[conf])
     assert (i0 != j0).sum() <= max(1, n0 // 200) and (i1 != j1).sum() <= max(1, n1 // 200)
     assert np.abs(q0 - m0).max() < 1e-3
+
+
+@pytest.mark.parametrize("H,W,seed", [(120, 160, 1), (250, 333, 3), (480, 640, 11), (376, 1241, 12)])
+def test_fast_mode_superpoint_matches_exact_mode(U, F, O, sp_blob, H, W, seed):
+    """precision=1 (3x3 convs on the f16 matrix core, split operands): dense maps
+    agree with the exact mode like the torch run of the reference graph does
+    (1e-5 / 1e-6); the keypoint set is the same up to near-ties at the top-k cut."""
+    img = U.synth.shift_stream(seed, 1, H, W)[0]
+    ex = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W)
+    fa = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, precision=1)
+    assert ex.build(sp_blob) and fa.build(sp_blob)
+    fe, ff = ex.infer(img), fa.infer(img)
+    Hc, Wc = H // 8, W // 8
+    he, hf = ex.debug_tensor(1, (Hc * 8, Wc * 8)), fa.debug_tensor(1, (Hc * 8, Wc * 8))
+    np.testing.assert_allclose(hf, he, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(fa.debug_tensor(2, (Hc, Wc, 256)), ex.debug_tensor(2, (Hc, Wc, 256)), rtol=1e-3, atol=1e-5)
+    se, sf = ex.debug_tensor(0, (Hc * 8, Wc * 8)), fa.debug_tensor(0, (Hc * 8, Wc * 8))
+    assert ((se != 0) != (sf != 0)).sum() <= 2                       # NMS support: at most a near-tie flips
+    ke = {(int(r[1]), int(r[2])) for r in fe}
+    kf = {(int(r[1]), int(r[2])) for r in ff}
+    assert len(ke ^ kf) <= max(2, len(ke) // 200)
+    common = sorted(ke & kf)
+    de = {(int(r[1]), int(r[2])): r for r in fe}
+    df = {(int(r[1]), int(r[2])): r for r in ff}
+    A = np.array([de[k] for k in common])
+    Bm = np.array([df[k] for k in common])
+    assert np.abs(A[:, 0] - Bm[:, 0]).max() < 2e-5          # scores
+    assert np.abs(A[:, 3:] - Bm[:, 3:]).max() < 1e-3        # descriptors: north_star tolerance

@@ -14,9 +14,9 @@ F, synth = U.frontend, U.synth
 H, W, B = 480, 640, 8
 spb = synth.pack_sp(synth.sp_weights(0))
 sgb = synth.pack_sg(synth.sg_weights(0))
-sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B)
-assert sp.build(spb)
 PREC = int(os.environ.get('URF_PRECISION', '0'))
+sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B, precision=PREC)
+assert sp.build(spb)
 pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=B, precision=PREC)
 assert pm.build(sgb)
 frames = synth.shift_stream(100, B + 1, H, W)

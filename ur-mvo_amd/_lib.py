@@ -24,7 +24,8 @@ SYMBOLS = [
 
 class SPConfig(C.Structure):
     _fields_ = [("max_keypoints", C.c_int), ("keypoint_threshold", C.c_double), ("remove_borders", C.c_int),
-                ("max_height", C.c_int), ("max_width", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+                ("max_height", C.c_int), ("max_width", C.c_int), ("max_batch", C.c_int), ("device", C.c_int),
+                ("precision", C.c_int)]
 
 
 class SGConfig(C.Structure):

@@ -24,6 +24,20 @@ struct H2Args {
   int ldT;
   long outT_bstride;
 };
+// fast 3x3 convolution (h2conv.hip).  Activations: NHWC f16 planes [B][H][W][Cin].
+struct H2ConvArgs {
+  const _Float16 *xh, *xl;   // input planes (unused when fused with conv1a)
+  int H, W, Cin;             // conv spatial size, Cin % 64 == 0
+  const _Float16 *wh, *wl;   // weights [tap][Cout][Cin] f16 planes
+  const float *bias;
+  int Cout;                  // % 64 == 0
+  _Float16 *oh, *ol;         // output planes (pooled size when POOL), or
+  float *out;                // fp32 output (OUTF32)
+  // fused conv1a: u8 image [B][H][W], fp32 weights [9][64], bias[64], u8->f32 table
+  const uint8_t *img;
+  const float *w1a, *b1a, *lut;
+};
+int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int batch, hipStream_t st);
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st);
 int launch_split(const float *x, size_t n, _Float16 *h, _Float16 *l, hipStream_t st);
 int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,

@@ -4,7 +4,7 @@
 // repack, the kernel pipeline on one HIP stream, pinned staging buffers.
 // Mirrors SuperPoint::build / infer (src/super_point.cpp:18-156).
 #include "../../include/urf.h"
-#include "urf_common.h"
+#include "h2.h"
 
 #include <stdarg.h>
 #include <string.h>
@@ -59,6 +59,10 @@ struct urf_sp {
   size_t wpd_off = 0, bpd_off = 0;  // convPa||convDa concatenated [9][128][512], bias[512]
   size_t wpb_off = 0, bpb_off = 0;  // convPb padded to 68 couts
   size_t lut_off = 0;
+  // fast precision mode: conv weights [tap][Cout][Cin] as (hi, lo) f16 planes
+  int precision = 0;
+  _Float16 *d_wh = nullptr, *d_wl = nullptr;
+  size_t hw_off[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, Pa||Da
   // activations
   float *a1 = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
         *a4b = nullptr, *apd = nullptr, *logits = nullptr, *ddb = nullptr, *desc = nullptr;
@@ -108,6 +112,8 @@ extern "C" int urf_sp_create(const urf_sp_config *cfg, urf_sp **out) {
   h->maxB = cfg->max_batch > 0 ? cfg->max_batch : 1;
   h->maxH = cfg->max_height > 0 ? cfg->max_height : 1500;
   h->maxW = cfg->max_width > 0 ? cfg->max_width : 1500;
+  h->precision = cfg->precision;
+  URF_CHECK(h->precision == 0 || h->precision == 1, "precision must be 0 (exact fp32) or 1 (fast split-f16)");
   *out = h;
   return 0;
 }
@@ -173,6 +179,40 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_HIP(hipMalloc((void **)&h->d_wts, host.size() * sizeof(float)));
   URF_HIP(hipMemcpy(h->d_wts, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
 
+  if (h->precision == 1) {
+    std::vector<_Float16> wh, wl;
+    auto putc = [&](const float *w, int cin, int cout, int coff, int ctot, size_t base) {
+      // w: [9][cin][cout] fp32 -> planes [9][ctot][cin] at rows coff..coff+cout
+      for (int t = 0; t < 9; ++t)
+        for (int o = 0; o < cout; ++o)
+          for (int c = 0; c < cin; ++c) {
+            const float v = w[((size_t)t * cin + c) * cout + o];
+            const _Float16 hi = (_Float16)v;
+            const size_t idx = base + ((size_t)t * ctot + coff + o) * cin + c;
+            wh[idx] = hi;
+            wl[idx] = (_Float16)(v - (float)hi);
+          }
+    };
+    for (int i = 1; i <= 7; ++i) {
+      const size_t base = wh.size();
+      wh.resize(base + (size_t)9 * kSpConv[i].cin * kSpConv[i].cout);
+      wl.resize(wh.size());
+      putc(src_w[i], kSpConv[i].cin, kSpConv[i].cout, 0, kSpConv[i].cout, base);
+      h->hw_off[i - 1] = base;
+    }
+    {
+      const size_t base = wh.size();
+      wh.resize(base + (size_t)9 * 128 * 512);
+      wl.resize(wh.size());
+      putc(src_w[8], 128, 256, 0, 512, base);
+      putc(src_w[10], 128, 256, 256, 512, base);
+      h->hw_off[7] = base;
+    }
+    URF_HIP(hipMalloc((void **)&h->d_wh, wh.size() * 2));
+    URF_HIP(hipMalloc((void **)&h->d_wl, wl.size() * 2));
+    URF_HIP(hipMemcpy(h->d_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+    URF_HIP(hipMemcpy(h->d_wl, wl.data(), wl.size() * 2, hipMemcpyHostToDevice));
+  }
   // ---- arena for the largest frame
   const size_t B = h->maxB, H = h->maxH, W = h->maxW;
   const size_t H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
@@ -258,7 +298,7 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
-    void *bufs[] = {h->d_wts, h->d_img, h->d_usermask, h->a1, h->a2a, h->a2b, h->a3a, h->a3b, h->a4a, h->a4b, h->apd,
+    void *bufs[] = {h->d_wh, h->d_wl, h->d_wts, h->d_img, h->d_usermask, h->a1, h->a2a, h->a2b, h->a3a, h->a3b, h->a4a, h->a4b, h->apd,
                     h->logits, h->ddb, h->desc, h->heat, h->scores, h->ss, h->mask, h->supp, h->counts,
                     h->cand_score, h->cand_idx, h->cand_n, h->kp_score, h->kp_idx, h->kp_n, h->d_feat, h->d_slots};
     for (void *p : bufs) (void)hipFree(p);
@@ -270,6 +310,55 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     (void)hipStreamDestroy(h->st);
   }
   delete h;
+}
+
+// the eight 3x3 convolutions in the fast precision mode (h2conv.hip).  Each fp32
+// activation buffer of N floats is reused as two f16 planes of N halfs.
+static int sp_convs_fast(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W) {
+  const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
+  hipStream_t st = h->st;
+  const float *wt = h->d_wts;
+  const bool prof = urf::g_profiling != 0;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
+  auto planes = [&](float *buf, size_t n, _Float16 **hi, _Float16 **lo) { *hi = (_Float16 *)buf; *lo = (_Float16 *)buf + n; };
+  auto conv = [&](float *in, int cin, int hh, int ww, int widx, const float *bias, int cout, float *out, bool pool,
+                  bool outf32) {
+    H2ConvArgs a = {};
+    _Float16 *ih, *il;
+    planes(in, (size_t)B * hh * ww * cin, &ih, &il);
+    a.xh = ih; a.xl = il; a.H = hh; a.W = ww; a.Cin = cin;
+    a.wh = h->d_wh + h->hw_off[widx]; a.wl = h->d_wl + h->hw_off[widx]; a.bias = bias; a.Cout = cout;
+    if (outf32) a.out = out;
+    else {
+      const size_t no = pool ? (size_t)B * (hh / 2) * (ww / 2) * cout : (size_t)B * hh * ww * cout;
+      planes(out, no, &a.oh, &a.ol);
+    }
+    return launch_h2conv(a, pool, false, outf32, B, st);
+  };
+  mark(ST_CONV1);
+  {
+    H2ConvArgs a = {};
+    a.H = H; a.W = W; a.Cin = 64; a.wh = h->d_wh + h->hw_off[0]; a.wl = h->d_wl + h->hw_off[0];
+    a.bias = wt + h->b_off[1]; a.Cout = 64;
+    planes(h->a1, (size_t)B * H2 * W2 * 64, &a.oh, &a.ol);
+    a.img = d_imgs; a.w1a = wt + h->w_off[0]; a.b1a = wt + h->b_off[0]; a.lut = wt + h->lut_off;
+    if (launch_h2conv(a, true, true, false, B, st)) return -1;
+  }
+  mark(ST_CONV2A);
+  if (conv(h->a1, 64, H2, W2, 1, wt + h->b_off[2], 64, h->a2a, false, false)) return -1;
+  mark(ST_CONV2B);
+  if (conv(h->a2a, 64, H2, W2, 2, wt + h->b_off[3], 64, h->a2b, true, false)) return -1;
+  mark(ST_CONV3A);
+  if (conv(h->a2b, 64, H4, W4, 3, wt + h->b_off[4], 128, h->a3a, false, false)) return -1;
+  mark(ST_CONV3B);
+  if (conv(h->a3a, 128, H4, W4, 4, wt + h->b_off[5], 128, h->a3b, true, false)) return -1;
+  mark(ST_CONV4A);
+  if (conv(h->a3b, 128, H8, W8, 5, wt + h->b_off[6], 128, h->a4a, false, false)) return -1;
+  mark(ST_CONV4B);
+  if (conv(h->a4a, 128, H8, W8, 6, wt + h->b_off[7], 128, h->a4b, false, false)) return -1;
+  mark(ST_PADA);
+  if (conv(h->a4b, 128, H8, W8, 7, wt + h->bpd_off, 512, h->apd, false, true)) return -1;
+  return 0;
 }
 
 // The kernel pipeline for B frames already resident in h->d_img (or d_imgs).
@@ -291,6 +380,9 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
     a.relu = 1;
     return launch_conv(a, 9, pool, false, B, st);
   };
+  if (h->precision == 1) {
+    if (sp_convs_fast(h, B, d_imgs, H, W)) return -1;
+  } else {
   mark(ST_CONV1);
   {  // conv1a (fused, VALU) + conv1b + relu + pool
     ConvArgs a = {};
@@ -314,6 +406,7 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   if (conv3(h->a4a, 128, H8, W8, wt + h->w_off[7], wt + h->b_off[7], 128, h->a4b, false)) return -1;
   mark(ST_PADA);
   if (conv3(h->a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, h->apd, false)) return -1;
+  }
   const int ncell = H8 * W8;
   mark(ST_PB);
   {  // convPb 1x1 on channels [0,256) of apd -> logits (68-wide rows)

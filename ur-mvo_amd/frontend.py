@@ -53,10 +53,10 @@ class SuperGlueConfig:
 class SuperPoint:
     """SuperPoint (include/super_point.h:20-33)."""
 
-    def __init__(self, super_point_config, max_height=0, max_width=0, max_batch=1, device=0):
+    def __init__(self, super_point_config, max_height=0, max_width=0, max_batch=1, device=0, precision=0):
         self.cfg = super_point_config
         self._c = SPConfig(super_point_config.max_keypoints, super_point_config.keypoint_threshold,
-                           super_point_config.remove_borders, max_height, max_width, max_batch, device)
+                           super_point_config.remove_borders, max_height, max_width, max_batch, device, precision)
         self._h = C.c_void_p()
         self._built = False
         check(_lib.lib().urf_sp_create(C.byref(self._c), C.byref(self._h)), "urf_sp_create")
