@@ -15,7 +15,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CTH = 8, CTW = 16, CPH = 10, CPW = 18;
-constexpr int CS = 72;   // halfs per LDS row (64 channels + 8 pad)
+constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-free ds_read_b128
 
 template <bool POOL, bool FUSE1A, bool OUTF32>
 __global__ void __launch_bounds__(256, 2) h2conv_kernel(H2ConvArgs a) {
@@ -188,7 +188,7 @@ int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int 
   const size_t lds = sizeof(_Float16) * (2 * CPH * CPW * CS + 2 * 64 * CS) + (fuse1a ? 12 * 20 * 4 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    const int mx = 76 * 1024;
+    const int mx = 80 * 1024;
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

@@ -19,10 +19,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 
 
-constexpr int HS = 72;  // LDS row stride in halfs (64 + 8 pad = 144 B)
+constexpr int BK = 32;  // K chunk = one 32-deep MFMA step: small LDS/VGPR footprint -> 2 workgroups (16 waves) per CU
+constexpr int HS = 48;  // LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
 
 template <bool TOUT>
-__global__ void __launch_bounds__(512, 1) h2gemm_kernel(H2Args a) {
+__global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
   _Float16 *Ah = hsm, *Bh = hsm + 2 * 128 * HS;  // planes: Ah | Al | Bh | Bl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,15 +47,15 @@ __global__ void __launch_bounds__(512, 1) h2gemm_kernel(H2Args a) {
     acc[m][0] = bv; acc[m][1] = bv;
   }
 
-  // staging: per chunk 4 planes x 128 rows x 8 (16-byte pieces) = 4096 pieces / 512 threads = 8
-  f16x8 pf[8];
+  // staging: per chunk 4 planes x 128 rows x 4 (16-byte pieces) = 2048 pieces / 512 threads = 4
+  f16x8 pf[4];
   auto issue = [&](int ch) {
-    const int c0 = ch * 64;
+    const int c0 = ch * BK;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = tid + 512 * u;        // 0..4095
-      const int plane = i >> 10;          // 0: Ah 1: Al 2: Bh 3: Bl
-      const int r = (i >> 3) & 127, j = i & 7;
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 512 * u;        // 0..2047
+      const int plane = i >> 9;           // 0: Ah 1: Al 2: Bh 3: Bl
+      const int r = (i >> 2) & 127, j = i & 3;
       const int cc = c0 + 8 * j;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (plane < 2) {
@@ -75,14 +76,14 @@ __global__ void __launch_bounds__(512, 1) h2gemm_kernel(H2Args a) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int i = tid + 512 * u;
-      const int plane = i >> 10, r = (i >> 3) & 127, j = i & 7;
+      const int plane = i >> 9, r = (i >> 2) & 127, j = i & 3;
       *(f16x8 *)(hsm + plane * 128 * HS + r * HS + 8 * j) = pf[u];
     }
   };
 
-  const int nchunks = a.Cin >> 6;
+  const int nchunks = a.Cin / BK;
   issue(0);
   const _Float16 *ap = Ah + (wc * 64 + px) * HS + 8 * g;   // + m*16*HS (+128*HS for lo)
   const _Float16 *bp = Bh + (wr * 32 + px) * HS + 8 * g;   // + r*16*HS
@@ -90,8 +91,8 @@ __global__ void __launch_bounds__(512, 1) h2gemm_kernel(H2Args a) {
     commit();
     __syncthreads();
     if (ch + 1 < nchunks) issue(ch + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    {
+      const int ks = 0;
       f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -175,11 +176,11 @@ __global__ void __launch_bounds__(512, 1) h2gemm_kernel(H2Args a) {
 
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0, "h2gemm: unsupported shape %d x %d", a.Cout, a.Cin);
-  const size_t lds = sizeof(_Float16) * 4 * 128 * HS;  // 73 728 B
+  const size_t lds = sizeof(_Float16) * 4 * 128 * HS;  // 81 920 B
   static bool attr_done = false;
   if (!attr_done) {
-    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
+    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
     attr_done = true;
   }
   dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);

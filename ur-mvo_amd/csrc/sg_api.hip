@@ -21,7 +21,7 @@ int launch_attn(const float *qkv, const int *counts, int cross, float *o, int ni
 int launch_score(const float *mdesc, const int *counts, float alpha, float *C, float *Ct, float *u, float *v, int P,
                  hipStream_t st);
 int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
-                    hipStream_t st);
+                    bool fast, hipStream_t st);
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int P,
@@ -377,7 +377,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
-  if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, st)) return -1;
+  if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, h->precision == 1, st)) return -1;
   mark(PT_DECODE);
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
                     h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,

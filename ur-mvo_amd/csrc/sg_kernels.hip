@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 // One wave per row.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
 // per row); `add` is staged once per workgroup in LDS; the sum is the canonical
 // wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
-template <bool ROWPASS>
+template <bool ROWPASS, bool FAST>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
   __shared__ __attribute__((aligned(16))) float sadd[LDC + 256];
@@ -379,14 +379,14 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
     const int c = 256 * t + 4 * lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (c + r < Cn) s = s + exp_c_nonpos(x[t][r] - m);
+      if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
   }
   s = bfly64_sum(s);
   if (lane == 0) {
     const float norm = -log_c((float)(n0 + n1));
     const int last = R - 1;
     const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
-    out[(size_t)p * LDC + row] = lm - (m + log_c(s));
+    out[(size_t)p * LDC + row] = lm - (m + (FAST ? __logf(s) : log_c(s)));
   }
 }
 
@@ -527,11 +527,16 @@ int launch_score(const float *mdesc, const int *counts, float alpha, float *C, f
   return 0;
 }
 int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
-                    hipStream_t st) {
+                    bool fast, hipStream_t st) {
   const dim3 grid((NP + 1 + 3) / 4, P), block(256);
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL((sinkhorn_half_kernel<true>), grid, block, 0, st, counts, C, v, u);
-    hipLaunchKernelGGL((sinkhorn_half_kernel<false>), grid, block, 0, st, counts, Ct, u, v);
+    if (fast) {
+      hipLaunchKernelGGL((sinkhorn_half_kernel<true, true>), grid, block, 0, st, counts, C, v, u);
+      hipLaunchKernelGGL((sinkhorn_half_kernel<false, true>), grid, block, 0, st, counts, Ct, u, v);
+    } else {
+      hipLaunchKernelGGL((sinkhorn_half_kernel<true, false>), grid, block, 0, st, counts, C, v, u);
+      hipLaunchKernelGGL((sinkhorn_half_kernel<false, false>), grid, block, 0, st, counts, Ct, u, v);
+    }
   }
   URF_HIP(hipGetLastError());
   return 0;
