@@ -30,6 +30,7 @@ MAX_KP = 1000
 # algorithmic work, SURVEY.md 8(d): GFLOP per 640x480 frame / per pair at n=1000
 GF_CONV1 = 22.649 + 0.354          # conv1b + fused conv1a
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+F16_MFMA_PEAK_TF = 2500.0          # dense f16/bf16 MFMA peak (v_mfma_f32_16x16x32_f16)
 
 
 def sg_linear_gflop(n0, n1):
@@ -52,6 +53,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+                    help="1 = fast (split-f16 MFMA, fp32-equivalent accuracy, default); 0 = exact fp32 (bit-identical to the oracle)")
+    ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -80,22 +84,24 @@ def main():
     F, synth, D = U.frontend, U.synth, U.dist
     spb = synth.pack_sp(synth.sp_weights(0))
     sgb = synth.pack_sg(synth.sg_weights(0))
+    PREC = args.precision
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
-                      device=local_rank)
+                      device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
-    pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank)
+    pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank,
+                         precision=PREC)
     assert pm.build(sgb), U._lib.lib().urf_last_error()
 
     # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
     # = frames [k*8*world, (k+1)*8*world); rank g owns the block [g*8, g*8+8) of
-    # it.  3 global batches are cycled.
-    NB = 3
+    # it.  5 global batches are cycled.
+    NB = 5
     stream = synth.shift_stream(100, NB * BATCH * world, H, W)
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
     del stream
     slot_floats = U._lib.lib().urf_slot_bytes() // 4
-    # feature slots of the last 3 global batches (ring): matching batch b needs the
+    # feature slots of the last 5 global batches (ring): matching batch b needs the
     # last slot of batch b-1 while SuperPoint already fills the slots of batch b+1
     ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)
     gathered = [None] * NB
@@ -134,6 +140,7 @@ def main():
 
     sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
     n_matches = []
+    kept = {}                      # batch index -> match lists (last steps), for the exact-mode cross-check
 
     def one_step(b, record):
         if world > 1:
@@ -142,7 +149,7 @@ def main():
             torch.cuda.synchronize()
         pm_step(b)
         sp_step(b + 1)
-        res = pm.fetch(BATCH)              # waits for match(b) only; SP(b+1) keeps the GPU busy
+        res = pm.fetch(BATCH, as_arrays=True)   # waits for match(b) only; SP(b+1) keeps the GPU busy
         if record:
             s = sp.stage_ms(previous=True)  # SP(b), complete since match(b) is
             p = pm.stage_ms()
@@ -150,7 +157,18 @@ def main():
             pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
             sink_ms.append(p[4]); ransac_ms.append(p[6])
             n_matches.append(sum(len(r) for r in res))
+            kept[b] = res
         return res
+
+    def match_coords(res, cur, prev_last):
+        """match lists as sets of pixel correspondences (x0,y0,x1,y1): keypoint ORDER may differ
+        between precision modes (score-sorted, near-ties swap), coordinates do not"""
+        feats = [F.slot_to_host(prev_last.data_ptr())[:, 1:3]] + [F.slot_to_host(cur[j].data_ptr())[:, 1:3] for j in range(BATCH)]
+        out = []
+        for j in range(BATCH):
+            f0, f1 = feats[j], feats[j + 1]
+            out.append({(f0[q, 0], f0[q, 1], f1[t, 0], f1[t, 1]) for q, t in zip(res[j]["queryIdx"], res[j]["trainIdx"])})
+        return out
 
     # prologue: SP(0) so that the loop body is exactly one match + one SP per step
     sp_step(0)
@@ -177,18 +195,71 @@ def main():
         n_avg = float(np.mean(kp))
         # ---- roofline of the dominant kernel (largest summed device time per step)
         per_step = {
-            "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)": (np.mean(conv1_ms), GF_CONV1 * BATCH),
-            "SuperGlue linear layers (conv_mfma_kernel<1>)": (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH),
-            "SuperGlue attention (attn_kernel)": (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH),
+            ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if PREC else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
+                (np.mean(conv1_ms), GF_CONV1 * BATCH),
+            ("SuperGlue linear layers (h2gemm_kernel)" if PREC else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
+                (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH),
+            ("SuperGlue attention (attn_h2_kernel)" if PREC else "SuperGlue attention (attn_kernel)"):
+                (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH),
         }
         dom = max(per_step, key=lambda k: per_step[k][0])
         ms, gf = per_step[dom]
         achieved = gf / ms  # GFLOP / ms = TFLOP/s
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+        # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); `achieved` counts the
+        # ALGORITHMIC flops once, so frac <= 1/3 by construction against the dense f16 peak
+        peak = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "mfma_issue_frac": round(achieved * (3 if PREC == 1 else 1) / peak, 4),
                     "launch_ms": round(float(ms), 4), "algorithmic_gflop_per_step": round(gf, 2),
                     "all_kernels_tflops": {k: round(v[1] / v[0], 2) for k, v in per_step.items()},
                     "all_kernels_ms_per_step": {k: round(float(v[0]), 3) for k, v in per_step.items()}}
+        stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
+                       "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
+        exact = None
+        if world == 1 and PREC == 1 and not args.no_exact_check:
+            # reference pass in the exact fp32 mode (bit-identical to the oracle) on the SAME
+            # batches: its throughput and how far the fast mode's match lists are from it
+            sp2 = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
+                               device=local_rank, precision=0)
+            pm2 = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
+                                  device=local_rank, precision=0)
+            assert sp2.build(spb) and pm2.build(sgb)
+            pm2.share_stream(sp2)
+            ring2 = torch.zeros_like(ring)
+            nst = min(4, args.steps)
+            last = args.warmup + args.steps - 1          # last timed batch of the fast run
+            b0 = last - nst + 1
+            # the fast ring still holds batches last-3 .. last+1: batches last-2 .. last are comparable
+            cmp_batches = [b for b in range(last - 2, last + 1) if b >= b0 + 1 and b in kept]
+            fast_sets = {b: match_coords(kept[b], ring[b % NB], ring[(b - 1) % NB][-1]) for b in cmp_batches}
+            sp2.infer_device(d_frames[((b0 - 1) % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[(b0 - 1) % NB].data_ptr())
+            sp2.infer_device(d_frames[(b0 % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[b0 % NB].data_ptr())
+            sp2.sync()
+            res_exact = {}
+            te = time.perf_counter()
+            for b in range(b0, b0 + nst):
+                cur, prev = ring2[b % NB], ring2[(b - 1) % NB]
+                s0 = [(cur[j - 1] if j > 0 else prev[-1]).data_ptr() for j in range(BATCH)]
+                s1 = [cur[j].data_ptr() for j in range(BATCH)]
+                pm2.match_device_async(s0, s1, True)
+                sp2.infer_device(d_frames[((b + 1) % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[(b + 1) % NB].data_ptr())
+                res_exact[b] = pm2.fetch(BATCH, as_arrays=True)
+            sp2.sync()
+            dte = time.perf_counter() - te
+            same_pairs = tot_pairs = same_m = tot_m = 0
+            for b in cmp_batches:
+                ex_sets = match_coords(res_exact[b], ring2[b % NB], ring2[(b - 1) % NB][-1])
+                for a_, b_ in zip(fast_sets[b], ex_sets):
+                    tot_pairs += 1
+                    same_pairs += int(a_ == b_)
+                    same_m += len(a_ & b_)
+                    tot_m += len(a_ | b_)
+            exact = {"value": round(nst * BATCH / dte, 2), "unit": "frames/s", "dtype": "f32",
+                     "ms_per_step": round(dte / nst * 1e3, 3),
+                     "pairs_with_identical_match_list": f"{same_pairs}/{tot_pairs}",
+                     "match_jaccard_fast_vs_exact": round(same_m / max(tot_m, 1), 6)}
+            del sp2, pm2
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
@@ -209,18 +280,20 @@ def main():
         out = {
             "metric": "VO front-end frames/sec (SP+SG+RANSAC) @640x480", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
+                      if PREC == 1 else "f32"), "data": "synthetic",
             "config": {"workload": "640x480 grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
                                    f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json configs[2])",
                        "resolution": "640x480", "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
-                       "sinkhorn_iterations": 100, "ransac_iterations": 200,
+                       "sinkhorn_iterations": 100, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
                        "weights": "seeded synthetic (reference ships none)",
                        "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "stage_ms_per_step": {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
-                                  "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)},
+            "exact_mode": exact,
+            "stage_ms_per_step": stage_means,
             "matches_per_step": round(float(np.mean(n_matches)), 1),
         }
         print(json.dumps(out))

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import DMatch, SGConfig, SPConfig, check
 
 CAP = 1024
+MATCH_DTYPE = np.dtype([("queryIdx", np.int32), ("trainIdx", np.int32), ("distance", np.float32)])
 
 
 def _p(a):
@@ -218,12 +219,15 @@ class PointMatching(_PM):
         b = (C.c_void_p * P)(*slot_ptrs1)
         check(_lib.lib().urf_match_device_async(self._h, P, a, b, int(bool(outlier_rejection))), "match_device_async")
 
-    def fetch(self, P):
-        out = (DMatch * (CAP * P))()
+    def fetch(self, P, as_arrays=False):
+        """match lists of the last batch.  as_arrays=True returns one numpy structured
+        array (queryIdx, trainIdx, distance) per pair without per-match Python objects."""
+        out = np.zeros((P, CAP), dtype=MATCH_DTYPE)
         n = (C.c_int * P)()
-        check(_lib.lib().urf_pm_fetch(self._h, P, out, CAP, n), "urf_pm_fetch")
-        return [[(out[p * CAP + i].queryIdx, out[p * CAP + i].trainIdx, out[p * CAP + i].distance)
-                 for i in range(n[p])] for p in range(P)]
+        check(_lib.lib().urf_pm_fetch(self._h, P, _p(out), CAP, n), "urf_pm_fetch")
+        if as_arrays:
+            return [out[p, :n[p]] for p in range(P)]
+        return [[(int(m[0]), int(m[1]), float(m[2])) for m in out[p, :n[p]]] for p in range(P)]
 
     def sync(self):
         check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
