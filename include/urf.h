@@ -149,6 +149,12 @@ int urf_pm_sync(urf_pm *h);
  * match(b), SP(b+1) ... then execute in order on one HIP stream, the host only
  * waits in urf_pm_fetch() for the batch it reads.  `sp` must outlive `h`. */
 int urf_pm_share_stream(urf_pm *h, urf_sp *sp);
+/* Two-stream pipelining instead: the matcher waits for the SuperPoint work enqueued
+ * so far (features ready); SuperPoint waits until the matcher's last batch has
+ * reached its Sinkhorn stage, so the next batch's convolutions (MFMA-bound) run
+ * beside the Sinkhorn iterations (cache-bandwidth-bound). */
+int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp);
+int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h);
 void *urf_sp_stream(urf_sp *h);
 
 /* EpipolarGeometry::_find_F, src/epipolar_geometry.cc:161-205: 8-point RANSAC
@@ -173,6 +179,7 @@ int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, const float *
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */
 int urf_sp_stage_ms(urf_sp *h, float *ms, int n);   /* ms[i]: last call's stage times */
+int urf_sp_stage_ms_age(urf_sp *h, float *ms, int n, int age); /* call `age` calls ago (0..3) */
 int urf_pm_stage_ms(urf_pm *h, float *ms, int n);
 int urf_set_profiling(int enable);
 

@@ -43,6 +43,9 @@ struct urf_pm {
   hipStream_t st = nullptr;
   bool own_stream = true;
   hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_sink = nullptr;      // recorded right before the Sinkhorn iterations of every batch
+  hipStream_t wait_before = nullptr; // optional: stream whose recorded work the next batch must wait for
+  hipEvent_t ev_ext = nullptr;
   bool built = false;
   float *d_w = nullptr;
   size_t kw[5], kb[5];
@@ -113,6 +116,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   URF_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  URF_HIP(hipEventCreateWithFlags(&h->ev_sink, hipEventDisableTiming));
+  URF_HIP(hipEventCreateWithFlags(&h->ev_ext, hipEventDisableTiming));
   std::vector<float> host;
   auto put = [&](const float *src, size_t n) {
     size_t off = align_up(host.size(), 64);
@@ -273,6 +278,8 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     for (int i = 0; i < 18; ++i) { (void)hipEventDestroy(h->ev_attn[i][0]); (void)hipEventDestroy(h->ev_attn[i][1]); }
     if (h->own_stream) (void)hipStreamDestroy(h->st);
     (void)hipEventDestroy(h->ev_done);
+    (void)hipEventDestroy(h->ev_sink);
+    (void)hipEventDestroy(h->ev_ext);
   }
   delete h;
 }
@@ -377,6 +384,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
+  (void)hipEventRecord(h->ev_sink, st);
   if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, h->precision == 1, st)) return -1;
   mark(PT_DECODE);
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
@@ -593,3 +601,30 @@ extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
 
 extern "C" void *urf_pm_stream_(urf_pm *h) { return h && h->built ? (void *)h->st : nullptr; }
 extern "C" int urf_pm_device_(urf_pm *h) { return h ? h->device : 0; }
+
+// Two-stream overlap (bench): SuperPoint of the NEXT batch is bandwidth/MFMA
+// complementary to the Sinkhorn iterations of the current one.
+//   urf_pm_wait_for_sp(pm, sp): the matcher's stream waits until everything already
+//     enqueued on the SuperPoint stream has finished (features ready).
+//   urf_sp_wait_for_sinkhorn(sp, pm): the SuperPoint stream waits until the matcher
+//     has reached the Sinkhorn stage of its last enqueued batch.
+extern "C" void *urf_sp_stream(urf_sp *h);
+extern "C" int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp) {
+  URF_CHECK(h && h->built && sp, "urf_pm_wait_for_sp: bad handle");
+  hipStream_t ss = (hipStream_t)urf_sp_stream(sp);
+  URF_CHECK(ss, "SuperPoint handle is not built");
+  URF_HIP(hipSetDevice(h->device));
+  if (ss == h->st) return 0;
+  URF_HIP(hipEventRecord(h->ev_ext, ss));
+  URF_HIP(hipStreamWaitEvent(h->st, h->ev_ext, 0));
+  return 0;
+}
+extern "C" int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h) {
+  URF_CHECK(h && h->built && sp, "urf_sp_wait_for_sinkhorn: bad handle");
+  hipStream_t ss = (hipStream_t)urf_sp_stream(sp);
+  URF_CHECK(ss, "SuperPoint handle is not built");
+  URF_HIP(hipSetDevice(h->device));
+  if (ss == h->st) return 0;
+  URF_HIP(hipStreamWaitEvent(ss, h->ev_sink, 0));
+  return 0;
+}

@@ -80,7 +80,7 @@ struct urf_sp {
   // last call geometry (debug taps)
   int lastH = 0, lastW = 0, lastB = 0;
   // timing
-  hipEvent_t evs[2][ST_COUNT + 1];  // two sets: the previous call's times stay readable
+  hipEvent_t evs[4][ST_COUNT + 1];  // ring of sets: the last 4 calls' times stay readable
   hipEvent_t *ev = nullptr;          // set used by the call being enqueued
   int ev_cur = 0;
   int ev_calls = 0;
@@ -248,7 +248,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_HIP(hipHostMalloc((void **)&h->h_img, B * H * W, hipHostMallocDefault));
   URF_HIP(hipHostMalloc((void **)&h->h_feat, B * (size_t)kCap * 259 * sizeof(double), hipHostMallocDefault));
   URF_HIP(hipHostMalloc((void **)&h->h_n, B * sizeof(int), hipHostMallocDefault));
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 4; ++k)
     for (int i = 0; i <= ST_COUNT; ++i) URF_HIP(hipEventCreate(&h->evs[k][i]));
   h->ev = h->evs[0];
   h->built = true;
@@ -305,7 +305,7 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
     (void)hipHostFree(h->h_n);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 4; ++k)
       for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(h->evs[k][i]);
     (void)hipStreamDestroy(h->st);
   }
@@ -452,7 +452,7 @@ static int sp_check_dims(urf_sp *h, int B, int rows, int cols) {
 
 static void sp_flip_events(urf_sp *h) {
   if (!urf::g_profiling) return;
-  h->ev_cur ^= 1;
+  h->ev_cur = (h->ev_cur + 1) & 3;
   h->ev = h->evs[h->ev_cur];
   h->ev_calls++;
 }
@@ -574,23 +574,23 @@ extern "C" int urf_sp_debug_tensor(urf_sp *h, int which, float *out, size_t n) {
   return 0;
 }
 
-// n > 0: stage times of the LATEST call (it must have completed);
-// n < 0: of the call before it (|n| entries) -- readable while the latest call
-// is still running on the stream.
-extern "C" int urf_sp_stage_ms(urf_sp *h, float *ms, int n) {
+// Stage times of the call `age` calls ago (0 = latest, up to 3); that call must
+// have completed.  urf_sp_stage_ms(h, ms, n) = age 0; n < 0 = age 1 with |n| entries.
+extern "C" int urf_sp_stage_ms_age(urf_sp *h, float *ms, int n, int age) {
   URF_CHECK(h && ms && h->built, "urf_sp_stage_ms: bad handle");
-  const int want_prev = n < 0;
-  const int cnt = n < 0 ? -n : n;
-  URF_CHECK(h->ev_calls >= (want_prev ? 2 : 1), "no timed call yet (urf_set_profiling(1) before the call)");
+  URF_CHECK(age >= 0 && age <= 3 && h->ev_calls > age, "no timed call of age %d (urf_set_profiling(1) before the call)", age);
   URF_HIP(hipSetDevice(h->device));
-  hipEvent_t *e = h->evs[want_prev ? (h->ev_cur ^ 1) : h->ev_cur];
-  for (int i = 0; i < cnt && i < ST_COUNT; ++i) {
+  hipEvent_t *e = h->evs[(h->ev_cur - age) & 3];
+  for (int i = 0; i < n && i < ST_COUNT; ++i) {
     float t = 0.0f;
     hipError_t rc = hipEventElapsedTime(&t, e[i], e[i + 1]);
     URF_CHECK(rc == hipSuccess, "stage %d of the requested call has not completed: %s", i, hipGetErrorString(rc));
     ms[i] = t;
   }
   return ST_COUNT;
+}
+extern "C" int urf_sp_stage_ms(urf_sp *h, float *ms, int n) {
+  return n < 0 ? urf_sp_stage_ms_age(h, ms, -n, 1) : urf_sp_stage_ms_age(h, ms, n, 0);
 }
 
 extern "C" void *urf_sp_stream(urf_sp *h) { return h && h->built ? (void *)h->st : nullptr; }

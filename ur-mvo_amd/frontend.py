@@ -113,11 +113,12 @@ class SuperPoint:
         check(_lib.lib().urf_sp_debug_tensor(self._h, which, _p(out), C.c_size_t(out.size)), "debug_tensor")
         return out
 
-    def stage_ms(self, previous=False):
-        """HIP-event stage times of the latest call, or (previous=True) of the call
-        before it, which stays readable while the latest one is still running."""
+    def stage_ms(self, previous=False, age=None):
+        """HIP-event stage times of the call `age` calls ago (0 = latest, up to 3; it must
+        have completed).  previous=True is age 1."""
         ms = (C.c_float * 32)()
-        n = check(_lib.lib().urf_sp_stage_ms(self._h, ms, -32 if previous else 32), "stage_ms")
+        a = age if age is not None else (1 if previous else 0)
+        n = check(_lib.lib().urf_sp_stage_ms_age(self._h, ms, 32, a), "stage_ms")
         return [ms[i] for i in range(n)]
 
     def save_engine(self, blob=None):
@@ -231,6 +232,12 @@ class PointMatching(_PM):
 
     def sync(self):
         check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
+
+    def wait_for_sp(self, superpoint):
+        check(_lib.lib().urf_pm_wait_for_sp(self._h, superpoint._h), "urf_pm_wait_for_sp")
+
+    def let_sp_overlap_sinkhorn(self, superpoint):
+        check(_lib.lib().urf_sp_wait_for_sinkhorn(superpoint._h, self._h), "urf_sp_wait_for_sinkhorn")
 
     def share_stream(self, superpoint):
         """run on the SuperPoint handle's HIP stream (in-order SP -> match pipeline)"""
