@@ -56,7 +56,13 @@ def main():
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="1 = fast (split-f16 MFMA, fp32-equivalent accuracy, default); 0 = exact fp32 (bit-identical to the oracle)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
+    ap.add_argument("--resolution", default="640x480", choices=["640x480", "1241x376"],
+                    help="frame size WxH: 640x480 (headline, BASELINE configs[2]) or the KITTI-size stream of configs[3]")
     args = ap.parse_args()
+    global H, W, GF_CONV1
+    if args.resolution == "1241x376":
+        H, W = 376, 1241
+        GF_CONV1 = (22.649 + 0.354) * (376 * 1241) / (480 * 640)
 
     import torch
     import torch.distributed as dist
@@ -337,17 +343,17 @@ def main():
             t_pm = time.perf_counter() - t
             cpu = {"value": round(1.0 / (t_sp + t_pm), 4), "unit": "frames/s", "cores": O.threads(),
                    "kind": "port", "host_cores_visible": ncores,
-                   "sample": f"1 frame 640x480: SuperPoint {t_sp:.2f}s + 1 pair SuperGlue+RANSAC {t_pm:.2f}s "
+                   "sample": f"1 frame {args.resolution}: SuperPoint {t_sp:.2f}s + 1 pair SuperGlue+RANSAC {t_pm:.2f}s "
                              f"(K={f0.shape[0]},{f1.shape[0]}, {len(om)} matches), C oracle with OpenMP"}
         out = {
-            "metric": "VO front-end frames/sec (SP+SG+RANSAC) @640x480", "value": round(fps, 2), "unit": "frames/s",
+            "metric": f"VO front-end frames/sec (SP+SG+RANSAC) @{args.resolution}", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
                       if PREC == 1 else "f32"), "data": "synthetic",
-            "config": {"workload": "640x480 grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
+            "config": {"workload": f"{args.resolution} grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
                                    f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json configs[2])",
-                       "resolution": "640x480", "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
                        "sinkhorn_iterations": 100, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
                        "weights": "seeded synthetic (reference ships none)",
