@@ -100,14 +100,16 @@ def main():
 
     # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
     # = frames [k*8*world, (k+1)*8*world); rank g owns the block [g*8, g*8+8) of
-    # it.  5 global batches are cycled.
-    NB = 5
+    # it.  NB global batches are cycled.
+    OVERLAP = int(os.environ.get("URF_BENCH_OVERLAP", "2"))
+    MATCHERS = int(os.environ.get("URF_BENCH_MATCHERS", "2")) if OVERLAP == 2 else 1
+    NB = MATCHERS + 3
     stream = synth.shift_stream(100, NB * BATCH * world, H, W)
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
     del stream
     slot_floats = U._lib.lib().urf_slot_bytes() // 4
-    # feature slots of the last 5 global batches (ring): matching batch b needs the
+    # feature slots of the last NB global batches (ring): matching batch b needs the
     # last slot of batch b-1 while SuperPoint already fills the slots of batch b+1
     ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)
     gathered = [None] * NB
@@ -121,15 +123,15 @@ def main():
     # URF_BENCH_OVERLAP: 0 = one in-order stream; 1 = SP(b+1) beside Sinkhorn(b) (two streams);
     # 2 (default) = three streams: two matchers alternate, so the cache-bandwidth-bound
     # Sinkhorn of batch b runs beside the MFMA-bound GNN of batch b+1 and SuperPoint of b+2
-    OVERLAP = int(os.environ.get("URF_BENCH_OVERLAP", "2"))
     pms = [pm]
     if OVERLAP == 0:
         pm.share_stream(sp)
     elif OVERLAP == 2:
-        pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                               device=local_rank, precision=PREC)
-        assert pm_b.build(sgb), U._lib.lib().urf_last_error()
-        pms.append(pm_b)
+        for _ in range(MATCHERS - 1):
+            pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
+                                   device=local_rank, precision=PREC)
+            assert pm_b.build(sgb), U._lib.lib().urf_last_error()
+            pms.append(pm_b)
 
     sp_calls = [0]   # number of SP calls enqueued so far (batch index of the latest = sp_calls-1)
 

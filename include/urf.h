@@ -187,6 +187,8 @@ int urf_set_profiling(int enable);
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);
 /* split-f16 GEMM probe (fast precision mode): Y = X W + bias, avg ms over reps */
+/* probe only: force the split-f16 GEMM tile (0 = 128x128, 1 = 64 couts x 128 rows, -1 = automatic) */
+int urf_probe_h2gemm_variant(int v);
 int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                      int reps, float *ms_out, int device);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);

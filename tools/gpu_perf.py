@@ -11,7 +11,7 @@ from __graft_entry__ import load_pkg  # noqa: E402
 
 U = load_pkg()
 F, synth = U.frontend, U.synth
-H, W, B = 480, 640, 8
+H, W, B = 480, 640, int(os.environ.get("URF_B", "8"))
 spb = synth.pack_sp(synth.sp_weights(0))
 sgb = synth.pack_sg(synth.sg_weights(0))
 PREC = int(os.environ.get('URF_PRECISION', '0'))

@@ -1,0 +1,65 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o pmc -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o pmc -- python3 bench.py ...
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/pmc_results.db gpurun_out/pmc_write/pmc_results.db \
+        profiles/r01_pmc_hbm.json "<the bench command>"
+
+Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3): both counters are in KiB;
+on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced reads at
+64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte streaming stores.  The counters sit on
+the memory side of L2, i.e. Infinity-Cache hits are included: this is L2-miss traffic, an upper
+bound on HBM bytes.
+"""
+import collections
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db):
+    cur = sqlite3.connect(db).cursor()
+    agg = collections.defaultdict(list)
+    for name, val in cur.execute("select kernel_name, value from counters_collection"):
+        agg[name].append(val)
+    return agg
+
+
+def family(name):
+    for key in ("ransac_", "h2gemm_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "conv_mfma_kernel",
+                "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
+                "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel"):
+        if key in name:
+            return key
+    return None
+
+
+def main():
+    fdb, wdb, out, cmd = sys.argv[1:5]
+    f, w = per_kernel(fdb), per_kernel(wdb)
+    fam = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
+    for name, vals in f.items():
+        k = family(name)
+        if k:
+            fam[k]["launches"] += len(vals)
+            fam[k]["fetch_kib"] += float(sum(vals))
+    for name, vals in w.items():
+        k = family(name)
+        if k:
+            fam[k]["write_kib"] += float(sum(vals))
+    res = {}
+    for k, v in sorted(fam.items(), key=lambda kv: -(2 * kv[1]["fetch_kib"] + kv[1]["write_kib"])):
+        n = max(v["launches"], 1)
+        res[k] = {"launches": v["launches"],
+                  "FETCH_SIZE_KiB_per_launch_raw": round(v["fetch_kib"] / n, 1),
+                  "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
+                  "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
+    json.dump({"command": cmd, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
+               "scope": "L2-miss (fabric) traffic incl. Infinity-Cache hits; separate --pmc passes",
+               "kernels": res}, open(out, "w"), indent=1)
+    for k, v in res.items():
+        print(f"{k:24s} {v['launches']:6d} launches  {v['bytes_per_launch'] / 1e6:9.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ SYMBOLS = [
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
     "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_sync",
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
-    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
+    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_probe_h2gemm_variant", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
 ]
 
 

@@ -33,10 +33,12 @@ __global__ void __launch_bounds__(512, 4) attn_h2_kernel(const _Float16 *qkh, co
   // [buffer][K planes | V planes]
   __shared__ __attribute__((aligned(16))) _Float16 kbuf[2][2][64 * AS];
   __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][64 * VS];
-  const int im = blockIdx.z, sm = cross ? (im ^ 1) : im;
-  const int head = blockIdx.y;
+  int qb, grp;
+  xcd_group_map(blockIdx.x, ANP / 128, (int)gridDim.x / (ANP / 128), qb, grp);   // the 8 query tiles of a head on one XCD
+  const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
+  const int head = grp & 3;
   const int nq = counts[im], ns = counts[sm];
-  const int q0 = blockIdx.x * 128;
+  const int q0 = qb * 128;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(512, 4) attn_h2_kernel(const _Float16 *qkh, co
 
 int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                    const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(attn_h2_kernel, dim3(ANP / 128, 4, nimg), dim3(512), 0, st, qkh, qkl, vth, vtl, counts, cross, oh, ol);
+  hipLaunchKernelGGL(attn_h2_kernel, dim3((ANP / 128) * 4 * nimg), dim3(512), 0, st, qkh, qkl, vth, vtl, counts, cross, oh, ol);
   URF_HIP(hipGetLastError());
   return 0;
 }

@@ -22,16 +22,19 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;  // K chunk = one 32-deep MFMA step: small LDS/VGPR footprint -> 2 workgroups (16 waves) per CU
 constexpr int HS = 48;  // LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
 
-template <bool TOUT>
-__global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
+template <bool TOUT, int WC, int WR>
+__global__ void __launch_bounds__(64 * WC * WR, (WC * WR >= 8) ? 4 : 3) h2gemm_kernel(H2Args a) {
+  constexpr int NT = 64 * WC * WR;      // threads
+  constexpr int AR = 64 * WC;           // cout rows of the A (weight) tile
+  constexpr int BR = 32 * WR;           // token rows of the B (activation) tile
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  _Float16 *Ah = hsm, *Bh = hsm + 2 * 128 * HS;  // planes: Ah | Al | Bh | Bl
+  _Float16 *Ah = hsm, *Bh = hsm + 2 * AR * HS;  // planes: Ah | Al | Bh | Bl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
-  const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * 128;
+  const int cout_base = blockIdx.y * AR, row0 = blockIdx.x * BR;
   if (a.counts && row0 >= a.counts[b]) return;
-  const int wc = wave >> 2, wr = wave & 3;  // 2 x 4 waves
+  const int wc = wave / WR, wr = wave % WR;
 
   f32x4 acc[4][2];
 #pragma unroll
@@ -47,28 +50,38 @@ __global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
     acc[m][0] = bv; acc[m][1] = bv;
   }
 
-  // staging: per chunk 4 planes x 128 rows x 4 (16-byte pieces) = 2048 pieces / 512 threads = 4
-  f16x8 pf[4];
+  // staging: per chunk 2 planes x (AR + BR) rows x 4 (16-byte pieces)
+  constexpr int PIECES = 2 * (AR + BR) * 4;
+  constexpr int NPF = (PIECES + NT - 1) / NT;
+  f16x8 pf[NPF];
+  auto decode = [&](int i, int &isB, int &plane, int &r, int &j) {
+    j = i & 3;
+    int q = i >> 2;                      // row index over [A hi | A lo | B hi | B lo]
+    if (q < 2 * AR) { isB = 0; plane = q / AR; r = q % AR; }
+    else { q -= 2 * AR; isB = 1; plane = q / BR; r = q % BR; }
+  };
   auto issue = [&](int ch) {
     const int c0 = ch * BK;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 512 * u;        // 0..2047
-      const int plane = i >> 9;           // 0: Ah 1: Al 2: Bh 3: Bl
-      const int r = (i >> 2) & 127, j = i & 3;
-      const int cc = c0 + 8 * j;
+    for (int u = 0; u < NPF; ++u) {
+      const int i = tid + NT * u;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (plane < 2) {
-        const _Float16 *w = plane ? a.wl : a.wh;
-        v = *(const f16x8 *)(w + (size_t)(cout_base + r) * a.Cin + cc);
-      } else {
-        const int row = row0 + r;
-        if (row < a.rows) {
-          const bool second = a.x2h && cc >= a.Cin1;
-          const _Float16 *x = second ? (plane == 2 ? a.x2h : a.x2l) : (plane == 2 ? a.xh : a.xl);
-          const size_t off = second ? (size_t)b * a.x2_bstride + (size_t)row * a.ldx2 + (cc - a.Cin1)
-                                    : (size_t)b * a.x_bstride + (size_t)row * a.ldx + cc;
-          v = *(const f16x8 *)(x + off);
+      if (i < PIECES) {
+        int isB, plane, r, j;
+        decode(i, isB, plane, r, j);
+        const int cc = c0 + 8 * j;
+        if (!isB) {
+          const _Float16 *w = plane ? a.wl : a.wh;
+          v = *(const f16x8 *)(w + (size_t)(cout_base + r) * a.Cin + cc);
+        } else {
+          const int row = row0 + r;
+          if (row < a.rows) {
+            const bool second = a.x2h && cc >= a.Cin1;
+            const _Float16 *x = second ? (plane ? a.x2l : a.x2h) : (plane ? a.xl : a.xh);
+            const size_t off = second ? (size_t)b * a.x2_bstride + (size_t)row * a.ldx2 + (cc - a.Cin1)
+                                      : (size_t)b * a.x_bstride + (size_t)row * a.ldx + cc;
+            v = *(const f16x8 *)(x + off);
+          }
         }
       }
       pf[u] = v;
@@ -76,10 +89,14 @@ __global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 512 * u;
-      const int plane = i >> 9, r = (i >> 2) & 127, j = i & 3;
-      *(f16x8 *)(hsm + plane * 128 * HS + r * HS + 8 * j) = pf[u];
+    for (int u = 0; u < NPF; ++u) {
+      const int i = tid + NT * u;
+      if (i < PIECES) {
+        int isB, plane, r, j;
+        decode(i, isB, plane, r, j);
+        _Float16 *dst = isB ? (Bh + plane * BR * HS) : (Ah + plane * AR * HS);
+        *(f16x8 *)(dst + r * HS + 8 * j) = pf[u];
+      }
     }
   };
 
@@ -97,12 +114,12 @@ __global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         ah[m] = *(const f16x8 *)(ap + m * 16 * HS + 32 * ks);
-        al[m] = *(const f16x8 *)(ap + 128 * HS + m * 16 * HS + 32 * ks);
+        al[m] = *(const f16x8 *)(ap + AR * HS + m * 16 * HS + 32 * ks);
       }
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         bh[r] = *(const f16x8 *)(bp + r * 16 * HS + 32 * ks);
-        bl[r] = *(const f16x8 *)(bp + 128 * HS + r * 16 * HS + 32 * ks);
+        bl[r] = *(const f16x8 *)(bp + BR * HS + r * 16 * HS + 32 * ks);
       }
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -174,20 +191,24 @@ __global__ void __launch_bounds__(512, 4) h2gemm_kernel(H2Args a) {
   }
 }
 
-int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
-  URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0, "h2gemm: unsupported shape %d x %d", a.Cout, a.Cin);
-  const size_t lds = sizeof(_Float16) * 4 * 128 * HS;  // 81 920 B
-  static bool attr_done = false;
-  if (!attr_done) {
-    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-    URF_HIP(hipFuncSetAttribute((const void *)h2gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-    attr_done = true;
-  }
-  dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
-  if (a.ohT) hipLaunchKernelGGL(h2gemm_kernel<true>, grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(h2gemm_kernel<false>, grid, dim3(512), lds, st, a);
+template <bool TOUT, int WC, int WR>
+static int launch_h2gemm_t(const H2Args &a, int batch, hipStream_t st) {
+  constexpr int AR = 64 * WC, BR = 32 * WR;
+  const size_t lds = sizeof(_Float16) * 2 * (AR + BR) * HS;
+  dim3 grid((a.rows + BR - 1) / BR, a.Cout / AR, batch);
+  hipLaunchKernelGGL((h2gemm_kernel<TOUT, WC, WR>), grid, dim3(64 * WC * WR), lds, st, a);
   URF_HIP(hipGetLastError());
   return 0;
+}
+
+int g_h2gemm_variant = -1;  // probe override: 0 = 128x128 tile (8 waves), 1 = 64x128 tile (4 waves)
+
+int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
+  URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0, "h2gemm: unsupported shape %d x %d", a.Cout, a.Cin);
+  // measured (tools/gpu_h2probe.py): the 64x128 tile loses 10-25 % to the 128x128 one at every shape of the path
+  int variant = g_h2gemm_variant >= 0 ? g_h2gemm_variant : 0;
+  if (a.ohT) return variant ? launch_h2gemm_t<true, 1, 4>(a, batch, st) : launch_h2gemm_t<true, 2, 4>(a, batch, st);
+  return variant ? launch_h2gemm_t<false, 1, 4>(a, batch, st) : launch_h2gemm_t<false, 2, 4>(a, batch, st);
 }
 
 // fp32 [n] -> (hi, lo) f16 planes
@@ -209,6 +230,7 @@ int launch_split(const float *x, size_t n, _Float16 *h, _Float16 *l, hipStream_t
 using namespace urf;
 
 // probe: Y[M][N] = X[M][K] W[K][N] + bias via the split-f16 path; returns ms per call (avg of reps)
+extern "C" int urf_probe_h2gemm_variant(int v) { urf::g_h2gemm_variant = v; return 0; }
 extern "C" int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                                 int reps, float *ms_out, int device) {
   URF_CHECK(X && W && Y && (N % 128) == 0 && (K % 64) == 0, "probe_h2gemm: need N%%128==0, K%%64==0");

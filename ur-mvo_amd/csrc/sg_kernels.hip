@@ -91,10 +91,12 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][N
   __shared__ __attribute__((aligned(16))) float kv[2][2][64 * VSTR];  // [double buffer][half][chunk]
   __shared__ float s_max[8][16];
   __shared__ float s_l[4][16];
-  const int im = blockIdx.z, sm = cross ? (im ^ 1) : im;
-  const int head = blockIdx.y;
+  int qtile, grp;
+  xcd_group_map(blockIdx.x, NP / 64, (int)gridDim.x / (NP / 64), qtile, grp);   // the 16 query tiles of a head on one XCD
+  const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
+  const int head = grp & 3;
   const int nq = counts[im], ns = counts[sm];
-  const int q0 = blockIdx.x * 64;
+  const int q0 = qtile * 64;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = wave & 3, kh = wave >> 2;
@@ -336,9 +338,10 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 
 // One Sinkhorn half-iteration (src/super_glue.cpp:436-451, max-stabilised):
 //   out[r] = log_marg[r] - LSE_c( M[r][c] + add[c] ),  r < R, c < Cn
-// One wave per row.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
+// SK_RW rows per wave.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
 // per row); `add` is staged once per workgroup in LDS; the sum is the canonical
 // wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
+constexpr int SK_RW = 1;  // rows per wave (2 measured slower: 2.10 vs 1.94 ms per 100 iterations x 8 pairs)
 template <bool ROWPASS, bool FAST>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
@@ -346,7 +349,22 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
   const int p = blockIdx.y;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
-  if (blockIdx.x * 4 >= R) return;
+  if (blockIdx.x * 4 * SK_RW >= R) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_RW;
+  const int lane = threadIdx.x & 63;
+  // the rows' own loads go out first: they do not depend on the staged vector
+  f32x4 mv[SK_RW][5];
+#pragma unroll
+  for (int q = 0; q < SK_RW; ++q) {
+    const bool live = row0 + q < R;
+    const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)(live ? row0 + q : 0) * LDC;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int c = 256 * t + 4 * lane;
+      mv[q][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (live && c < Cn) mv[q][t] = *(const f32x4 *)(mr + c);  // LDC = 1028 >= c + 4: stays inside the row
+    }
+  }
   const float *ad = add + (size_t)p * LDC;
   for (int i = threadIdx.x; i < (LDC + 256) / 4; i += 256) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -354,39 +372,39 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
     *(f32x4 *)(sadd + 4 * i) = v;
   }
   __syncthreads();
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const int lane = threadIdx.x & 63;
-  const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)row * LDC;
-  f32x4 x[5];
-  float m = -FLT_MAX;
+  const float norm = -log_c((float)(n0 + n1));
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    const int c = 256 * t + 4 * lane;
-    x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (c < Cn) {  // LDC = 1028 >= c + 4: the 16-byte load stays inside the row
-      const f32x4 mv = *(const f32x4 *)(mr + c);
-      const f32x4 av = *(const f32x4 *)(sadd + c);
+  for (int q = 0; q < SK_RW; ++q) {
+    const int row = row0 + q;
+    if (row >= R) break;
+    f32x4 x[5];
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int c = 256 * t + 4 * lane;
+      x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+      if (c < Cn) {
+        const f32x4 av = *(const f32x4 *)(sadd + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < Cn) { x[t][r] = mv[q][t][r] + av[r]; m = fmaxf(m, x[t][r]); }
+      }
+    }
+    m = bfly64_max(m);
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int c = 256 * t + 4 * lane;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (c + r < Cn) { x[t][r] = mv[r] + av[r]; m = fmaxf(m, x[t][r]); }
+        if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
     }
-  }
-  m = bfly64_max(m);
-  float s = 0.0f;
-#pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    const int c = 256 * t + 4 * lane;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
-  }
-  s = bfly64_sum(s);
-  if (lane == 0) {
-    const float norm = -log_c((float)(n0 + n1));
-    const int last = R - 1;
-    const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
-    out[(size_t)p * LDC + row] = lm - (m + (FAST ? __logf(s) : log_c(s)));
+    s = bfly64_sum(s);
+    if (lane == 0) {
+      const int last = R - 1;
+      const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
+      out[(size_t)p * LDC + row] = lm - (m + (FAST ? __logf(s) : log_c(s)));
+    }
   }
 }
 
@@ -515,7 +533,7 @@ int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int hei
   return 0;
 }
 int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(attn_kernel, dim3(NP / 64, 4, nimg), dim3(512), 0, st, qkv, counts, cross, o);
+  hipLaunchKernelGGL(attn_kernel, dim3((NP / 64) * 4 * nimg), dim3(512), 0, st, qkv, counts, cross, o);
   URF_HIP(hipGetLastError());
   return 0;
 }
@@ -528,7 +546,7 @@ int launch_score(const float *mdesc, const int *counts, float alpha, float *C, f
 }
 int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
                     bool fast, hipStream_t st) {
-  const dim3 grid((NP + 1 + 3) / 4, P), block(256);
+  const dim3 grid((NP + 1 + 4 * SK_RW - 1) / (4 * SK_RW), P), block(256);
   for (int it = 0; it < iters; ++it) {
     if (fast) {
       hipLaunchKernelGGL((sinkhorn_half_kernel<true, true>), grid, block, 0, st, counts, C, v, u);

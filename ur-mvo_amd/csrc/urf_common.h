@@ -61,4 +61,22 @@ constexpr int kCap = 1024;
 constexpr int kSlotHeader = 4;  // [K, 0, 0, 0]
 constexpr size_t kSlotFloats = kSlotHeader + (size_t)kCap * 4 + (size_t)kCap * 256;
 
+// XCD-aware workgroup map for kernels whose workgroups re-read a per-group operand
+// (attention: the QB query tiles of one (image, head) share that head's K/V).
+// Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so
+// the linear id L runs on XCD L % 8; the QB tiles of a group are given ids that are
+// congruent mod 8 and adjacent in dispatch order, so the group's operand is fetched
+// into ONE L2 once.  Falls back to the plain order when the group count is not a
+// multiple of 8.  (MI355X_MICROARCH.md: L2 per XCD, not cross-XCD coherent.)
+__device__ __forceinline__ void xcd_group_map(int L, int QB, int G, int &qb, int &group) {
+  if ((G & 7) == 0) {
+    const int xcd = L & 7, slot = L >> 3;
+    group = xcd * (G >> 3) + slot / QB;
+    qb = slot % QB;
+  } else {
+    group = L / QB;
+    qb = L % QB;
+  }
+}
+
 }  // namespace urf
