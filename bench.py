@@ -26,6 +26,8 @@ from __graft_entry__ import load_pkg  # noqa: E402
 
 H, W = 480, 640
 BATCH = 8
+# diagnostic only (what-if runs); any value but 100 is not the reference configuration and is flagged in the output
+SINK_ITERS = int(os.environ.get("URF_BENCH_SINKHORN_ITERS", "100"))
 MAX_KP = 1000
 # algorithmic work, SURVEY.md 8(d): GFLOP per 640x480 frame / per pair at n=1000
 GF_CONV1 = 22.649 + 0.354          # conv1b + fused conv1a
@@ -95,7 +97,7 @@ def main():
                       device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
     pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank,
-                         precision=PREC)
+                         precision=PREC, sinkhorn_iterations=SINK_ITERS)
     assert pm.build(sgb), U._lib.lib().urf_last_error()
 
     # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
@@ -129,7 +131,7 @@ def main():
     elif OVERLAP == 2:
         for _ in range(MATCHERS - 1):
             pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                                   device=local_rank, precision=PREC)
+                                   device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS)
             assert pm_b.build(sgb), U._lib.lib().urf_last_error()
             pms.append(pm_b)
 
@@ -357,7 +359,7 @@ def main():
                                    f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json configs[2])",
                        "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
-                       "sinkhorn_iterations": 100, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
+                       "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
                        "weights": "seeded synthetic (reference ships none)",
                        "streams": {0: "one in-order stream", 1: "2 streams: SP(b+1) beside Sinkhorn(b)",
                                    2: "3 streams: Sinkhorn(b) beside GNN(b+1) and SP(b+2)"}[OVERLAP],

@@ -9,6 +9,8 @@
 // Tile: 512-thread workgroup (8 waves) = 128 couts x 128 rows, K chunk 64.
 // Wave (wc, wr) = 64 couts x 32 rows = 8 accumulators; per 32-deep k-step it
 // reads 8 A + 4 B 16-byte fragments from LDS and issues 24 MFMAs.
+#include <cstdlib>
+
 #include "h2.h"
 
 namespace urf {
@@ -21,6 +23,165 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;  // K chunk = one 32-deep MFMA step: small LDS/VGPR footprint -> 2 workgroups (16 waves) per CU
 constexpr int HS = 48;  // LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
+
+// accumulators -> outputs.  acc[m][r]: cout tile m (16) x token tile r (16) of wave (wc, wr)
+template <bool TOUT>
+__device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2], int b, int cout_base, int row0, int wc,
+                                            int wr, int px, int g) {
+  if (TOUT) {
+    // lane owns tokens 4g..4g+3 of r-tile for cout px of m-tile -> 8-byte stores along the token axis
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int tok = row0 + wr * 32 + r * 16 + 4 * g;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int co = cout_base + wc * 64 + m * 16 + px;
+        f16x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[m][r][q];
+          if (tok + q >= a.rows) v = 0.0f;
+          h[q] = (_Float16)v; l[q] = (_Float16)(v - (float)h[q]);
+        }
+        const size_t off = (size_t)b * a.outT_bstride + (size_t)co * a.ldT + tok;
+        *(f16x4 *)(a.ohT + off) = h;
+        *(f16x4 *)(a.olT + off) = l;
+      }
+    }
+    return;
+  }
+  // epilogue: lane owns couts 4g..4g+3 of m-tile for row (token) px of r-tile
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = row0 + wr * 32 + r * 16 + px;
+    if (row >= a.rows) continue;
+    const size_t ro = (size_t)b * a.out_bstride + (size_t)row * a.ld_out + cout_base + wc * 64 + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x4 v = acc[m][r];
+      if (a.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+      }
+      if (a.res) {
+        const f32x4 rv = *(const f32x4 *)(a.res + ro + m * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rv[q] + v[q];
+      }
+      if (a.out) *(f32x4 *)(a.out + ro + m * 16) = v;
+      if (a.oh) {
+        f16x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)v[q]; l[q] = (_Float16)(v[q] - (float)h[q]); }
+        *(f16x4 *)(a.oh + ro + m * 16) = h;
+        *(f16x4 *)(a.ol + ro + m * 16) = l;
+      }
+    }
+  }
+}
+
+// bias -> accumulators (the MFMA C operand)
+template <bool TOUT>
+__device__ __forceinline__ void h2_init_acc(const H2Args &a, f32x4 (&acc)[4][2], int cout_base, int wc, int px, int g) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    f32x4 bv;
+    if (TOUT) {
+      const float bb = a.bias[cout_base + wc * 64 + m * 16 + px];
+      bv = f32x4{bb, bb, bb, bb};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = a.bias[cout_base + wc * 64 + m * 16 + 4 * g + r];
+    }
+    acc[m][0] = bv; acc[m][1] = bv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: the four f16 planes of a K chunk go global -> LDS with global_load_lds_dwordx4
+// (no VGPR round trip, no ds_write pass), two LDS stages, ONE barrier per chunk.
+// One wave-instruction fills 16 rows x 64 B of one plane, lane l -> byte 16 l of that 1-KiB piece
+// (row l>>2, 16-byte slot l&3).  Rows are unpadded (64 B), so the slot holding k-group kg of row r
+// is kg ^ sw(r), sw(r) = (-(r>>2)) & 3: with it the four 16-lane groups of a ds_read_b128 fragment
+// read (rows 0-3,12-15 of kg | rows 4-11 of kg+1 ...) touch 16 distinct (row mod 4, slot) pairs =
+// all 64 banks once.  The permutation is applied to the SOURCE address of the DMA and to the read.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+constexpr int GP = 128 * BK;   // halfs per plane per stage (128 rows x 32)
+
+template <bool TOUT>
+__global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];   // [stage][Ah | Al | Bh | Bl][128][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * 128;
+  if (a.counts && row0 >= a.counts[b]) return;
+  const int wc = wave >> 2, wr = wave & 3;
+  f32x4 acc[4][2];
+  h2_init_acc<TOUT>(a, acc, cout_base, wc, px, g);
+
+  // DMA role of this lane: instruction u (= plane), row block `wave`, row/slot from the lane id
+  const int drow = wave * 16 + (lane >> 2);
+  const int dkg = (lane & 3) ^ ((-(drow >> 2)) & 3);
+  const bool brow_ok = row0 + drow < a.rows;   // rows past the end are never stored: their LDS bytes may be stale
+  const _Float16 *srcA_h = a.wh + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
+  const _Float16 *srcA_l = a.wl + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
+  const size_t xoff = (size_t)b * a.x_bstride + (size_t)(row0 + drow) * a.ldx + 8 * dkg;
+  const size_t x2off = a.x2h ? (size_t)b * a.x2_bstride + (size_t)(row0 + drow) * a.ldx2 + 8 * dkg : 0;
+  auto issue = [&](int ch, int stage) {
+    const int c0 = ch * BK;
+    _Float16 *base = hsm + stage * 4 * GP + wave * 16 * BK;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(srcA_h + c0), (lds_void *)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void *)(srcA_l + c0), (lds_void *)(base + GP), 16, 0, 0);
+    if (brow_ok) {
+      const bool second = a.x2h && c0 >= a.Cin1;
+      const _Float16 *xh = second ? a.x2h + x2off + (c0 - a.Cin1) : a.xh + xoff + c0;
+      const _Float16 *xl = second ? a.x2l + x2off + (c0 - a.Cin1) : a.xl + xoff + c0;
+      __builtin_amdgcn_global_load_lds((gbl_void *)xh, (lds_void *)(base + 2 * GP), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)xl, (lds_void *)(base + 3 * GP), 16, 0, 0);
+    }
+  };
+
+  // fragment read offsets (halfs) inside a plane: row r -> r*32 + 8*(g ^ sw(r)); sw depends on (r>>2)&3 = (px>>2)
+  const int swz = 8 * (g ^ ((-(px >> 2)) & 3));
+  const int aoff = (wc * 64 + px) * BK + swz;   // + m*16*BK
+  const int boff = (wr * 32 + px) * BK + swz;   // + r*16*BK
+  const int nchunks = a.Cin / BK;
+  issue(0, 0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk ch has landed
+    __syncthreads();
+    if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
+    const _Float16 *st = hsm + (ch & 1) * 4 * GP;
+    f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ah[m] = *(const f16x8 *)(st + aoff + m * 16 * BK);
+      al[m] = *(const f16x8 *)(st + GP + aoff + m * 16 * BK);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      bh[r] = *(const f16x8 *)(st + 2 * GP + boff + r * 16 * BK);
+      bl[r] = *(const f16x8 *)(st + 3 * GP + boff + r * 16 * BK);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (TOUT) {  // D[row = token][col = cout]
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[r], al[m], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[r], ah[m], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[r], ah[m], acc[m][r], 0, 0, 0);
+        } else {     // D[row = cout][col = token]
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[r], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[r], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
+        }
+      }
+  }
+  h2_epilogue<TOUT>(a, acc, b, cout_base, row0, wc, wr, px, g);
+}
 
 template <bool TOUT, int WC, int WR>
 __global__ void __launch_bounds__(64 * WC * WR, (WC * WR >= 8) ? 4 : 3) h2gemm_kernel(H2Args a) {
@@ -37,18 +198,7 @@ __global__ void __launch_bounds__(64 * WC * WR, (WC * WR >= 8) ? 4 : 3) h2gemm_k
   const int wc = wave / WR, wr = wave % WR;
 
   f32x4 acc[4][2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    f32x4 bv;
-    if (TOUT) {
-      const float bb = a.bias[cout_base + wc * 64 + m * 16 + px];
-      bv = f32x4{bb, bb, bb, bb};
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = a.bias[cout_base + wc * 64 + m * 16 + 4 * g + r];
-    }
-    acc[m][0] = bv; acc[m][1] = bv;
-  }
+  h2_init_acc<TOUT>(a, acc, cout_base, wc, px, g);
 
   // staging: per chunk 2 planes x (AR + BR) rows x 4 (16-byte pieces)
   constexpr int PIECES = 2 * (AR + BR) * 4;
@@ -139,56 +289,7 @@ __global__ void __launch_bounds__(64 * WC * WR, (WC * WR >= 8) ? 4 : 3) h2gemm_k
     __syncthreads();
   }
 
-  if (TOUT) {
-    // lane owns tokens 4g..4g+3 of r-tile for cout px of m-tile -> 8-byte stores along the token axis
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int tok = row0 + wr * 32 + r * 16 + 4 * g;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int co = cout_base + wc * 64 + m * 16 + px;
-        f16x4 h, l;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = acc[m][r][q];
-          if (tok + q >= a.rows) v = 0.0f;
-          h[q] = (_Float16)v; l[q] = (_Float16)(v - (float)h[q]);
-        }
-        const size_t off = (size_t)b * a.outT_bstride + (size_t)co * a.ldT + tok;
-        *(f16x4 *)(a.ohT + off) = h;
-        *(f16x4 *)(a.olT + off) = l;
-      }
-    }
-    return;
-  }
-  // epilogue: lane owns couts 4g..4g+3 of m-tile for row (token) px of r-tile
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = row0 + wr * 32 + r * 16 + px;
-    if (row >= a.rows) continue;
-    const size_t ro = (size_t)b * a.out_bstride + (size_t)row * a.ld_out + cout_base + wc * 64 + 4 * g;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      f32x4 v = acc[m][r];
-      if (a.relu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
-      }
-      if (a.res) {
-        const f32x4 rv = *(const f32x4 *)(a.res + ro + m * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = rv[q] + v[q];
-      }
-      if (a.out) *(f32x4 *)(a.out + ro + m * 16) = v;
-      if (a.oh) {
-        f16x4 h, l;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)v[q]; l[q] = (_Float16)(v[q] - (float)h[q]); }
-        *(f16x4 *)(a.oh + ro + m * 16) = h;
-        *(f16x4 *)(a.ol + ro + m * 16) = l;
-      }
-    }
-  }
+  h2_epilogue<TOUT>(a, acc, b, cout_base, row0, wc, wr, px, g);
 }
 
 template <bool TOUT, int WC, int WR>
@@ -201,12 +302,31 @@ static int launch_h2gemm_t(const H2Args &a, int batch, hipStream_t st) {
   return 0;
 }
 
-int g_h2gemm_variant = -1;  // probe override: 0 = 128x128 tile (8 waves), 1 = 64x128 tile (4 waves)
+int g_h2gemm_variant = -1;  // probe override: 0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 (default)
 
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0, "h2gemm: unsupported shape %d x %d", a.Cout, a.Cin);
-  // measured (tools/gpu_h2probe.py): the 64x128 tile loses 10-25 % to the 128x128 one at every shape of the path
-  int variant = g_h2gemm_variant >= 0 ? g_h2gemm_variant : 0;
+  // measured (tools/gpu_h2probe.py, 16384 rows): LDS-DMA 128x128 174-276 TFLOP/s logical > register-staged 128x128
+  // 155-251 > register-staged 64x128 140-193 at every shape of the path
+  if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
+    const char *e = getenv("URF_H2GEMM_VARIANT");
+    g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+  }
+  const int variant = g_h2gemm_variant;
+  if (variant == 2) {
+    const size_t lds = sizeof(_Float16) * 2 * 4 * GP;   // 64 KiB: two stages of four planes
+    dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
+    static bool attr_set = false;
+    if (!attr_set) {
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((h2gemm_glds_kernel<false>), grid, dim3(512), lds, st, a);
+    URF_HIP(hipGetLastError());
+    return 0;
+  }
   if (a.ohT) return variant ? launch_h2gemm_t<true, 1, 4>(a, batch, st) : launch_h2gemm_t<true, 2, 4>(a, batch, st);
   return variant ? launch_h2gemm_t<false, 1, 4>(a, batch, st) : launch_h2gemm_t<false, 2, 4>(a, batch, st);
 }

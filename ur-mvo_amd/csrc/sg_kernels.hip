@@ -6,6 +6,7 @@
 //
 // All matrix products are exact-fp32 v_mfma_f32_16x16x4_f32 fma chains in the
 // canonical order of DESIGN.md; exp/log are the canonical polynomials.
+#include <cstdlib>
 #include "urf_common.h"
 #include "urf_math.h"
 
@@ -341,7 +342,11 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 // SK_RW rows per wave.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
 // per row); `add` is staged once per workgroup in LDS; the sum is the canonical
 // wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
-constexpr int SK_RW = 1;  // rows per wave (2 measured slower: 2.10 vs 1.94 ms per 100 iterations x 8 pairs)
+// Grid-stride over rows: wave w of the launch handles rows w, w + W, w + 2W, ... (W = waves in the
+// pair's grid slice) with the next row's five 16-byte loads in flight while the current row is
+// reduced.  The launch is sized to about four 4-wave workgroups per CU instead of one wave per
+// row: a half-iteration is latency-bound, and 32 resident waves per CU would only keep the
+// MFMA-bound kernels of the other streams (GNN of the next batch, SuperPoint) off the CUs.
 template <bool ROWPASS, bool FAST>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
@@ -349,22 +354,24 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
   const int p = blockIdx.y;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
-  if (blockIdx.x * 4 * SK_RW >= R) return;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_RW;
+  const int nw = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x * 4 >= R) return;
   const int lane = threadIdx.x & 63;
-  // the rows' own loads go out first: they do not depend on the staged vector
-  f32x4 mv[SK_RW][5];
-#pragma unroll
-  for (int q = 0; q < SK_RW; ++q) {
-    const bool live = row0 + q < R;
-    const float *mr = M + (size_t)p * (NP + 1) * LDC + (size_t)(live ? row0 + q : 0) * LDC;
+  const float *Mp = M + (size_t)p * (NP + 1) * LDC;
+  auto load_row = [&](int r, f32x4 (&mv)[5]) {
+    const bool live = r < R;
+    const float *mr = Mp + (size_t)(live ? r : 0) * LDC;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int c = 256 * t + 4 * lane;
-      mv[q][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (live && c < Cn) mv[q][t] = *(const f32x4 *)(mr + c);  // LDC = 1028 >= c + 4: stays inside the row
+      mv[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (live && c < Cn) mv[t] = *(const f32x4 *)(mr + c);  // LDC = 1028 >= c + 4: stays inside the row
     }
-  }
+  };
+  // the first row's loads go out before the vector is staged: they do not depend on it
+  f32x4 cur[5], nxt[5];
+  load_row(row, cur);
   const float *ad = add + (size_t)p * LDC;
   for (int i = threadIdx.x; i < (LDC + 256) / 4; i += 256) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -373,10 +380,8 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
   }
   __syncthreads();
   const float norm = -log_c((float)(n0 + n1));
-#pragma unroll
-  for (int q = 0; q < SK_RW; ++q) {
-    const int row = row0 + q;
-    if (row >= R) break;
+  for (; row < R; row += nw) {
+    if (row + nw < R) load_row(row + nw, nxt);
     f32x4 x[5];
     float m = -FLT_MAX;
 #pragma unroll
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
         const f32x4 av = *(const f32x4 *)(sadd + c);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (c + r < Cn) { x[t][r] = mv[q][t][r] + av[r]; m = fmaxf(m, x[t][r]); }
+          if (c + r < Cn) { x[t][r] = cur[t][r] + av[r]; m = fmaxf(m, x[t][r]); }
       }
     }
     m = bfly64_max(m);
@@ -405,6 +410,8 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
       const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
       out[(size_t)p * LDC + row] = lm - (m + (FAST ? __logf(s) : log_c(s)));
     }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) cur[t] = nxt[t];
   }
 }
 
@@ -546,7 +553,18 @@ int launch_score(const float *mdesc, const int *counts, float alpha, float *C, f
 }
 int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
                     bool fast, hipStream_t st) {
-  const dim3 grid((NP + 1 + 4 * SK_RW - 1) / (4 * SK_RW), P), block(256);
+  // rows per wave k so that the whole launch is about `target` workgroups (4 per CU; measured at 8 pairs:
+  // 1 row/wave 1332 frames/s, 1024 workgroups 1385, 512 -> 1358, 256 -> 1319 in the 3-stream pipeline)
+  static int target = -1;
+  if (target < 0) {
+    const char *e = getenv("URF_SINKHORN_BLOCKS");   // tuning knob for A/B runs
+    target = e ? atoi(e) : 1024;
+    if (target < 1) target = 1024;
+  }
+  const int rows = NP + 1;
+  int k = (P * rows + 4 * target - 1) / (4 * target);
+  if (k < 1) k = 1;
+  const dim3 grid((rows + 4 * k - 1) / (4 * k), P), block(256);
   for (int it = 0; it < iters; ++it) {
     if (fast) {
       hipLaunchKernelGGL((sinkhorn_half_kernel<true, true>), grid, block, 0, st, counts, C, v, u);
