@@ -49,6 +49,30 @@ def sg_attn_gflop(n0, n1):
     return 9 * (self_l + cross_l) / 1e9
 
 
+
+def pmc_traffic(kernel_label, resolution, prec):
+    """HBM-side bytes per step of the dominant kernel family, from the committed summary of the two
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py) of this same command.
+    bench.py cannot collect counters about itself: the summary is the newest profiles/r*_pmc_hbm*.json
+    for this resolution; None when there is none (or for the exact mode, not profiled)."""
+    import glob
+    if prec != 1:
+        return None, "no PMC pass for the exact mode"
+    tag = "" if resolution == "640x480" else "_" + resolution
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm{tag}.json")))
+    if not files:
+        return None, "no committed PMC summary for this resolution"
+    d = json.load(open(files[-1]))
+    fam = ("h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
+           else "h2conv_kernel<pool,fuse1a>")
+    k = d["kernels"].get(fam)
+    if not k:
+        return None, f"{os.path.basename(files[-1])} has no {fam}"
+    calls = d["superpoint_calls"] if fam.startswith("h2conv") else d["matcher_calls"]
+    return int(k["bytes_total"] / calls), (f"bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the "
+                                           f"{k['launches'] // calls} {fam} launches of a step; L2-miss traffic incl. "
+                                           f"Infinity-Cache hits; {os.path.basename(files[-1])}")
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,8 +301,10 @@ def main():
         # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); `achieved` counts the
         # ALGORITHMIC flops once, so frac <= 1/3 by construction against the dense f16 peak
         peak = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
+        traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_note": traffic_src,
                     "mfma_issue_frac": round(achieved * (3 if PREC == 1 else 1) / peak, 4),
                     "launch_ms": round(float(ms), 4), "algorithmic_gflop_per_step": round(gf, 2),
                     "measured": "HIP events on the library stream, serialised 5-step pass right after the timed region "

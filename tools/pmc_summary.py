@@ -26,7 +26,9 @@ def per_kernel(db):
 
 
 def family(name):
-    for key in ("ransac_", "h2gemm_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "conv_mfma_kernel",
+    if "h2conv_kernel<true, true" in name:
+        return "h2conv_kernel<pool,fuse1a>"      # conv1a+conv1b fused: its own line (bench.py's conv1 kernel)
+    for key in ("ransac_", "h2gemm", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
                 "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel"):
         if key in name:
@@ -50,11 +52,13 @@ def main():
     res = {}
     for k, v in sorted(fam.items(), key=lambda kv: -(2 * kv[1]["fetch_kib"] + kv[1]["write_kib"])):
         n = max(v["launches"], 1)
-        res[k] = {"launches": v["launches"],
+        res[k] = {"launches": v["launches"], "bytes_total": int((2 * v["fetch_kib"] + v["write_kib"]) * 1024),
                   "FETCH_SIZE_KiB_per_launch_raw": round(v["fetch_kib"] / n, 1),
                   "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
                   "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
-    json.dump({"command": cmd, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
+    pm_calls = max(fam.get("sinkhorn_half_kernel", {"launches": 0})["launches"] // 200, 1)
+    sp_calls = max(fam.get("topk_kernel", {"launches": 0})["launches"], 1)
+    json.dump({"command": cmd, "matcher_calls": pm_calls, "superpoint_calls": sp_calls, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
                "scope": "L2-miss (fabric) traffic incl. Infinity-Cache hits; separate --pmc passes",
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
