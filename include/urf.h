@@ -183,11 +183,43 @@ int urf_sp_stage_ms_age(urf_sp *h, float *ms, int n, int age); /* call `age` cal
 int urf_pm_stage_ms(urf_pm *h, float *ms, int n);
 int urf_set_profiling(int enable);
 
+/* ---------------------------------------------------------------- Camera -- */
+/* Camera::UndistortImage as the first device stage.
+ * The reference builds two CV_32FC1 maps once (Camera::Camera, src/camera.cc:69-85,
+ * cv::initUndistortRectifyMap / cv::fisheye::initUndistortRectifyMap) and calls
+ * cv::remap(image, out, map1, map2, cv::INTER_LINEAR) per frame (:116-118). */
+typedef struct {
+  int width, height;       /* image_width / image_height (src/camera.cc:16-17) */
+  int distortion_type;     /* 0 = radial-tangential, else fisheye (src/camera.cc:42,76-84) */
+  double K[9];             /* LEFT_K, row-major */
+  double D[14];            /* LEFT_D: k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4]]] or fisheye k1..k4 */
+  int n_dist;
+  double R[9];             /* cv::Mat::eye for the monocular setups (src/camera.cc:78), LEFT_R for stereo */
+  double P[9];             /* LEFT_P.rowRange(0,3).colRange(0,3) */
+  int device;
+} urf_cam_config;
+typedef struct urf_cam urf_cam;
+
+/* Camera::Camera's map construction (host, once). */
+int urf_cam_create(const urf_cam_config *cfg, urf_cam **out);
+/* Same handle from maps the caller already has (Camera::_map1/_map2, CV_32FC1, width x height):
+ * the drop-in a maintainer uses, OpenCV's own maps stay the source of truth. */
+int urf_cam_create_from_maps(const float *map1, const float *map2, int width, int height, int device, urf_cam **out);
+void urf_cam_destroy(urf_cam *h);
+int urf_cam_maps(urf_cam *h, float *map1, float *map2);
+/* Camera::UndistortImage(image, image_undistorted), src/camera.cc:116-118: host u8 in, host u8 out. */
+int urf_cam_undistort(urf_cam *h, const uint8_t *img, int rows, int cols, size_t step, uint8_t *out, size_t ostep);
+/* n device-resident frames (rows x cols, contiguous) -> n frames height x width, enqueued on
+ * `stream` (hipStream_t; pass urf_sp_stream(sp) to run in order in front of
+ * urf_sp_infer_device) or on the handle's own stream when NULL. */
+int urf_cam_undistort_device(urf_cam *h, const void *d_imgs, int n, int rows, int cols, void *d_out, void *stream);
+int urf_cam_sync(urf_cam *h);
+
 /* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);
 /* split-f16 GEMM probe (fast precision mode): Y = X W + bias, avg ms over reps */
-/* probe only: force the split-f16 GEMM tile (0 = 128x128, 1 = 64 couts x 128 rows, -1 = automatic) */
+/* probe only: force the split-f16 GEMM kernel (0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 = default) */
 int urf_probe_h2gemm_variant(int v);
 int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                      int reps, float *ms_out, int device);

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "liburf_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c",
+    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c",
                                               "urf_oracle.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -241,3 +241,45 @@ def epi_reconstruct(K, keys1, keys2, matches12, sigma=1.0, iterations=200, seed=
     sc = np.zeros(2, np.float32)
     ok = lib().oepi_reconstruct(C.byref(cfg), _p(k1), n1, _p(k2), n2, _p(m), _p(T), _p(P), _p(tri), C.byref(model), _p(sc))
     return bool(ok), T.reshape(4, 4), P, tri, model.value, (float(sc[0]), float(sc[1]))
+
+
+class CamConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("distortion_type", C.c_int), ("K", C.c_double * 9),
+                ("D", C.c_double * 14), ("n_dist", C.c_int), ("R", C.c_double * 9), ("P", C.c_double * 9)]
+
+
+def cam_config(width, height, K, D, P=None, R=None, distortion_type=0):
+    c = CamConfig()
+    c.width, c.height, c.distortion_type = int(width), int(height), int(distortion_type)
+    K = np.asarray(K, np.float64).reshape(9)
+    P = K if P is None else np.asarray(P, np.float64).reshape(3, -1)[:, :3].reshape(9)
+    R = np.eye(3).reshape(9) if R is None else np.asarray(R, np.float64).reshape(9)
+    D = np.asarray(D, np.float64).reshape(-1)
+    for i in range(9):
+        c.K[i], c.P[i], c.R[i] = K[i], P[i], R[i]
+    for i in range(14):
+        c.D[i] = D[i] if i < D.size else 0.0
+    c.n_dist = int(min(D.size, 14))
+    return c
+
+
+def cam_init_maps(cfg):
+    """src/camera.cc:69-85 -> (map1, map2) float32 [H, W]"""
+    m1 = np.empty((cfg.height, cfg.width), np.float32)
+    m2 = np.empty_like(m1)
+    rc = lib().ocam_init_maps(C.byref(cfg), _p(m1), _p(m2))
+    if rc != 0:
+        raise ValueError("singular P*R")
+    return m1, m2
+
+
+def cam_remap(img, map1, map2):
+    """src/camera.cc:116-118 (cv::remap, INTER_LINEAR, constant border 0)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    map1 = np.ascontiguousarray(map1, np.float32)
+    map2 = np.ascontiguousarray(map2, np.float32)
+    oh, ow = map1.shape
+    out = np.empty((oh, ow), np.uint8)
+    lib().ocam_remap(_p(img), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]), _p(map1), _p(map2), oh, ow,
+                     _p(out), C.c_size_t(out.strides[0]))
+    return out

@@ -118,6 +118,23 @@ typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; } oepi_
 int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
                      const int *matches12, float *T21, float *P3D, uint8_t *tri, int *model, float *scores);
 
+/* ---------------- camera ---------------- */
+typedef struct {
+  int width, height;       /* image_width / image_height, src/camera.cc:16-17 */
+  int distortion_type;     /* 0 = radial-tangential, else fisheye (src/camera.cc:42,76-84) */
+  double K[9];             /* LEFT_K */
+  double D[14];            /* LEFT_D */
+  int n_dist;
+  double R[9];             /* identity for the monocular setups (src/camera.cc:78) */
+  double P[9];             /* LEFT_P(0:3,0:3) */
+} ocam_config;
+
+/* Camera::Camera map construction, src/camera.cc:69-85 (OpenCV initUndistortRectifyMap). */
+int ocam_init_maps(const ocam_config *c, float *map1, float *map2);
+/* Camera::UndistortImage, src/camera.cc:116-118 (cv::remap INTER_LINEAR, constant border 0). */
+void ocam_remap(const uint8_t *img, int H, int W, size_t step, const float *map1, const float *map2, int oh, int ow,
+                uint8_t *out, size_t ostep);
+
 /* canonical math probes (tests) */
 float o_exp(float x);
 float o_log(float x);

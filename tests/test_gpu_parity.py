@@ -379,3 +379,62 @@ def test_fast_mode_superpoint_matches_exact_mode(U, F, O, sp_blob, H, W, seed):
     Bm = np.array([df[k] for k in common])
     assert np.abs(A[:, 0] - Bm[:, 0]).max() < 2e-5          # scores
     assert np.abs(A[:, 3:] - Bm[:, 3:]).max() < 1e-3        # descriptors: north_star tolerance
+
+
+# ------------------------------------------------------------------ camera
+CAM_K = np.array([[420.5, 0, 318.2], [0, 419.1, 242.7], [0, 0, 1]])
+CAM_P = np.array([[400.0, 0, 320, 0], [0, 400, 240, 0], [0, 0, 1, 0]])
+
+
+@pytest.mark.parametrize("dist,kind", [([-0.28, 0.07, 1e-3, -2e-3, 0.01], 0), ([0.02, -0.01, 0.004, -0.001], 1),
+                                       ([0, 0, 0, 0], 0), ([-0.3, 0.1, 0, 0, 0, 0.01, -0.02, 0.003], 0)])
+def test_camera_maps_and_undistort_bit_exact_vs_oracle(F, O, dist, kind):
+    W, H = 640, 480
+    cam = F.Camera(W, H, CAM_K, dist, P=CAM_P, distortion_type=kind)
+    m1, m2 = cam.maps()
+    o1, o2 = O.cam_init_maps(O.cam_config(W, H, CAM_K, dist, P=CAM_P, distortion_type=kind))
+    assert np.array_equal(m1, o1) and np.array_equal(m2, o2)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    assert np.array_equal(cam.UndistortImage(img), O.cam_remap(img, o1, o2))
+    # a cv::Mat view with a row stride (ROI of a wider image)
+    wide = rng.integers(0, 256, (H, W + 24)).astype(np.uint8)
+    assert np.array_equal(cam.UndistortImage(wide[:, 8:8 + W]), O.cam_remap(np.ascontiguousarray(wide[:, 8:8 + W]), o1, o2))
+
+
+def test_camera_from_maps_edges_and_ragged_sizes(F, O):
+    """maps handed over as they are (the maintainer's OpenCV maps): out-of-image, non-finite and
+    border-straddling coordinates, a source of a different size than the map, odd widths."""
+    rng = np.random.default_rng(11)
+    for (oh, ow, sh, sw) in [(33, 61, 40, 50), (480, 640, 480, 640), (1, 1, 7, 5), (17, 1030, 64, 1030)]:
+        m1 = rng.uniform(-3, sw + 2, (oh, ow)).astype(np.float32)
+        m2 = rng.uniform(-3, sh + 2, (oh, ow)).astype(np.float32)
+        m1.flat[0] = np.nan; m2.flat[-1] = np.inf
+        if ow > 4:
+            m1[0, 1:4] = [sw - 1, sw - 0.5, -0.5]
+        img = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+        cam = F.Camera.from_maps(m1, m2)
+        assert np.array_equal(cam.UndistortImage(img), O.cam_remap(img, m1, m2)), (oh, ow, sh, sw)
+
+
+def test_undistort_in_front_of_superpoint_on_one_stream(U, F, O, sp_blob, sp640):
+    """device-resident chain raw frames -> remap -> SuperPoint slots (only the raw u8 frame would
+    cross PCIe) == oracle remap followed by the host-path SuperPoint"""
+    import torch
+    H, W, B = 480, 640, 3
+    cam = F.Camera(W, H, CAM_K, [-0.28, 0.07, 1e-3, -2e-3, 0.01], P=CAM_P)
+    raw = np.stack(U.synth.shift_stream(7, B, H, W))
+    d_raw = torch.from_numpy(raw).cuda()
+    d_und = torch.zeros_like(d_raw)
+    slots = torch.zeros((B, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    cam.undistort_device(d_raw.data_ptr(), B, H, W, d_und.data_ptr(), superpoint=sp640)
+    sp640.infer_device(d_und.data_ptr(), B, H, W, slots[0].data_ptr())
+    sp640.sync()
+    m1, m2 = cam.maps()
+    for j in range(B):
+        und = O.cam_remap(raw[j], m1, m2)
+        assert np.array_equal(d_und[j].cpu().numpy(), und)
+        feat = sp640.infer(und)
+        # slots keep f32 (what SuperGlue consumes); the host API widens the same values to f64
+        assert feat is not None and np.array_equal(F.slot_to_host(slots[j].data_ptr()).astype(np.float32), feat.astype(np.float32))

@@ -240,3 +240,69 @@ def test_epipolar_reconstruct_recovers_the_motion(O):
     # too few matches
     ok, *_ = O.epi_reconstruct(K, k1[:7], k2, np.arange(7, dtype=np.int32))
     assert not ok
+
+
+# ------------------------------------------------------------------ camera
+# OpenCV is a third-party dependency that is not in the image and the reference holds no vectors
+# for it (parity unpinned): the restatement is checked against the closed forms it must satisfy.
+def _cam_K():
+    return np.array([[420.5, 0, 318.2], [0, 419.1, 242.7], [0, 0, 1]])
+
+
+def test_camera_maps_follow_the_distortion_model(O):
+    """map(u, v) = K * distort(K'^-1 (u, v, 1)): a vectorised, non-incremental numpy evaluation of
+    the radial-tangential and the fisheye model agrees to 1e-3 px (float maps)."""
+    K = _cam_K()
+    P = np.array([[400.0, 0, 320, 0], [0, 400, 240, 0], [0, 0, 1, 0]])
+    W, H = 640, 480
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    x, y = (u - P[0, 2]) / P[0, 0], (v - P[1, 2]) / P[1, 1]
+    r2 = x * x + y * y
+    # radial-tangential, 5 coefficients
+    k1, k2, p1, p2, k3 = -0.28, 0.07, 1e-3, -2e-3, 0.01
+    kr = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    m1, m2 = O.cam_init_maps(O.cam_config(W, H, K, [k1, k2, p1, p2, k3], P=P))
+    assert np.abs(m1 - (K[0, 0] * xd + K[0, 2])).max() < 1e-3 and np.abs(m2 - (K[1, 1] * yd + K[1, 2])).max() < 1e-3
+    # fisheye (equidistant polynomial)
+    kf = [0.02, -0.01, 0.004, -0.001]
+    r = np.sqrt(r2)
+    th = np.arctan(r)
+    thd = th * (1 + kf[0] * th ** 2 + kf[1] * th ** 4 + kf[2] * th ** 6 + kf[3] * th ** 8)
+    sc = np.where(r == 0, 1.0, thd / np.where(r == 0, 1.0, r))
+    m1, m2 = O.cam_init_maps(O.cam_config(W, H, K, kf, P=P, distortion_type=1))
+    assert np.abs(m1 - (K[0, 0] * x * sc + K[0, 2])).max() < 1e-3 and np.abs(m2 - (K[1, 1] * y * sc + K[1, 2])).max() < 1e-3
+    # no distortion, P = K: the identity map, and remap returns the image
+    m1, m2 = O.cam_init_maps(O.cam_config(W, H, K, [0, 0, 0, 0]))
+    assert np.abs(m1 - u).max() < 1e-3 and np.abs(m2 - v).max() < 1e-3
+
+
+def test_camera_remap_is_opencv_fixed_point_bilinear(O):
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    img = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    assert np.array_equal(O.cam_remap(img, u, v), img)
+    # integer shift: pixels that leave the image read the constant border 0
+    out = O.cam_remap(img, u + 3, v - 2)
+    ref = np.zeros_like(img)
+    ref[2:, :W - 3] = img[:H - 2, 3:]
+    assert np.array_equal(out, ref)
+    # half-pixel: (a + b + 1) >> 1; at the right edge the second tap is the border
+    out = O.cam_remap(img, u + 0.5, v)
+    a = img.astype(np.int32)
+    b = np.concatenate([a[:, 1:], np.zeros((H, 1), np.int32)], axis=1)
+    assert np.array_equal(out, ((a + b + 1) >> 1).astype(np.uint8))
+    # coordinates are quantised to 1/32 px, weights to 15 bits: within 1 grey level of float bilinear
+    fx, fy = rng.uniform(0, W - 1.01, (H, W)).astype(np.float32), rng.uniform(0, H - 1.01, (H, W)).astype(np.float32)
+    out = O.cam_remap(img, fx, fy).astype(np.float64)
+    qx, qy = np.round(fx * 32) / 32, np.round(fy * 32) / 32
+    x0, y0 = np.floor(qx).astype(int), np.floor(qy).astype(int)
+    ax, ay = qx - x0, qy - y0
+    x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+    fl = (a[y0, x0] * (1 - ax) * (1 - ay) + a[y0, x1] * ax * (1 - ay) + a[y1, x0] * (1 - ax) * ay + a[y1, x1] * ax * ay)
+    assert np.abs(out - fl).max() <= 0.5 + 1e-9
+    # non-finite and far-away coordinates are outside
+    bad = u.copy(); bad[0, 0] = np.nan; bad[0, 1] = np.inf; bad[0, 2] = 1e9; bad[0, 3] = -1e9
+    assert (O.cam_remap(img, bad, v)[0, :4] == 0).all()

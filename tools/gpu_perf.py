@@ -44,3 +44,17 @@ n = 1000
 lin = (2 * (3 * 32 + 32 * 64 + 64 * 128 + 128 * 256 + 256 * 256) + 18 * 2 * (3 * 65536 + 65536 + 262144 + 131072) + 2 * 65536) * 2 * n / 1e9 * B
 att = 9 * 4 * 256 * (4 * n * n) / 1e9 * B
 print("TFLOP/s: conv1 %.1f  linear %.1f  attn %.1f" % (gf_conv1 / s[1], lin / (p[1] + p[2] - p[7]), att / p[7]))
+
+# ---- Camera::UndistortImage stage: HBM-bound gather, 6 map bytes + 1 source + 1 output byte/pixel
+import time
+K = np.array([[420.5, 0, 318.2], [0, 419.1, 242.7], [0, 0, 1]])
+cam = F.Camera(W, H, K, [-0.28, 0.07, 1e-3, -2e-3, 0.01])
+d_und = torch.zeros_like(d[:B])
+for reps in (3, 200):
+    cam.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cam.undistort_device(d[0].data_ptr(), B, H, W, d_und.data_ptr())
+    cam.sync()
+    dt = (time.perf_counter() - t0) / reps
+print("undistort %d frames %dx%d: %.1f us/launch, %.0f GB/s algorithmic (8 B/pixel)" % (B, W, H, dt * 1e6, B * H * W * 8 / dt / 1e9))

@@ -19,6 +19,8 @@ SYMBOLS = [
     "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_sync",
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
     "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_probe_h2gemm_variant", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
+    "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
+    "urf_cam_undistort_device", "urf_cam_sync",
 ]
 
 
@@ -37,6 +39,12 @@ class SGConfig(C.Structure):
 
 class EpiConfig(C.Structure):
     _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32)]
+
+
+class CamConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("distortion_type", C.c_int), ("K", C.c_double * 9),
+                ("D", C.c_double * 14), ("n_dist", C.c_int), ("R", C.c_double * 9), ("P", C.c_double * 9),
+                ("device", C.c_int)]
 
 
 class DMatch(C.Structure):
@@ -72,6 +80,7 @@ def lib():
         L.urf_normalize_keypoints.restype = None
         L.urf_sp_destroy.restype = None
         L.urf_pm_destroy.restype = None
+        L.urf_cam_destroy.restype = None
         L.urf_sp_stream.restype = C.c_void_p
         _lib = L
     return _lib

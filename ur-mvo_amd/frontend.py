@@ -280,6 +280,72 @@ class EpipolarGeometry:
         return bool(rc), T.reshape(4, 4), P[:n1], tri[:n1], model.value, (float(sc[0]), float(sc[1]))
 
 
+class Camera:
+    """The undistortion part of Camera (include/camera.h, src/camera.cc:69-85, 116-118 of UR-MVO):
+    maps built once, `UndistortImage` per frame on the GPU.
+
+    Camera(width, height, K, D, P=None, R=None, distortion_type=0)  -- maps from the calibration, or
+    Camera.from_maps(map1, map2)                                     -- OpenCV's own CV_32FC1 maps."""
+
+    def __init__(self, width=0, height=0, K=None, D=(), P=None, R=None, distortion_type=0, device=0, _maps=None):
+        self._h = C.c_void_p()
+        if _maps is not None:
+            m1 = np.ascontiguousarray(_maps[0], np.float32)
+            m2 = np.ascontiguousarray(_maps[1], np.float32)
+            assert m1.shape == m2.shape and m1.ndim == 2
+            self.height, self.width = m1.shape
+            check(_lib.lib().urf_cam_create_from_maps(_p(m1), _p(m2), self.width, self.height, device,
+                                                      C.byref(self._h)), "urf_cam_create_from_maps")
+            return
+        c = _lib.CamConfig()
+        c.width, c.height, c.distortion_type, c.device = int(width), int(height), int(distortion_type), int(device)
+        Kf = np.asarray(K, np.float64).reshape(9)
+        Pf = Kf if P is None else np.asarray(P, np.float64).reshape(3, -1)[:, :3].reshape(9)   # LEFT_P(0:3,0:3)
+        Rf = np.eye(3).reshape(9) if R is None else np.asarray(R, np.float64).reshape(9)
+        Df = np.asarray(D, np.float64).reshape(-1)
+        for i in range(9):
+            c.K[i], c.P[i], c.R[i] = Kf[i], Pf[i], Rf[i]
+        for i in range(min(Df.size, 14)):
+            c.D[i] = Df[i]
+        c.n_dist = int(min(Df.size, 14))
+        self.width, self.height = int(width), int(height)
+        check(_lib.lib().urf_cam_create(C.byref(c), C.byref(self._h)), "urf_cam_create")
+
+    @classmethod
+    def from_maps(cls, map1, map2, device=0):
+        return cls(device=device, _maps=(map1, map2))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().urf_cam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def maps(self):
+        m1 = np.empty((self.height, self.width), np.float32)
+        m2 = np.empty_like(m1)
+        check(_lib.lib().urf_cam_maps(self._h, _p(m1), _p(m2)), "urf_cam_maps")
+        return m1, m2
+
+    def UndistortImage(self, image):
+        """src/camera.cc:116-118: u8 [rows, cols] -> u8 [height, width]"""
+        img = np.asarray(image)
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        out = np.empty((self.height, self.width), np.uint8)
+        check(_lib.lib().urf_cam_undistort(self._h, _p(img), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]),
+                                           _p(out), C.c_size_t(out.strides[0])), "urf_cam_undistort")
+        return out
+
+    def undistort_device(self, d_imgs, n, rows, cols, d_out, superpoint=None):
+        """n device-resident frames; with `superpoint` the remap is enqueued on that handle's stream, in
+        order in front of its next infer_device()."""
+        st = _lib.lib().urf_sp_stream(superpoint._h) if superpoint is not None else None
+        check(_lib.lib().urf_cam_undistort_device(self._h, C.c_void_p(d_imgs), n, rows, cols, C.c_void_p(d_out),
+                                                  C.c_void_p(st)), "urf_cam_undistort_device")
+
+    def sync(self):
+        check(_lib.lib().urf_cam_sync(self._h), "urf_cam_sync")
+
+
 def slot_to_host(d_slot_ptr):
     feat = np.zeros((CAP, 259), np.float64)
     K = C.c_int(0)
