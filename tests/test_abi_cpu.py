@@ -101,3 +101,74 @@ def test_cpp_shim_headers_compile_and_link(tmp_path):
                            "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front",
                            "-Wl,-rpath," + os.path.join(ROOT, "ur-mvo_amd")])
     assert os.path.exists(exe)
+
+
+# ------------------------------------------------------------------ weight import (the data format in front of build())
+def test_superpoint_state_dict_and_onnx_import_reproduce_the_packed_blob(U, tmp_path):
+    """names of superpoint/SP/model.py:38-53 -> the SP blob; the ONNX reader finds the same tensors by
+    name (raw_data and float_data encodings) and, for an exporter that renamed them, by Conv order"""
+    W = U.weights_io
+    w = U.synth.sp_weights(0)
+    blob = U.synth.pack_sp(w)
+    sd = {}
+    for name, (Wt, b) in w.items():
+        sd[name + ".weight"], sd[name + ".bias"] = Wt, b
+    assert np.array_equal(W.superpoint_from_state_dict(sd), blob)
+    nodes, prev = [], "input"
+    for i, (name, *_r) in enumerate(U.synth.SP_CONVS):
+        nodes.append(("Conv", [prev, name + ".weight", name + ".bias"], [f"t{i}"]))
+        nodes.append(("Relu", [f"t{i}"], [f"r{i}"]))
+        prev = f"r{i}"
+    for raw in (True, False):
+        p = str(tmp_path / f"sp_{raw}.onnx")
+        W.write_onnx(p, sd, nodes, raw=raw)
+        assert np.array_equal(W.superpoint_from_onnx(p), blob)
+    anon = {f"onnx::Conv_{100 + 2 * i}": sd[n + ".weight"] for i, (n, *_r) in enumerate(U.synth.SP_CONVS)}
+    anon.update({f"onnx::Conv_{101 + 2 * i}": sd[n + ".bias"] for i, (n, *_r) in enumerate(U.synth.SP_CONVS)})
+    nodes2 = [("Conv", [f"x{i}", f"onnx::Conv_{100 + 2 * i}", f"onnx::Conv_{101 + 2 * i}"], [f"x{i + 1}"])
+              for i in range(len(U.synth.SP_CONVS))]
+    p = str(tmp_path / "sp_anon.onnx")
+    W.write_onnx(p, anon, nodes2)
+    assert np.array_equal(W.superpoint_from_onnx(p), blob)
+    # container round trip = what urf_sp_build_file reads
+    c = str(tmp_path / "sp.urfw")
+    W.save_container(c, W.KIND_SP, blob)
+    kind, back = W.load_container(c)
+    assert kind == 1 and np.array_equal(back, blob)
+    with pytest.raises(ValueError):
+        W.save_container(c, W.KIND_SG, blob)
+
+
+def test_superglue_state_dict_import_folds_batchnorm_and_reorders_heads(U, tmp_path):
+    W = U.weights_io
+    w = U.synth.sg_weights(0)
+    blob = U.synth.pack_sg(w)
+    sd = W.superglue_to_state_dict(w)
+    assert sd["gnn.layers.3.attn.proj.1.weight"].shape == (256, 256, 1) and "kenc.encoder.10.running_var" in sd
+    assert np.array_equal(W.superglue_from_state_dict(sd), blob)
+    # an exported graph with BatchNorm folded and anonymous initialisers: both images walk the same
+    # layers (every weight is used twice), the importer keeps first uses in graph order
+    folded, nodes, k = {}, [], [0]
+
+    def conv(Wt, b, src):
+        name = f"onnx::Conv_{k[0]}"
+        if not any(v is Wt for v in folded.values()):
+            folded[name + "w"], folded[name + "b"] = Wt[:, :, None], b
+            k[0] += 1
+        key = [n for n, v in folded.items() if v.base is Wt or v is Wt or (v.shape[:2] == Wt.shape and np.shares_memory(v, Wt))][0]
+        nodes.append(("Conv", [src, key, key[:-1] + "b"], [src + "'"]))
+
+    seq = []
+    for (Wt, b, bnp) in w["kenc"]:
+        seq.append(U.synth._fold_bn(Wt, b, bnp))
+    for L in w["layers"]:
+        seq += [L["q"], L["k"], L["v"], L["merge"], U.synth._fold_bn(*L["mlp0"]), L["mlp1"]]
+    seq.append(w["final"])
+    for img in ("a", "b"):                 # second image: the same initialisers again
+        for (Wt, b) in seq:
+            conv(Wt, b, img)
+    folded["bin_score"] = np.array(w["bin_score"], np.float32)
+    p = str(tmp_path / "sg.onnx")
+    W.write_onnx(p, folded, nodes)
+    got = W.superglue_from_onnx(p)
+    assert got.shape == blob.shape and np.array_equal(got, blob)
