@@ -215,6 +215,46 @@ int urf_cam_undistort(urf_cam *h, const uint8_t *img, int rows, int cols, size_t
 int urf_cam_undistort_device(urf_cam *h, const void *d_imgs, int n, int rows, int cols, void *d_out, void *stream);
 int urf_cam_sync(urf_cam *h);
 
+/* ------------------------------------------------------------ frame stream -- */
+/* The batched caller of the path: what
+ * Tracking::ExtractFeatureThread / ExtractFeatureAndMatch (src/tracking.cc:123-218,
+ * 338-377) do per frame -- SuperPoint, then PointMatching against the previous
+ * (key)frame with outlier rejection -- for a stream of frames submitted in batches.
+ * Features stay in device slots between the two stages; SuperPoint and
+ * `matchers` PointMatching handles run on their own HIP streams so consecutive
+ * batches overlap; only raw u8 frames go up and match lists come down. */
+typedef struct {
+  urf_sp_config sp;          /* max_batch is overridden by `batch` */
+  urf_sg_config sg;          /* max_pairs / device are overridden (batch, sp.device) */
+  int batch;                 /* frames per submit, 1..64 */
+  int matchers;              /* 0 -> 2 alternating matcher handles */
+  int history_batches;       /* extra batches kept resident for references older than 2 batches */
+  int outlier_rejection;     /* MatchingPoints(..., outlier_rejection): src/tracking.cc:355 passes true */
+} urf_fe_config;
+typedef struct urf_fe urf_fe;
+
+int urf_fe_create(const urf_fe_config *cfg, urf_fe **out);
+int urf_fe_build(urf_fe *h, const float *sp_blob, size_t sp_floats, const float *sg_blob, size_t sg_floats);
+int urf_fe_build_files(urf_fe *h, const char *sp_engine_file, const char *sg_engine_file);
+void urf_fe_destroy(urf_fe *h);
+/* Camera::UndistortImage in front of SuperPoint; `cam` is borrowed, map_rows x map_cols is its map size. */
+int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols);
+/* n <= batch host frames (u8, row stride `step`, frame stride `frame_stride` bytes); asynchronous.
+ * ref: NULL or n global frame indices (counted from the first submitted frame): frame j is matched
+ * against frame ref[j] (-1 = its predecessor) -- the reference matches against the last keyframe
+ * (src/tracking.cc:196-203).  A referenced frame must be in this batch or in one of the
+ * 2 + history_batches batches before it.  At most `matchers` + 1 batches may be in flight (the
+ * newest one's SuperPoint runs while the older ones are matched). */
+int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step, size_t frame_stride,
+                  const long *ref);
+/* Oldest batch in flight: K[j] keypoints, nmatch[j] matches at matches[j*cap ...] (queryIdx -> the
+ * reference frame, trainIdx -> frame j); the stream's first frame has no reference and 0 matches.
+ * feat: NULL or nframes matrices of 259 x URF_MAX_KEYPOINTS f64 (column-major). */
+int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat);
+int urf_fe_in_flight(urf_fe *h);
+urf_sp *urf_fe_superpoint(urf_fe *h);
+urf_pm *urf_fe_matcher(urf_fe *h, int i);
+
 /* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);

@@ -438,3 +438,67 @@ def test_undistort_in_front_of_superpoint_on_one_stream(U, F, O, sp_blob, sp640)
         feat = sp640.infer(und)
         # slots keep f32 (what SuperGlue consumes); the host API widens the same values to f64
         assert feat is not None and np.array_equal(F.slot_to_host(slots[j].data_ptr()).astype(np.float32), feat.astype(np.float32))
+
+
+# ------------------------------------------------------------------ frame stream
+def _as_tuples(m):
+    return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
+
+
+def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, sp640, pm):
+    """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
+    SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)"""
+    frames = np.stack(U.synth.shift_stream(17, 21, 480, 640))
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=1000), F.SuperGlueConfig(), batch=8, max_height=480, max_width=640)
+    assert fs.build(sp_blob, sg_blob)
+    got_K, got_m, got_f = [], [], []
+    for b0 in (0, 8, 16):
+        fs.submit(frames[b0:b0 + 8])
+        if fs.in_flight() == 3:
+            K, m, f = fs.collect(want_features=True)
+            got_K += list(K); got_m += m; got_f += f
+    while fs.in_flight():
+        K, m, f = fs.collect(want_features=True)
+        got_K += list(K); got_m += m; got_f += f
+    assert len(got_K) == 21
+    feats = [sp640.infer(fr) for fr in frames]
+    assert len(got_m[0]) == 0                                # no predecessor
+    for t in range(21):
+        assert got_K[t] == feats[t].shape[0]
+        assert np.array_equal(got_f[t].astype(np.float32), feats[t].astype(np.float32))
+        if t > 0:
+            ref = pm.MatchingPoints(feats[t - 1], feats[t], True)
+            assert _as_tuples(got_m[t]) == ref, t
+            assert len(ref) > 300
+
+
+def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg_blob, sp640, pm):
+    """frames matched against a keyframe up to two batches back, undistortion in front, and the error
+    paths: too many batches in flight, a reference that left the ring"""
+    K = np.array([[420.5, 0, 318.2], [0, 419.1, 242.7], [0, 0, 1]])
+    cam = F.Camera(640, 480, K, [-0.05, 0.01, 1e-4, -2e-4])
+    m1, m2 = cam.maps()
+    frames = np.stack(U.synth.shift_stream(23, 12, 480, 640, step=(0, 0)))     # a static scene: any pair matches
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=600), F.SuperGlueConfig(), batch=4, max_height=480, max_width=640)
+    assert fs.build(sp_blob, sg_blob)
+    fs.set_camera(cam)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=600), max_height=480, max_width=640)
+    assert sp.build(sp_blob)
+    feats = [sp.infer(O.cam_remap(fr, m1, m2)) for fr in frames]
+    out = []
+    fs.submit(frames[0:4])                      # predecessor chain
+    fs.submit(frames[4:8], ref=[0, 0, 5, -1])   # keyframe 0 (previous batch), an earlier frame of this batch, predecessor
+    fs.submit(frames[8:12], ref=[0, 3, 7, 10])  # keyframe two batches back; its match call is deferred
+    with pytest.raises(RuntimeError, match="in flight"):
+        fs.submit(frames[8:12])                 # matchers + 1 batches already in flight
+    while fs.in_flight():
+        out += fs.collect()[1]
+    refs = [None, 0, 1, 2, 0, 0, 5, 6, 0, 3, 7, 10]
+    for t in range(1, 12):
+        want = pm.MatchingPoints(feats[refs[t]], feats[t], True)
+        assert _as_tuples(out[t]) == want, t
+    with pytest.raises(RuntimeError, match="left the ring"):
+        fs.submit(frames[0:4], ref=[-1, -1, -1, 0])   # frame 0 is 3 batches back: outside the 2-batch window
+    assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
+    fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
+    assert _as_tuples(fs.collect()[1][3]) == pm.MatchingPoints(feats[9], feats[3], True)

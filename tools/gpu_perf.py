@@ -58,3 +58,31 @@ for reps in (3, 200):
     cam.sync()
     dt = (time.perf_counter() - t0) / reps
 print("undistort %d frames %dx%d: %.1f us/launch, %.0f GB/s algorithmic (8 B/pixel)" % (B, W, H, dt * 1e6, B * H * W * 8 / dt / 1e9))
+
+# ---- native frame stream (urf_fe_*): host frames in, match lists out = the PCIe-inclusive rate
+frames_h = np.stack(synth.shift_stream(100, 5 * B, H, W))
+for with_cam in (False, True):
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=1000), F.SuperGlueConfig(), batch=B, max_height=H, max_width=W,
+                       precision=PREC)
+    assert fs.build(spb, sgb)
+    if with_cam:
+        fs.set_camera(cam)
+    nb, t_sub, t_col = 40, 0.0, 0.0
+    for b in range(nb + 2):
+        if b == 2:
+            t0 = time.perf_counter()
+            t_sub = t_col = 0.0
+        k = b % 5
+        ta = time.perf_counter()
+        fs.submit(frames_h[k * B:(k + 1) * B])
+        tb = time.perf_counter()
+        if fs.in_flight() == 3:
+            fs.collect()
+        t_sub += tb - ta
+        t_col += time.perf_counter() - tb
+    while fs.in_flight():
+        fs.collect()
+    dt = time.perf_counter() - t0
+    print("frame stream (host u8 frames -> match lists%s): %.0f frames/s; host per batch: submit %.2f ms, collect (wait + deferred enqueue) %.2f ms"
+          % (", undistort in front" if with_cam else "", nb * B / dt, 1e3 * t_sub / nb, 1e3 * t_col / nb))
+    del fs

@@ -21,6 +21,8 @@ SYMBOLS = [
     "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_probe_h2gemm_variant", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync",
+    "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
+    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher",
 ]
 
 
@@ -45,6 +47,11 @@ class CamConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("distortion_type", C.c_int), ("K", C.c_double * 9),
                 ("D", C.c_double * 14), ("n_dist", C.c_int), ("R", C.c_double * 9), ("P", C.c_double * 9),
                 ("device", C.c_int)]
+
+
+class FEConfig(C.Structure):
+    _fields_ = [("sp", SPConfig), ("sg", SGConfig), ("batch", C.c_int), ("matchers", C.c_int),
+                ("history_batches", C.c_int), ("outlier_rejection", C.c_int)]
 
 
 class DMatch(C.Structure):
@@ -81,6 +88,9 @@ def lib():
         L.urf_sp_destroy.restype = None
         L.urf_pm_destroy.restype = None
         L.urf_cam_destroy.restype = None
+        L.urf_fe_destroy.restype = None
+        L.urf_fe_superpoint.restype = C.c_void_p
+        L.urf_fe_matcher.restype = C.c_void_p
         L.urf_sp_stream.restype = C.c_void_p
         _lib = L
     return _lib

@@ -1,0 +1,273 @@
+// fe_api.hip -- the batched caller of the path.
+//
+// Tracking::ExtractFeatureThread / ExtractFeatureAndMatch (src/tracking.cc:123-218,
+// 338-377 of the reference) take ONE frame, spawn a thread, run SuperPoint, copy
+// the features to the host, copy them back for SuperGlue, and sleep between
+// polls.  urf_fe is the same contract for a STREAM of frames, submitted in
+// batches: features stay in device slots between SuperPoint and SuperGlue, each
+// frame is matched against the previous frame or against an earlier frame the
+// caller names (the reference matches against its last keyframe,
+// src/tracking.cc:196-203), and three HIP streams overlap the stages of
+// consecutive batches (SuperPoint | matcher A | matcher B).  Only raw u8 frames
+// go up and match lists (optionally features) come down.
+//
+// This file is orchestration only: it calls the same C ABI a user would
+// (urf_sp_infer_device, urf_match_device_async, urf_pm_fetch, urf_cam_*).
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "../../include/urf.h"
+#include "urf_common.h"
+
+namespace {
+constexpr int kMaxMatchers = 4;
+}
+
+struct urf_fe {
+  urf_fe_config cfg{};
+  int B = 0, M = 0, NB = 0;           // frames per batch, matchers, ring depth (batches)
+  int rows = 0, cols = 0;             // raw frame geometry (fixed at the first submit)
+  int frows = 0, fcols = 0;           // geometry fed to SuperPoint (the camera's map size when undistorting)
+  urf_sp *sp = nullptr;
+  urf_pm *pm[kMaxMatchers] = {nullptr, nullptr, nullptr, nullptr};
+  urf_cam *cam = nullptr;             // borrowed
+  bool built = false;
+  size_t slot_bytes = 0;
+  uint8_t *d_slots = nullptr;         // NB x B slots
+  uint8_t *d_raw = nullptr;           // NB x B raw frames
+  uint8_t *d_und = nullptr;           // NB x B undistorted frames (camera set)
+  uint8_t *h_stage = nullptr;         // pinned, NB x B raw frames
+  int *h_K = nullptr;                 // pinned, NB x B keypoint counts (copied on SuperPoint's stream right after SP(b))
+  std::vector<hipEvent_t> ev_K;       // per ring entry: that copy has landed
+  hipStream_t cst = nullptr;          // non-blocking stream for collect-time copies (a null-stream copy would
+                                      // wait for every blocking stream, i.e. serialise the pipeline)
+  long next_batch = 0;                // index of the next batch to submit
+  long frames_seen = 0;               // global index of the first frame of the next batch
+  struct Pending {
+    long batch; int n; int first_pair; long first_frame;
+    bool matched;                       // its match call has been enqueued (else deferred until its matcher is free)
+    std::vector<const void *> s0, s1;
+  };
+  std::deque<Pending> pending;
+  std::vector<long> batch_first;      // ring: global index of the first frame held by ring entry k
+  std::vector<int> batch_n;           // ring: frames held by ring entry k
+  std::vector<long> batch_id;         // ring: batch index held by ring entry k
+};
+
+static uint8_t *slot_ptr(urf_fe *h, long ring_entry, int j) {
+  return h->d_slots + ((size_t)ring_entry * h->B + j) * h->slot_bytes;
+}
+
+extern "C" int urf_fe_create(const urf_fe_config *cfg, urf_fe **out) {
+  URF_CHECK(cfg && out, "urf_fe_create: null argument");
+  URF_CHECK(cfg->batch >= 1 && cfg->batch <= 64, "urf_fe_create: batch must be 1..64");
+  urf_fe *h = new urf_fe;
+  h->cfg = *cfg;
+  h->B = cfg->batch;
+  h->M = cfg->matchers <= 0 ? 2 : (cfg->matchers > kMaxMatchers ? kMaxMatchers : cfg->matchers);
+  // ring: M batches being matched + 1 whose SuperPoint already runs + the 2 + history_batches a reference may reach
+  h->NB = h->M + 3 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
+  urf_sp_config sc = cfg->sp;
+  sc.max_batch = h->B;
+  if (urf_sp_create(&sc, &h->sp)) { delete h; return -1; }
+  for (int m = 0; m < h->M; ++m) {
+    urf_sg_config gc = cfg->sg;
+    gc.max_pairs = h->B;
+    gc.device = sc.device;
+    if (urf_pm_create(&gc, &h->pm[m])) { urf_fe_destroy(h); return -1; }
+  }
+  h->batch_first.assign(h->NB, -1);
+  h->batch_n.assign(h->NB, 0);
+  h->batch_id.assign(h->NB, -1);
+  *out = h;
+  return 0;
+}
+
+extern "C" int urf_fe_build(urf_fe *h, const float *sp_blob, size_t sp_floats, const float *sg_blob, size_t sg_floats) {
+  URF_CHECK(h && sp_blob && sg_blob, "urf_fe_build: null argument");
+  if (urf_sp_build(h->sp, sp_blob, sp_floats)) return -1;
+  for (int m = 0; m < h->M; ++m)
+    if (urf_pm_build(h->pm[m], sg_blob, sg_floats)) return -1;
+  h->slot_bytes = urf_slot_bytes();
+  URF_HIP(hipSetDevice(h->cfg.sp.device));
+  URF_HIP(hipMalloc((void **)&h->d_slots, (size_t)h->NB * h->B * h->slot_bytes));
+  URF_HIP(hipMemset(h->d_slots, 0, (size_t)h->NB * h->B * h->slot_bytes));
+  URF_HIP(hipHostMalloc((void **)&h->h_K, sizeof(int) * h->B * h->NB, hipHostMallocDefault));
+  URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
+  h->ev_K.resize(h->NB);
+  for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->built = true;
+  return 0;
+}
+
+extern "C" int urf_fe_build_files(urf_fe *h, const char *sp_engine_file, const char *sg_engine_file) {
+  URF_CHECK(h && sp_engine_file && sg_engine_file, "urf_fe_build_files: null argument");
+  if (urf_sp_build_file(h->sp, sp_engine_file)) return -1;
+  for (int m = 0; m < h->M; ++m)
+    if (urf_pm_build_file(h->pm[m], sg_engine_file)) return -1;
+  h->slot_bytes = urf_slot_bytes();
+  URF_HIP(hipSetDevice(h->cfg.sp.device));
+  URF_HIP(hipMalloc((void **)&h->d_slots, (size_t)h->NB * h->B * h->slot_bytes));
+  URF_HIP(hipMemset(h->d_slots, 0, (size_t)h->NB * h->B * h->slot_bytes));
+  URF_HIP(hipHostMalloc((void **)&h->h_K, sizeof(int) * h->B * h->NB, hipHostMallocDefault));
+  URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
+  h->ev_K.resize(h->NB);
+  for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->built = true;
+  return 0;
+}
+
+extern "C" void urf_fe_destroy(urf_fe *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.sp.device);
+  for (int m = 0; m < kMaxMatchers; ++m)
+    if (h->pm[m]) { (void)urf_pm_sync(h->pm[m]); }
+  if (h->sp && h->built) (void)urf_sp_sync(h->sp);
+  for (int m = 0; m < kMaxMatchers; ++m) urf_pm_destroy(h->pm[m]);
+  urf_sp_destroy(h->sp);
+  (void)hipFree(h->d_slots); (void)hipFree(h->d_raw); (void)hipFree(h->d_und);
+  (void)hipHostFree(h->h_stage); (void)hipHostFree(h->h_K);
+  if (h->cst) (void)hipStreamDestroy(h->cst);
+  for (auto &e : h->ev_K) (void)hipEventDestroy(e);
+  delete h;
+}
+
+// Camera::UndistortImage in front of SuperPoint (src/tracking.cc feeds undistorted frames); `cam` is borrowed.
+extern "C" int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols) {
+  URF_CHECK(h && h->next_batch == 0, "urf_fe_set_camera: set the camera before the first submit");
+  URF_CHECK(!cam || (map_rows > 0 && map_cols > 0), "urf_fe_set_camera: give the map size");
+  h->cam = cam;
+  h->frows = cam ? map_rows : 0;
+  h->fcols = cam ? map_cols : 0;
+  return 0;
+}
+
+static int fe_enqueue_match(urf_fe *h, urf_fe::Pending &p) {
+  urf_pm *pm = h->pm[p.batch % h->M];
+  if (!p.s0.empty()) {
+    if (urf_pm_wait_for_sp(pm, h->sp)) return -1;        // match(b) needs SP(b) (and every earlier slot)
+    if (urf_match_device_async(pm, (int)p.s0.size(), p.s0.data(), p.s1.data(), h->cfg.outlier_rejection)) return -1;
+  }
+  p.matched = true;
+  return 0;
+}
+
+// Submit n <= batch frames (host u8, row stride `step`; frame stride `frame_stride` bytes).
+// ref: NULL, or n global frame indices: frame j is matched against frame ref[j] (-1 = its predecessor).
+// A referenced frame must be in this batch or in one of the 2 + history_batches batches before it.
+// The very first frame of the stream has no predecessor: it gets 0 matches.
+extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step,
+                             size_t frame_stride, const long *ref) {
+  URF_CHECK(h && h->built, "urf_fe_submit: handle is not built");
+  URF_CHECK(frames && n >= 1 && n <= h->B && rows > 0 && cols > 0 && step >= (size_t)cols, "urf_fe_submit: bad argument");
+  URF_CHECK((int)h->pending.size() <= h->M, "urf_fe_submit: %d batches in flight, collect one first", h->M + 1);
+  URF_HIP(hipSetDevice(h->cfg.sp.device));
+  if (!h->d_raw) {
+    h->rows = rows; h->cols = cols;
+    if (!h->cam) { h->frows = rows; h->fcols = cols; }
+    const size_t fr = (size_t)rows * cols;
+    URF_HIP(hipMalloc((void **)&h->d_raw, (size_t)h->NB * h->B * fr));
+    URF_HIP(hipHostMalloc((void **)&h->h_stage, (size_t)h->NB * h->B * fr, hipHostMallocDefault));
+    if (h->cam) URF_HIP(hipMalloc((void **)&h->d_und, (size_t)h->NB * h->B * h->frows * h->fcols));
+  }
+  URF_CHECK(rows == h->rows && cols == h->cols, "urf_fe_submit: frame size changed (%dx%d -> %dx%d)", h->cols, h->rows, cols, rows);
+  const long b = h->next_batch;
+  const int k = (int)(b % h->NB);
+  // pair list first: a bad reference must fail before anything is enqueued or the ring changes
+  std::vector<const void *> s0, s1;
+  int first_pair = 0;
+  for (int j = 0; j < n; ++j) {
+    const long g = h->frames_seen + j;
+    const long want = (ref && ref[j] >= 0) ? ref[j] : g - 1;
+    if (want < 0) { first_pair = 1; continue; }          // first frame of the stream
+    URF_CHECK(j > 0 || first_pair == 0, "urf_fe_submit: internal pair bookkeeping");
+    URF_CHECK(want < g, "urf_fe_submit: frame %ld cannot be matched against frame %ld", g, want);
+    const uint8_t *src = nullptr;
+    if (want >= h->frames_seen) {
+      src = slot_ptr(h, k, (int)(want - h->frames_seen));   // an earlier frame of this batch
+    } else {
+      // window = the last NB - M - 1 batches: an older ring entry may be refilled by SuperPoint while
+      // this batch's matcher (up to M submits behind) still reads it; entry k is being refilled now
+      for (int e = 0; e < h->NB && !src; ++e)
+        if (e != k && h->batch_id[e] >= b - (h->NB - h->M - 1) && want >= h->batch_first[e] &&
+            want < h->batch_first[e] + h->batch_n[e])
+          src = slot_ptr(h, e, (int)(want - h->batch_first[e]));
+    }
+    URF_CHECK(src, "urf_fe_submit: reference frame %ld has left the ring (history_batches too small)", want);
+    s0.push_back(src);
+    s1.push_back(slot_ptr(h, k, j));
+  }
+  const size_t fr = (size_t)rows * cols;
+  hipStream_t st = (hipStream_t)urf_sp_stream(h->sp);
+  // raw frames -> pinned staging -> device, on SuperPoint's stream.  The staging entry k was last
+  // read by the copy of batch b - NB, which finished before match(b - NB) was collected.
+  uint8_t *stage = h->h_stage + (size_t)k * h->B * fr;
+  for (int j = 0; j < n; ++j)
+    for (int r = 0; r < rows; ++r) memcpy(stage + (size_t)j * fr + (size_t)r * cols, frames + (size_t)j * frame_stride + (size_t)r * step, cols);
+  uint8_t *d_raw = h->d_raw + (size_t)k * h->B * fr;
+  URF_HIP(hipMemcpyAsync(d_raw, stage, (size_t)n * fr, hipMemcpyHostToDevice, st));
+  const uint8_t *d_in = d_raw;
+  if (h->cam) {
+    uint8_t *d_und = h->d_und + (size_t)k * h->B * h->frows * h->fcols;
+    if (urf_cam_undistort_device(h->cam, d_raw, n, rows, cols, d_und, st)) return -1;
+    d_in = d_und;
+  }
+  if (urf_sp_infer_device(h->sp, n, d_in, h->frows, h->fcols, slot_ptr(h, k, 0))) return -1;
+  // keypoint counts (slot headers) come down behind SP(b), long before the batch is collected
+  URF_HIP(hipMemcpy2DAsync(h->h_K + (size_t)k * h->B, sizeof(int), slot_ptr(h, k, 0), h->slot_bytes, sizeof(int), n,
+                           hipMemcpyDeviceToHost, st));
+  URF_HIP(hipEventRecord(h->ev_K[k], st));
+  h->batch_first[k] = h->frames_seen;
+  h->batch_n[k] = n;
+  h->batch_id[k] = b;
+  urf_fe::Pending p{b, n, first_pair, h->frames_seen, false, std::move(s0), std::move(s1)};
+  // SuperPoint(b) is enqueued in any case; the match call needs its matcher handle free, i.e. the batch
+  // M submits back collected -- otherwise it is deferred to that collect
+  if ((int)h->pending.size() < h->M) {
+    if (fe_enqueue_match(h, p)) return -1;
+  }
+  h->pending.push_back(std::move(p));
+  h->next_batch = b + 1;
+  h->frames_seen += n;
+  return 0;
+}
+
+// Results of the oldest submitted batch (blocks until its match lists are on the host).
+//   nframes: frames in that batch; K[j]: keypoints of frame j; nmatch[j] / matches[j*cap ..]: its matches
+//   (queryIdx indexes the reference frame's keypoints, trainIdx frame j's, like
+//   PointMatching::MatchingPoints(features_ref, features_j)); feat: NULL or nframes matrices
+//   of 259 x URF_MAX_KEYPOINTS f64 (column-major, the reference's Eigen storage).
+extern "C" int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat) {
+  URF_CHECK(h && h->built && nframes && K && matches && nmatch, "urf_fe_collect: bad argument");
+  URF_CHECK(!h->pending.empty(), "urf_fe_collect: nothing submitted");
+  URF_HIP(hipSetDevice(h->cfg.sp.device));
+  const urf_fe::Pending &p0 = h->pending.front();
+  URF_CHECK(p0.matched, "urf_fe_collect: internal: oldest batch has no match call");
+  const urf_fe::Pending p = p0;
+  const int k = (int)(p.batch % h->NB);
+  urf_pm *pm = h->pm[p.batch % h->M];
+  const int P = p.n - p.first_pair;
+  for (int j = 0; j < p.n; ++j) nmatch[j] = 0;
+  if (P > 0) {
+    if (urf_pm_fetch(pm, P, matches + (size_t)p.first_pair * cap, cap, nmatch + p.first_pair)) return -1;
+  } else {
+    if (urf_sp_sync(h->sp)) return -1;
+  }
+  URF_HIP(hipEventSynchronize(h->ev_K[k]));
+  for (int j = 0; j < p.n; ++j) K[j] = h->h_K[(size_t)k * h->B + j];
+  if (feat)
+    for (int j = 0; j < p.n; ++j) {
+      int kk = 0;
+      if (urf_slot_to_host(slot_ptr(h, k, j), feat + (size_t)j * URF_FEAT_ROWS * URF_MAX_KEYPOINTS, URF_MAX_KEYPOINTS, &kk)) return -1;
+    }
+  *nframes = p.n;
+  h->pending.pop_front();
+  for (auto &q : h->pending)     // the matcher handle is free again: enqueue the batch that was waiting for it
+    if (!q.matched && q.batch % h->M == p.batch % h->M) return fe_enqueue_match(h, q);
+  return 0;
+}
+
+extern "C" int urf_fe_in_flight(urf_fe *h) { return h ? (int)h->pending.size() : 0; }
+extern "C" urf_sp *urf_fe_superpoint(urf_fe *h) { return h ? h->sp : nullptr; }
+extern "C" urf_pm *urf_fe_matcher(urf_fe *h, int i) { return (h && i >= 0 && i < h->M) ? h->pm[i] : nullptr; }

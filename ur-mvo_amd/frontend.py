@@ -316,7 +316,7 @@ class Camera:
         return cls(device=device, _maps=(map1, map2))
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:   # _lib is None at interpreter exit
             _lib.lib().urf_cam_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -344,6 +344,71 @@ class Camera:
 
     def sync(self):
         check(_lib.lib().urf_cam_sync(self._h), "urf_cam_sync")
+
+
+class FrameStream:
+    """Batched caller of the path (urf_fe_*, SURVEY section 8 f1): what Tracking::ExtractFeatureAndMatch
+    (src/tracking.cc:338-377) does per frame, for a stream of frames submitted in batches.
+
+        fs = FrameStream(SuperPointConfig(), SuperGlueConfig(), batch=8, max_height=480, max_width=640)
+        fs.build(sp_blob, sg_blob)
+        fs.submit(frames[0:8]); fs.submit(frames[8:16])
+        K, matches = fs.collect()          # batch 0: keypoint counts, one match array per frame
+    """
+
+    def __init__(self, sp_cfg, sg_cfg, batch=8, max_height=0, max_width=0, device=0, precision=0, matchers=2,
+                 history_batches=0, outlier_rejection=True, sinkhorn_iterations=100, ransac_iterations=200,
+                 ransac_sigma=1.0, ransac_seed=0):
+        c = _lib.FEConfig()
+        c.sp = SPConfig(sp_cfg.max_keypoints, sp_cfg.keypoint_threshold, sp_cfg.remove_borders, max_height, max_width,
+                        batch, device, precision)
+        c.sg = SGConfig(sg_cfg.image_width, sg_cfg.image_height, sg_cfg.matching_threshold, sinkhorn_iterations, batch,
+                        device, ransac_iterations, ransac_sigma, ransac_seed, precision)
+        c.batch, c.matchers, c.history_batches, c.outlier_rejection = batch, matchers, history_batches, int(outlier_rejection)
+        self.batch = batch
+        self._h = C.c_void_p()
+        self._cam = None
+        check(_lib.lib().urf_fe_create(C.byref(c), C.byref(self._h)), "urf_fe_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.lib().urf_fe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def build(self, sp_blob, sg_blob):
+        a = np.ascontiguousarray(sp_blob, np.float32)
+        b = np.ascontiguousarray(sg_blob, np.float32)
+        return _lib.lib().urf_fe_build(self._h, _p(a), C.c_size_t(a.size), _p(b), C.c_size_t(b.size)) == 0
+
+    def set_camera(self, camera):
+        self._cam = camera     # borrowed by the native handle: keep it alive
+        check(_lib.lib().urf_fe_set_camera(self._h, camera._h if camera is not None else None,
+                                           camera.height if camera is not None else 0,
+                                           camera.width if camera is not None else 0), "urf_fe_set_camera")
+
+    def submit(self, frames, ref=None):
+        """frames: [n, rows, cols] u8 (n <= batch); ref: None or n global frame indices (-1 = predecessor)"""
+        fr = np.ascontiguousarray(frames, np.uint8)
+        assert fr.ndim == 3
+        r = None if ref is None else np.ascontiguousarray(ref, np.int64)
+        check(_lib.lib().urf_fe_submit(self._h, _p(fr), fr.shape[0], fr.shape[1], fr.shape[2], C.c_size_t(fr.strides[1]),
+                                       C.c_size_t(fr.strides[0]), _p(r)), "urf_fe_submit")
+
+    def collect(self, want_features=False):
+        """-> (K[n], [match array per frame]) or (K, matches, [features [K_j, 259] per frame])"""
+        n = C.c_int(0)
+        K = np.zeros(self.batch, np.int32)
+        nm = np.zeros(self.batch, np.int32)
+        m = np.zeros((self.batch, CAP), MATCH_DTYPE)
+        feat = np.zeros((self.batch, CAP, 259), np.float64) if want_features else None
+        check(_lib.lib().urf_fe_collect(self._h, C.byref(n), _p(K), _p(m), CAP, _p(nm), _p(feat)), "urf_fe_collect")
+        out = [m[j, :nm[j]].copy() for j in range(n.value)]
+        if want_features:
+            return K[:n.value].copy(), out, [feat[j, :K[j]].copy() for j in range(n.value)]
+        return K[:n.value].copy(), out
+
+    def in_flight(self):
+        return _lib.lib().urf_fe_in_flight(self._h)
 
 
 def slot_to_host(d_slot_ptr):
