@@ -105,12 +105,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # URF_BENCH_FORCE_DIST=1: run the N>1 exchange path (RCCL all-gather on its own stream, ordered
+    # by events) in a process group of ONE rank -- the only way to execute that code on a 1-GPU box
+    force_dist = world == 1 and os.environ.get("URF_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    exchange = world > 1 or force_dist          # feature slots go through the all-gather
+    async_exchange = exchange and not shared_gpu
 
     U = load_pkg()
     F, synth, D = U.frontend, U.synth, U.dist
@@ -159,6 +165,13 @@ def main():
             assert pm_b.build(sgb), U._lib.lib().urf_last_error()
             pms.append(pm_b)
 
+    if async_exchange:
+        sp_ext = torch.cuda.ExternalStream(sp.stream_ptr(), device=dev)
+        pm_ext = [torch.cuda.ExternalStream(m.stream_ptr(), device=dev) for m in pms]
+        comm = torch.cuda.Stream(device=dev)
+        gathered_buf = torch.zeros((NB, world * BATCH, slot_floats), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+
     sp_calls = [0]   # number of SP calls enqueued so far (batch index of the latest = sp_calls-1)
 
     def sp_step(b):
@@ -168,7 +181,7 @@ def main():
 
     def slots_of(b):
         k = b % NB
-        return (ring[k], 0) if world == 1 else (gathered[k], rank * BATCH)
+        return (ring[k], 0) if not exchange else (gathered[k], rank * BATCH)
 
     def pm_step(b, matcher):
         """enqueue the matching of the pairs this rank owns in global batch b"""
@@ -210,9 +223,22 @@ def main():
     def one_step(b, record):
         """enqueue match(b) and SP(b+1); fetch the oldest finished batch"""
         mt = pms[b % len(pms)]
-        if world > 1:
-            sp.sync()                                               # SP(b) complete
-            gathered[b % NB] = D.all_gather_slots(ring[b % NB], world)   # RCCL over xGMI
+        if async_exchange:
+            # SP(b) -> all-gather(b) -> match(b) ordered by events, no host wait: the RCCL kernel runs
+            # on its own stream beside SuperPoint(b+1) and the other matcher
+            k = b % NB
+            ev_sp = torch.cuda.Event()
+            ev_sp.record(sp_ext)                                    # tail of the SuperPoint stream = SP(b)
+            comm.wait_event(ev_sp)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered_buf[k], ring[k])   # RCCL over xGMI
+                ev_ag = torch.cuda.Event()
+                ev_ag.record(comm)
+            pm_ext[b % len(pms)].wait_event(ev_ag)
+            gathered[k] = gathered_buf[k]
+        elif exchange:                                              # gloo test rig: host-staged, synchronous
+            sp.sync()
+            gathered[b % NB] = D.all_gather_slots(ring[b % NB], world)
             torch.cuda.synchronize()
         if OVERLAP:
             mt.wait_for_sp(sp)                  # match(b) needs SP(b)
@@ -272,7 +298,7 @@ def main():
         for b in range(bl, bl + 5):
             sp_step(b)
             sp.sync()
-            if world > 1:
+            if exchange:
                 gathered[b % NB] = ring[b % NB].repeat(world, 1)   # layout stand-in, no collective
             pms[0].wait_for_sp(sp) if OVERLAP else None
             pm_step(b, pms[0])
@@ -397,7 +423,7 @@ def main():
             "matches_per_step": round(float(np.mean(n_matches)), 1),
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

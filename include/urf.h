@@ -156,6 +156,9 @@ int urf_pm_share_stream(urf_pm *h, urf_sp *sp);
 int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp);
 int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h);
 void *urf_sp_stream(urf_sp *h);
+/* the handles' HIP streams (hipStream_t), for callers that order their own work (an RCCL
+ * all-gather of the slots, torch ops) against the library's with events instead of host syncs */
+void *urf_pm_stream(urf_pm *h);
 
 /* EpipolarGeometry::_find_F, src/epipolar_geometry.cc:161-205: 8-point RANSAC
  * on n pixel correspondences (host arrays of x,y pairs).  Returns 0;

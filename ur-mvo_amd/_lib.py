@@ -22,7 +22,7 @@ SYMBOLS = [
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
-    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher",
+    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.urf_fe_superpoint.restype = C.c_void_p
         L.urf_fe_matcher.restype = C.c_void_p
         L.urf_sp_stream.restype = C.c_void_p
+        L.urf_pm_stream.restype = C.c_void_p
         _lib = L
     return _lib
 

@@ -600,6 +600,7 @@ extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
 }
 
 extern "C" void *urf_pm_stream_(urf_pm *h) { return h && h->built ? (void *)h->st : nullptr; }
+extern "C" void *urf_pm_stream(urf_pm *h) { return urf_pm_stream_(h); }
 extern "C" int urf_pm_device_(urf_pm *h) { return h ? h->device : 0; }
 
 // Two-stream overlap (bench): SuperPoint of the NEXT batch is bandwidth/MFMA

@@ -73,6 +73,10 @@ class SuperPoint:
         self._built = rc == 0
         return self._built
 
+    def stream_ptr(self):
+        """the handle's hipStream_t (for torch.cuda.ExternalStream / event ordering)"""
+        return _lib.lib().urf_sp_stream(self._h)
+
     def infer(self, image, mask=None):
         """infer(image, mask, features) -> features [K,259] (or None on failure)."""
         image = np.asarray(image)
@@ -213,6 +217,9 @@ class PointMatching(_PM):
         n = check(_lib.lib().urf_match(self._h, _p(f0), f0.shape[0], _p(f1), f1.shape[0],
                                        int(bool(outlier_rejection)), out, CAP), "urf_match")
         return [(out[i].queryIdx, out[i].trainIdx, out[i].distance) for i in range(n)]
+
+    def stream_ptr(self):
+        return _lib.lib().urf_pm_stream(self._h)
 
     def match_device_async(self, slot_ptrs0, slot_ptrs1, outlier_rejection=True):
         P = len(slot_ptrs0)
