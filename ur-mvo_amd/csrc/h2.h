@@ -23,6 +23,9 @@ struct H2Args {
   _Float16 *ohT, *olT;
   int ldT;
   long outT_bstride;
+  // dual launch (LDS-DMA kernel): cout tiles below t_from take the normal epilogue (out/oh/ol), tiles from
+  // t_from on the transposed one with row index cout - t_from: Q|K and V^T of a GNN layer in ONE launch
+  int t_from;
 };
 // fast 3x3 convolution (h2conv.hip).  Activations: NHWC f16 planes [B][H][W][Cin].
 struct H2ConvArgs {

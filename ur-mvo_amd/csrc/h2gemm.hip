@@ -43,7 +43,7 @@ __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2],
           if (tok + q >= a.rows) v = 0.0f;
           h[q] = (_Float16)v; l[q] = (_Float16)(v - (float)h[q]);
         }
-        const size_t off = (size_t)b * a.outT_bstride + (size_t)co * a.ldT + tok;
+        const size_t off = (size_t)b * a.outT_bstride + (size_t)(co - a.t_from) * a.ldT + tok;
         *(f16x4 *)(a.ohT + off) = h;
         *(f16x4 *)(a.olT + off) = l;
       }
@@ -110,8 +110,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr int GP = 128 * BK;   // halfs per plane per stage (128 rows x 32)
 
 template <bool TOUT>
-__global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
-  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];   // [stage][Ah | Al | Bh | Bl][128][32]
+__device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
@@ -181,6 +180,16 @@ __global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
       }
   }
   h2_epilogue<TOUT>(a, acc, b, cout_base, row0, wc, wr, px, g);
+}
+
+// MODE 0: token-major outputs, 1: transposed outputs, 2: both in one launch (uniform branch per workgroup)
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];   // [stage][Ah | Al | Bh | Bl][128][32]
+  if (MODE == 0) h2gemm_glds_body<false>(a, hsm);
+  else if (MODE == 1) h2gemm_glds_body<true>(a, hsm);
+  else if ((int)blockIdx.y * 128 >= a.t_from) h2gemm_glds_body<true>(a, hsm);
+  else h2gemm_glds_body<false>(a, hsm);
 }
 
 template <bool TOUT, int WC, int WR>
@@ -306,6 +315,7 @@ int g_h2gemm_variant = -1;  // probe override: 0 = register-staged 128x128, 1 = 
 
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0, "h2gemm: unsupported shape %d x %d", a.Cout, a.Cin);
+
   // measured (tools/gpu_h2probe.py, 16384 rows): LDS-DMA 128x128 174-276 TFLOP/s logical > register-staged 128x128
   // 155-251 > register-staged 64x128 140-193 at every shape of the path
   if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
@@ -313,17 +323,21 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
   }
   const int variant = g_h2gemm_variant;
+  URF_CHECK(a.t_from == 0 || (variant == 2 && (a.t_from % 128) == 0 && a.ohT),
+            "h2gemm: the dual epilogue needs the LDS-DMA kernel and a 128-aligned split");
   if (variant == 2) {
     const size_t lds = sizeof(_Float16) * 2 * 4 * GP;   // 64 KiB: two stages of four planes
     dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
     static bool attr_set = false;
     if (!attr_set) {
-      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((h2gemm_glds_kernel<false>), grid, dim3(512), lds, st, a);
+    if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, a);
+    else if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<1>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((h2gemm_glds_kernel<0>), grid, dim3(512), lds, st, a);
     URF_HIP(hipGetLastError());
     return 0;
   }

@@ -323,13 +323,18 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
   hipStream_t st = h->st;
   if (launch_split(h->x, (size_t)NI * NP * 256, h->xh, h->xl, st)) return -1;
   for (int l = 0; l < SG_LAYERS; ++l) {
-    // Q | K (token-major) and V^T ([d][token]) projections
-    if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->H[l].qk, h->L[l].bqkv, 512, nullptr, h->qkh,
-                  h->qkl, 512, false, nullptr, false))
-      return -1;
-    if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->H[l].v, h->L[l].bqkv + 512, 256, nullptr,
-                  h->vth, h->vtl, 0, false, nullptr, true))
-      return -1;
+    // Q | K (token-major) and V^T ([d][token]) projections: ONE launch over the fused [768][256] weight
+    // (x is read once; a second launch costs ~9 us of fixed time)
+    {
+      H2Args a = {};
+      a.xh = h->xh; a.xl = h->xl; a.ldx = 256; a.x_bstride = (long)NP * 256;
+      a.rows = NP; a.Cin = 256;
+      a.wh = h->d_wh + h->H[l].qk; a.wl = h->d_wl + h->H[l].qk; a.bias = h->d_w + h->L[l].bqkv; a.Cout = 768;
+      a.counts = h->counts;
+      a.oh = h->qkh; a.ol = h->qkl; a.ld_out = 512; a.out_bstride = (long)NP * 512;
+      a.ohT = h->vth; a.olT = h->vtl; a.ldT = NP; a.outT_bstride = (long)256 * NP; a.t_from = 512;
+      if (launch_h2gemm(a, NI, st)) return -1;
+    }
     if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
     if (launch_attn_h2(h->qkh, h->qkl, h->vth, h->vtl, h->counts, l & 1, h->oh, h->ol, NI, st)) return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
