@@ -33,6 +33,7 @@ MAX_KP = 1000
 GF_CONV1 = 22.649 + 0.354          # conv1b + fused conv1a
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 F16_MFMA_PEAK_TF = 2500.0          # dense f16/bf16 MFMA peak (v_mfma_f32_16x16x32_f16)
+HBM_PEAK_GBS = 8000.0              # HBM3E peak (MI355X_MICROARCH.md)
 
 
 def sg_linear_gflop(n0, n1):
@@ -40,6 +41,21 @@ def sg_linear_gflop(n0, n1):
     per_pt += 18 * 2 * (3 * 256 * 256 + 256 * 256 + 512 * 512 + 512 * 256)      # qkv, merge, mlp
     per_pt += 2 * 256 * 256                                                      # final proj
     return per_pt * (n0 + n1) / 1e9
+
+
+def sg_linear_gbytes(n0, n1, fast):
+    """algorithmic HBM-side bytes of the linear layers of one pair: every activation tensor read or
+    written once at 4 B per element (fp32, or two f16 planes in the fast mode), weights once per step
+    (counted by the caller).  Per GNN layer and keypoint: qkv 256 in + 768 out, merge 256 + 256,
+    mlp0 512 + 512, mlp1 512 in + 256 residual + 256 out (+ 256 plane copy of x in the fast mode)."""
+    per_pt = 18 * (1024 + 512 + 1024 + 1024 + (256 if fast else 0))
+    per_pt += (4 + 32) + (32 + 64) + (64 + 128) + (128 + 256) + (256 + 256 + 256) + (256 + 256)   # kenc, final proj
+    return 4.0 * per_pt * (n0 + n1) / 1e9
+
+
+def sg_attn_gbytes(n0, n1):
+    """q, k, v in and the message out, once each, 256 channels x 4 B, 18 layers"""
+    return 18 * 4 * 256 * 4.0 * (n0 + n1) / 1e9
 
 
 def sg_attn_gflop(n0, n1):
@@ -313,31 +329,49 @@ def main():
         kp = [int(F.slot_to_host(ring[0][j].data_ptr()).shape[0]) for j in range(BATCH)]
         n_avg = float(np.mean(kp))
         # ---- roofline of the dominant kernel (largest summed device time per step)
-        per_step = {
+        SG_WEIGHT_GB = 12003905 * 4 / 1e9                     # streamed once per step by the linear layers
+        Hc_, Wc_ = H // 2, W // 2
+        conv1_gb = BATCH * (H * W + Hc_ * Wc_ * 64 * 4) / 1e9   # u8 frame in, pooled 64-channel map out (4 B/element)
+        per_step = {   # name: (ms, GFLOP, GB) per step
             ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if PREC else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
-                (np.mean(conv1_ms), GF_CONV1 * BATCH),
-            ("SuperGlue linear layers (h2gemm_kernel)" if PREC else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
-                (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH),
+                (np.mean(conv1_ms), GF_CONV1 * BATCH, conv1_gb),
+            ("SuperGlue linear layers (h2gemm_glds_kernel)" if PREC else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
+                (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH,
+                 sg_linear_gbytes(n_avg, n_avg, PREC == 1) * BATCH + SG_WEIGHT_GB),
             ("SuperGlue attention (attn_h2_kernel)" if PREC else "SuperGlue attention (attn_kernel)"):
-                (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH),
+                (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH, sg_attn_gbytes(n_avg, n_avg) * BATCH),
         }
         dom = max(per_step, key=lambda k: per_step[k][0])
-        ms, gf = per_step[dom]
-        achieved = gf / ms  # GFLOP / ms = TFLOP/s
-        # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); `achieved` counts the
-        # ALGORITHMIC flops once, so frac <= 1/3 by construction against the dense f16 peak
-        peak = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
+        ms, gf, gb = per_step[dom]
+        # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); the MFMA roof is priced on the
+        # ALGORITHMIC flops (counted once), so its fraction is <= 1/3 by construction
+        peak_tf = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
+        issue = 3 if PREC == 1 else 1
+
+        def roofs(ms_, gf_, gb_):
+            t_mfma, t_hbm = gf_ * issue / peak_tf, gb_ / HBM_PEAK_GBS * 1e3      # ms at each roof
+            return ("hbm" if t_hbm > t_mfma else "mfma"), t_mfma, t_hbm
+
+        bound, t_mfma, t_hbm = roofs(ms, gf, gb)      # the binding roof = the one with the larger minimum time
         traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+        if bound == "hbm":
+            achieved, peak, unit = gb / ms * 1e3, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = gf / ms, peak_tf, "TFLOP/s"
+        roofline = {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_note": traffic_src,
-                    "mfma_issue_frac": round(achieved * (3 if PREC == 1 else 1) / peak, 4),
+                    "why_this_bound": f"minimum time at the HBM roof {t_hbm:.3f} ms vs at the MFMA roof {t_mfma:.3f} ms "
+                                      f"(algorithmic {gb:.2f} GB and {gf:.1f} GFLOP x{issue} MFMA per step)",
+                    "tflops_logical": round(gf / ms, 2), "mfma_issue_frac": round(gf * issue / ms / peak_tf, 4),
                     "launch_ms": round(float(ms), 4), "algorithmic_gflop_per_step": round(gf, 2),
+                    "algorithmic_gbytes_per_step": round(gb, 3),
                     "measured": "HIP events on the library stream, serialised 5-step pass right after the timed region "
                                 "(the timed region overlaps 3 streams; rocprofv3 --kernel-trace serialises as well)",
                     "in_timed_region_ms_per_step": {k: (round(v, 3) if v is not None else None) for k, v in insitu.items()},
-                    "all_kernels_tflops": {k: round(v[1] / v[0], 2) for k, v in per_step.items()},
-                    "all_kernels_ms_per_step": {k: round(float(v[0]), 3) for k, v in per_step.items()}}
+                    "all_kernels": {k: {"ms_per_step": round(float(v[0]), 3), "tflops_logical": round(v[1] / v[0], 2),
+                                        "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(*v)[0]}
+                                    for k, v in per_step.items()}}
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
         exact = None
