@@ -502,3 +502,44 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
     assert _as_tuples(fs.collect()[1][3]) == pm.MatchingPoints(feats[9], feats[3], True)
+
+
+# ------------------------------------------------------------------ error behaviour of the boundary
+def test_c_abi_errors_are_negative_codes_with_text_and_leave_outputs_untouched(U, F, sp_blob, sg_blob, pm):
+    """reference contract: bool/count returns, no exceptions, outputs untouched on failure
+    (src/tracking.cc:328-331,346-350)"""
+    import ctypes as C
+    L = U._lib.lib()
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=100), max_height=64, max_width=64)
+    assert not sp.build(sp_blob[:-1]) and b"blob" in L.urf_last_error().lower()        # wrong container size
+    assert sp.infer(np.zeros((32, 32), np.uint8)) is None                                 # not built
+    assert sp.build(sp_blob)
+    feat = np.full((8, 259), 7.0)
+    K = C.c_int(-5)
+    img = np.zeros((128, 128), np.uint8)
+    rc = L.urf_sp_infer(sp._h, img.ctypes.data_as(C.c_void_p), 128, 128, C.c_size_t(128), None, C.c_size_t(0),
+                        feat.ctypes.data_as(C.c_void_p), 8, C.byref(K))
+    assert rc < 0 and K.value == -5 and (feat == 7.0).all()                               # larger than the arena
+    assert len(L.urf_last_error()) > 0
+    ok = np.zeros((64, 64), np.uint8); ok[20:40, 20:40] = 255
+    assert sp.infer(ok) is not None                                                       # the handle survives
+    # a frame with more keypoints than the caller's buffer: error, buffer untouched
+    big = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=120, max_width=160)
+    assert big.build(sp_blob)
+    tex = U.synth.base_frame(3, 120, 160)
+    n = big.infer(tex).shape[0]
+    assert n > 8
+    rc = L.urf_sp_infer(big._h, tex.ctypes.data_as(C.c_void_p), 120, 160, C.c_size_t(160), None, C.c_size_t(0),
+                        feat.ctypes.data_as(C.c_void_p), 8, C.byref(K))
+    assert rc < 0 and (feat == 7.0).all()
+    # matcher: more than 1024 keypoints, zero keypoints, cap too small
+    rng = np.random.default_rng(1)
+    f0, f1 = make_features(rng, 50), make_features(rng, 60)
+    out = (U._lib.DMatch * 4)()
+    assert L.urf_match(pm._h, np.zeros((1025, 259)).ctypes.data_as(C.c_void_p), 1025, f1.ctypes.data_as(C.c_void_p), 60,
+                       0, out, 4) < 0
+    assert pm.MatchingPoints(np.zeros((0, 259)), f1, True) == []                          # nothing to match is not an error
+    m = pm.MatchingPoints(f0, f0, False)
+    assert len(m) > 4
+    assert L.urf_match(pm._h, f0.ctypes.data_as(C.c_void_p), 50, f0.ctypes.data_as(C.c_void_p), 50, 0, out, 4) < 0
+    assert b"cap" in L.urf_last_error()
