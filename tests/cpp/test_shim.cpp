@@ -4,6 +4,8 @@
 // compare with the ctypes path.  Usage: test_shim sp.urfw sg.urfw f0.raw f1.raw H W
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "epipolar_geometry.h"
@@ -33,9 +35,23 @@ int main(int argc, char **argv) {
   auto b0 = read_file(argv[3], (size_t)H * W), b1 = read_file(argv[4], (size_t)H * W);
   cv::Mat image0(H, W, 0, b0.data()), image1(H, W, 0, b1.data()), mask;
   Eigen::Matrix<double, 259, Eigen::Dynamic> features0, features1;
-  if (!superpoint->infer(image0, mask, features0) || !superpoint->infer(image1, mask, features1)) return 1;
+  // every call of the reference comes from a FRESH std::thread (src/tracking.cc:334-335, 364-366): the
+  // handles keep no thread-local state and bind their HIP device on entry
+  bool ok0 = false, ok1 = false;
+  std::function<void()> extract_point = [&]() { ok0 = superpoint->infer(image0, mask, features0); };   // ExtractFeatrue
+  std::thread t0(extract_point);
+  t0.join();
   std::vector<cv::DMatch> matches;
-  const int n = point_matching->MatchingPoints(features0, features1, matches, true);                   // tracking.cc:354
+  int n = -1;
+  std::function<void()> extract_point_and_match = [&]() {                                              // ExtractFeatureAndMatch
+    ok1 = superpoint->infer(image1, mask, features1);
+    if (!ok1) return;
+    matches.clear();
+    n = point_matching->MatchingPoints(features0, features1, matches, true);                           // tracking.cc:354
+  };
+  std::thread t1(extract_point_and_match);
+  t1.join();
+  if (!ok0 || !ok1) return 1;
   printf("K0=%ld K1=%ld matches=%d\n", (long)features0.cols(), (long)features1.cols(), n);
   for (int i = 0; i < n; ++i) printf("%d %d %.9g\n", matches[i].queryIdx, matches[i].trainIdx, matches[i].distance);
   // EpipolarGeometry compiles against the same handle (mono init, src/tracking.cc:52-55,559)

@@ -98,7 +98,7 @@ def test_cpp_shim_headers_compile_and_link(tmp_path):
     exe = str(tmp_path / "test_shim")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front",
+                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front", "-pthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "ur-mvo_amd")])
     assert os.path.exists(exe)
 

@@ -258,7 +258,7 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     exe = str(tmp_path / "test_shim")
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front",
+                           "-L" + os.path.join(ROOT, "ur-mvo_amd"), "-lurf_front", "-pthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "ur-mvo_amd")])
     L = U._lib.lib()
     spw, sgw = str(tmp_path / "sp.urfw"), str(tmp_path / "sg.urfw")
