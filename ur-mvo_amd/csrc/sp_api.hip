@@ -63,6 +63,8 @@ struct urf_sp {
   int precision = 0;
   _Float16 *d_wh = nullptr, *d_wl = nullptr;
   size_t hw_off[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, Pa||Da
+  size_t hpb_off = 0, hdb_off = 0;   // fast mode 1x1 heads: convPb [128 (65 used)][256], convDb [256][256] planes
+  size_t bpb128_off = 0;             // convPb bias padded to 128
   // activations
   float *a1 = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
         *a4b = nullptr, *apd = nullptr, *logits = nullptr, *ddb = nullptr, *desc = nullptr;
@@ -172,6 +174,10 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     h->bpb_off = put(nullptr, 68);
     memcpy(host.data() + h->bpb_off, src_b[9], 65 * sizeof(float));
   }
+  {  // the fast mode's convPb runs as a 128-wide split-f16 GEMM: bias padded with zeros
+    h->bpb128_off = put(nullptr, 128);
+    memcpy(host.data() + h->bpb128_off, src_b[9], 65 * sizeof(float));
+  }
   {  // u8 -> f32 : float(u8) / 255.0 in double, narrowed (src/super_point.cpp:171-172)
     h->lut_off = put(nullptr, 256);
     for (int v = 0; v < 256; ++v) host[h->lut_off + v] = (float)((double)(float)v / 255.0);
@@ -208,6 +214,21 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
       putc(src_w[10], 128, 256, 256, 512, base);
       h->hw_off[7] = base;
     }
+    auto put1x1 = [&](const float *w, int cin, int cout, int cpad) {   // w: [cin][cout] fp32 -> planes [cpad][cin]
+      const size_t base = wh.size();
+      wh.resize(base + (size_t)cpad * cin, (_Float16)0.0f);
+      wl.resize(wh.size(), (_Float16)0.0f);
+      for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+          const float v = w[(size_t)c * cout + o];
+          const _Float16 hi = (_Float16)v;
+          wh[base + (size_t)o * cin + c] = hi;
+          wl[base + (size_t)o * cin + c] = (_Float16)(v - (float)hi);
+        }
+      return base;
+    };
+    h->hpb_off = put1x1(src_w[9], 256, 65, 128);
+    h->hdb_off = put1x1(src_w[11], 256, 256, 256);
     URF_HIP(hipMalloc((void **)&h->d_wh, wh.size() * 2));
     URF_HIP(hipMalloc((void **)&h->d_wl, wl.size() * 2));
     URF_HIP(hipMemcpy(h->d_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
@@ -227,7 +248,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->a4a, B * H8 * W8 * 128)) return -1;
   if (dalloc(&h->a4b, B * H8 * W8 * 128)) return -1;
   if (dalloc(&h->apd, B * H8 * W8 * 512)) return -1;
-  if (dalloc(&h->logits, B * H8 * W8 * 68)) return -1;
+  if (dalloc(&h->logits, B * H8 * W8 * (h->precision == 1 ? 128 : 68))) return -1;
   if (dalloc(&h->ddb, B * H8 * W8 * 256)) return -1;
   if (dalloc(&h->desc, B * H8 * W8 * 256)) return -1;
   if (dalloc(&h->heat, B * Hs * Ws)) return -1;
@@ -357,7 +378,7 @@ static int sp_convs_fast(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W) 
   mark(ST_CONV4B);
   if (conv(h->a4a, 128, H8, W8, 6, wt + h->b_off[7], 128, h->a4b, false, false)) return -1;
   mark(ST_PADA);
-  if (conv(h->a4b, 128, H8, W8, 7, wt + h->bpd_off, 512, h->apd, false, true)) return -1;
+  if (conv(h->a4b, 128, H8, W8, 7, wt + h->bpd_off, 512, h->apd, false, false)) return -1;   // planes [cells][512]
   return 0;
 }
 
@@ -408,6 +429,28 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   if (conv3(h->a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, h->apd, false)) return -1;
   }
   const int ncell = H8 * W8;
+  int logit_ld = 68;
+  if (h->precision == 1) {
+    // the two 1x1 heads as split-f16 GEMMs on the planes of Pa || Da ([cells][512]: hi plane, then lo plane)
+    const _Float16 *ph = (const _Float16 *)h->apd, *pl = ph + (size_t)B * ncell * 512;
+    logit_ld = 128;
+    mark(ST_PB);
+    {
+      urf::H2Args a = {};
+      a.xh = ph; a.xl = pl; a.ldx = 512; a.x_bstride = (long)ncell * 512; a.rows = ncell; a.Cin = 256;
+      a.wh = h->d_wh + h->hpb_off; a.wl = h->d_wl + h->hpb_off; a.bias = wt + h->bpb128_off; a.Cout = 128;
+      a.out = h->logits; a.ld_out = 128; a.out_bstride = (long)ncell * 128;
+      if (urf::launch_h2gemm(a, B, st)) return -1;
+    }
+    mark(ST_DB);
+    {
+      urf::H2Args a = {};
+      a.xh = ph + 256; a.xl = pl + 256; a.ldx = 512; a.x_bstride = (long)ncell * 512; a.rows = ncell; a.Cin = 256;
+      a.wh = h->d_wh + h->hdb_off; a.wl = h->d_wl + h->hdb_off; a.bias = wt + h->b_off[11]; a.Cout = 256;
+      a.out = h->ddb; a.ld_out = 256; a.out_bstride = (long)ncell * 256;
+      if (urf::launch_h2gemm(a, B, st)) return -1;
+    }
+  } else {
   mark(ST_PB);
   {  // convPb 1x1 on channels [0,256) of apd -> logits (68-wide rows)
     ConvArgs a = {};
@@ -424,8 +467,9 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
     a.out = h->ddb; a.out_ld = 256; a.out_bstride = (long)ncell * 256; a.relu = 0;
     if (launch_conv(a, 1, false, false, B, st)) return -1;
   }
+  }
   mark(ST_SOFTMAX);
-  if (launch_softmax(h->logits, 68, H8, W8, h->heat, B, st)) return -1;
+  if (launch_softmax(h->logits, logit_ld, H8, W8, h->heat, B, st)) return -1;
   mark(ST_NMS);
   if (launch_nms(h->heat, h->mask, h->supp, h->ss, h->scores, Hs, Ws, B, st)) return -1;
   mark(ST_SELECT);
