@@ -49,7 +49,7 @@ struct urf_pm {
   bool built = false;
   float *d_w = nullptr;
   size_t kw[5], kb[5];
-  struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2; } L[18];
+  struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2, b1f; } L[18];
   size_t wf, bf;
   float bin_score = 1.0f;
   // fast precision mode (split-f16 MFMA): transposed weights as hi/lo f16 planes
@@ -157,6 +157,17 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     h->L[l].wm = put(wm, 65536); h->L[l].bm = put(bm, 256);
     h->L[l].w1 = put(w1, 262144); h->L[l].b1 = put(b1, 512);
     h->L[l].w2 = put(w2, 131072); h->L[l].b2 = put(b2, 256);
+    if (h->precision == 1) {
+      // fast mode folds the merge layer into the first MLP layer (both linear, nothing in between):
+      //   W0 [x ; Wm o + bm] + b0 = W0x x + (W0m Wm) o + (b0 + W0m bm)
+      h->L[l].b1f = put(nullptr, 512);
+      float *bf = host.data() + h->L[l].b1f;
+      for (int o = 0; o < 512; ++o) {
+        double acc = b1[o];
+        for (int j = 0; j < 256; ++j) acc += (double)w1[(size_t)(256 + j) * 512 + o] * (double)bm[j];
+        bf[o] = (float)acc;
+      }
+    }
   }
   h->wf = put(p, 65536); p += 65536;
   h->bf = put(p, 256); p += 256;
@@ -190,7 +201,31 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       putT(wk, 256, 256);                 // rows 256..511 of the fused [512][256] matrix
       h->H[l].v = putT(wv, 256, 256);
       h->H[l].m = putT(wm, 256, 256);
-      h->H[l].w1 = putT(w1, 512, 512);
+      {  // first MLP layer with the merge layer folded in: input = [x (256) ; attention output o (256, head-major)]
+        std::vector<double> wc((size_t)512 * 512);   // [cin][cout]
+        for (int c = 0; c < 256; ++c)
+          for (int o = 0; o < 512; ++o) wc[(size_t)c * 512 + o] = w1[(size_t)c * 512 + o];
+        for (int c = 0; c < 256; ++c) {              // W'[o][c] = sum_j W0[o][256 + j] Wm[j][c]
+          double *dst = wc.data() + (size_t)(256 + c) * 512;
+          for (int o = 0; o < 512; ++o) dst[o] = 0.0;
+          for (int j = 0; j < 256; ++j) {
+            const double m = wm[(size_t)c * 256 + j];
+            const float *row = w1 + (size_t)(256 + j) * 512;
+            for (int o = 0; o < 512; ++o) dst[o] += (double)row[o] * m;
+          }
+        }
+        const size_t off = wh.size();
+        wh.resize(off + (size_t)512 * 512);
+        wl.resize(off + (size_t)512 * 512);
+        for (int o = 0; o < 512; ++o)
+          for (int c = 0; c < 512; ++c) {
+            const double v = wc[(size_t)c * 512 + o];
+            const _Float16 hi = (_Float16)v;
+            wh[off + (size_t)o * 512 + c] = hi;
+            wl[off + (size_t)o * 512 + c] = (_Float16)(v - (double)hi);
+          }
+        h->H[l].w1 = off;
+      }
       h->H[l].w2 = putT(w2, 512, 256);
     }
     h->hwf = putT(q, 256, 256);
@@ -338,10 +373,8 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
     if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
     if (launch_attn_h2(h->qkh, h->qkl, h->vth, h->vtl, h->counts, l & 1, h->oh, h->ol, NI, st)) return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
-    if (h2_linear(h, NI, h->oh, h->ol, 256, 256, nullptr, nullptr, 0, 0, h->H[l].m, h->L[l].bm, 256, nullptr, h->mh, h->ml,
-                  256, false, nullptr, false))
-      return -1;
-    if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->mh, h->ml, 256, 256, h->H[l].w1, h->L[l].b1, 512, nullptr, h->hh,
+    // merge + first MLP layer in one GEMM over [x ; o] (weights folded at build())
+    if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->oh, h->ol, 256, 256, h->H[l].w1, h->L[l].b1f, 512, nullptr, h->hh,
                   h->hl, 512, true, nullptr, false))
       return -1;
     if (h2_linear(h, NI, h->hh, h->hl, 512, 512, nullptr, nullptr, 0, 0, h->H[l].w2, h->L[l].b2, 256, h->x, h->xh, h->xl,
