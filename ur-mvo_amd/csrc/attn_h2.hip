@@ -9,6 +9,7 @@
 #include "h2.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace urf {
 
@@ -27,131 +28,165 @@ constexpr int VS = 72;       // V^T rows: 144 B, conflict-free ds_read_b64
 // Workgroup = 512 threads = 8 query tiles (128 queries) x 1 head; K chunk
 // [64 keys][64 d] and V^T chunk [64 d][64 keys] (hi/lo planes) double-buffered in
 // LDS and shared by the 8 waves.
-__global__ void __launch_bounds__(512, 4) attn_h2_kernel(const _Float16 *qkh, const _Float16 *qkl,
-                                                         const _Float16 *vth, const _Float16 *vtl, const int *counts,
-                                                         int cross, _Float16 *oh, _Float16 *ol) {
+// QT query tiles (16 queries each) per wave, NW waves per workgroup: every K / V^T fragment read from
+// LDS feeds QT MFMAs instead of one.
+template <int QT, int NW>
+__global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, const _Float16 *qkl,
+                                                          const _Float16 *vth, const _Float16 *vtl, const int *counts,
+                                                          int cross, _Float16 *oh, _Float16 *ol) {
+  constexpr int NT = 64 * NW, QB = 16 * QT * NW;   // threads, queries per workgroup
+  constexpr int NV = 512 / NT;                     // staging roles per thread (512 = 2 tensors x 2 planes x 16 rows x 8 pieces)
   // [buffer][K planes | V planes]
   __shared__ __attribute__((aligned(16))) _Float16 kbuf[2][2][64 * AS];
   __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][64 * VS];
   int qb, grp;
-  xcd_group_map(blockIdx.x, ANP / 128, (int)gridDim.x / (ANP / 128), qb, grp);   // the 8 query tiles of a head on one XCD
+  xcd_group_map(blockIdx.x, ANP / QB, (int)gridDim.x / (ANP / QB), qb, grp);   // the query tiles of a head on one XCD
   const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
   const int head = grp & 3;
   const int nq = counts[im], ns = counts[sm];
-  const int q0 = qb * 128;
+  const int q0 = qb * QB;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int nchunk = (ns + 63) >> 6;
 
-  // staging: thread -> (tensor sk: 0 = K, 1 = V^T; plane sp; row sr (+32u); 16-byte piece sj)
-  const int sk = tid >> 8, sp = (tid >> 7) & 1, st = tid & 127;
-  const int sj = st & 7, sr = st >> 3;
-  f16x8 pf[4];
+  // staging: virtual thread vt -> (tensor sk: 0 = K, 1 = V^T; plane sp; row sr (+16u); 16-byte piece sj)
+  f16x8 pf[NV][4];
   auto issue = [&](int ch) {
-    if (sk == 0) {
-      const _Float16 *base = (sp ? qkl : qkh) + ((size_t)sm * ANP) * 512 + 256 + head * 64;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int key = ch * 64 + sr + 16 * u;
-        pf[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < ns) pf[u] = *(const f16x8 *)(base + (size_t)key * 512 + 8 * sj);
-      }
-    } else {
-      const _Float16 *base = (sp ? vtl : vth) + ((size_t)sm * 256 + head * 64) * ANP;
+    for (int v = 0; v < NV; ++v) {
+      const int vt = tid + NT * v;
+      const int sk = vt >> 8, sp = (vt >> 7) & 1, st = vt & 127;
+      const int sj = st & 7, sr = st >> 3;
+      if (sk == 0) {
+        const _Float16 *base = (sp ? qkl : qkh) + ((size_t)sm * ANP) * 512 + 256 + head * 64;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int d = sr + 16 * u;
-        const int key0 = ch * 64 + 8 * sj;
-        f16x8 v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (key0 < ns) {
-          v = *(const f16x8 *)(base + (size_t)d * ANP + key0);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (key0 + e >= ns) v[e] = (_Float16)0.0f;   // stale tokens beyond the count
+        for (int u = 0; u < 4; ++u) {
+          const int key = ch * 64 + sr + 16 * u;
+          pf[v][u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (key < ns) pf[v][u] = *(const f16x8 *)(base + (size_t)key * 512 + 8 * sj);
         }
-        pf[u] = v;
+      } else {
+        const _Float16 *base = (sp ? vtl : vth) + ((size_t)sm * 256 + head * 64) * ANP;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = sr + 16 * u;
+          const int key0 = ch * 64 + 8 * sj;
+          f16x8 x = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (key0 < ns) {
+            x = *(const f16x8 *)(base + (size_t)d * ANP + key0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (key0 + e >= ns) x[e] = (_Float16)0.0f;   // stale tokens beyond the count
+          }
+          pf[v][u] = x;
+        }
       }
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (sk == 0) *(f16x8 *)(kbuf[buf][sp] + (sr + 16 * u) * AS + 8 * sj) = pf[u];
-      else *(f16x8 *)(vbuf[buf][sp] + (sr + 16 * u) * VS + 8 * sj) = pf[u];
+    for (int v = 0; v < NV; ++v) {
+      const int vt = tid + NT * v;
+      const int sk = vt >> 8, sp = (vt >> 7) & 1, st = vt & 127;
+      const int sj = st & 7, sr = st >> 3;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (sk == 0) *(f16x8 *)(kbuf[buf][sp] + (sr + 16 * u) * AS + 8 * sj) = pf[v][u];
+        else *(f16x8 *)(vbuf[buf][sp] + (sr + 16 * u) * VS + 8 * sj) = pf[v][u];
+      }
     }
   };
 
   issue(0);
-  f16x8 qh[2], ql[2];
-  {
-    const size_t qo = ((size_t)im * ANP + q0 + wave * 16 + px) * 512 + head * 64 + 8 * g;
+  f16x8 qh[QT][2], ql[QT][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const size_t qo = ((size_t)im * ANP + q0 + (wave * QT + t) * 16 + px) * 512 + head * 64 + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qh[ks] = *(const f16x8 *)(qkh + qo + 32 * ks);
-      ql[ks] = *(const f16x8 *)(qkl + qo + 32 * ks);
+      qh[t][ks] = *(const f16x8 *)(qkh + qo + 32 * ks);
+      ql[t][ks] = *(const f16x8 *)(qkl + qo + 32 * ks);
     }
   }
   commit(0);
   __syncthreads();
 
-  float m = -FLT_MAX, part = 0.0f;
-  f32x4 oacc[4];
+  float m[QT], part[QT];
+  f32x4 oacc[QT][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -FLT_MAX; part[t] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
 
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) issue(ch + 1);
     // ---- S^T = K Q^T for the 64 keys of this chunk
-    f32x4 s[4];
+    f32x4 s[QT][4];
     const _Float16 *kph = kbuf[buf][0] + px * AS + 8 * g;
     const _Float16 *kpl = kbuf[buf][1] + px * AS + 8 * g;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 acc[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const f16x8 ah = *(const f16x8 *)(kph + kt * 16 * AS + 32 * ks);
         const f16x8 al = *(const f16x8 *)(kpl + kt * 16 * AS + 32 * ks);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t][ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[t][ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t][ks], acc[t], 0, 0, 0);
+        }
       }
       const int kb0 = ch * 64 + kt * 16 + 4 * g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = (kb0 + r < ns) ? acc[r] * 0.125f : -FLT_MAX;
-      s[kt] = acc;
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = (kb0 + r < ns) ? acc[t][r] * 0.125f : -FLT_MAX;
+        s[t][kt] = acc[t];
+      }
     }
     // ---- online softmax update (per query = per px; the 4 lanes g share it)
-    float cm = -FLT_MAX;
+    float mn[QT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int t = 0; t < QT; ++t) {
+      float cm = -FLT_MAX;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cm = fmaxf(cm, s[kt][r]);
-    cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-    cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-    const float mn = fmaxf(m, cm);
-    const float alpha = __expf(m - mn);
-    m = mn;
-    part = part * alpha;
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+        for (int r = 0; r < 4; ++r) cm = fmaxf(cm, s[t][kt][r]);
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      mn[t] = fmaxf(m[t], cm);
+      const float alpha = __expf(m[t] - mn[t]);
+      m[t] = mn[t];
+      part[t] = part[t] * alpha;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[dt][r] = oacc[dt][r] * alpha;
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[t][dt][r] = oacc[t][dt][r] * alpha;
+    }
     // ---- O^T += V^T P^T, 32 keys per k-step
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
-      f16x8 ph, pl;
+      f16x8 ph[QT], pl[QT];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float sv = s[2 * kp + (e >> 2)][e & 3];
-        const float p = (sv == -FLT_MAX) ? 0.0f : __expf(sv - mn);
-        part = part + p;
-        const _Float16 h = (_Float16)p;
-        ph[e] = h;
-        pl[e] = (_Float16)(p - (float)h);
-      }
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sv = s[t][2 * kp + (e >> 2)][e & 3];
+          const float p = (sv == -FLT_MAX) ? 0.0f : __expf(sv - mn[t]);
+          part[t] = part[t] + p;
+          const _Float16 h = (_Float16)p;
+          ph[t][e] = h;
+          pl[t][e] = (_Float16)(p - (float)h);
+        }
       const _Float16 *vph = vbuf[buf][0] + px * VS + (2 * kp) * 16 + 4 * g;
       const _Float16 *vpl = vbuf[buf][1] + px * VS + (2 * kp) * 16 + 4 * g;
 #pragma unroll
@@ -161,37 +196,61 @@ __global__ void __launch_bounds__(512, 4) attn_h2_kernel(const _Float16 *qkh, co
         const f16x4 b0 = *(const f16x4 *)(vpl + dt * 16 * VS), b1 = *(const f16x4 *)(vpl + dt * 16 * VS + 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ah[e] = a0[e]; ah[4 + e] = a1[e]; al[e] = b0[e]; al[4 + e] = b1[e]; }
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph, oacc[dt], 0, 0, 0);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pl, oacc[dt], 0, 0, 0);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ph, oacc[dt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[t], oacc[t][dt], 0, 0, 0);
+          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pl[t], oacc[t][dt], 0, 0, 0);
+          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ph[t], oacc[t][dt], 0, 0, 0);
+        }
       }
     }
     if (ch + 1 < nchunk) commit(buf ^ 1);
     __syncthreads();
   }
-  float l = part + __shfl_xor(part, 16, 64);
-  l = l + __shfl_xor(l, 32, 64);
-  const int q = q0 + wave * 16 + px;
-  const size_t oo = ((size_t)im * ANP + q) * 256 + head * 64 + 4 * g;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    f16x4 h, lo;
+  for (int t = 0; t < QT; ++t) {
+    float l = part[t] + __shfl_xor(part[t], 16, 64);
+    l = l + __shfl_xor(l, 32, 64);
+    const int q = q0 + (wave * QT + t) * 16 + px;
+    const size_t oo = ((size_t)im * ANP + q) * 256 + head * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = oacc[dt][r] / l;
-      h[r] = (_Float16)v;
-      lo[r] = (_Float16)(v - (float)h[r]);
+    for (int dt = 0; dt < 4; ++dt) {
+      f16x4 h, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = oacc[t][dt][r] / l;
+        h[r] = (_Float16)v;
+        lo[r] = (_Float16)(v - (float)h[r]);
+      }
+      *(f16x4 *)(oh + oo + dt * 16) = h;
+      *(f16x4 *)(ol + oo + dt * 16) = lo;
     }
-    *(f16x4 *)(oh + oo + dt * 16) = h;
-    *(f16x4 *)(ol + oo + dt * 16) = lo;
   }
+}
+
+template <int QT, int NW>
+static int launch_attn_h2_t(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
+                            const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
+  hipLaunchKernelGGL((attn_h2_kernel<QT, NW>), dim3((ANP / (16 * QT * NW)) * 4 * nimg), dim3(64 * NW), 0, st, qkh, qkl, vth,
+                     vtl, counts, cross, oh, ol);
+  URF_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                    const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(attn_h2_kernel, dim3((ANP / 128) * 4 * nimg), dim3(512), 0, st, qkh, qkl, vth, vtl, counts, cross, oh, ol);
-  URF_HIP(hipGetLastError());
-  return 0;
+  // URF_ATTN_VARIANT (A/B runs): 0 = 1 tile x 8 waves, 1 = 2 tiles x 4 waves, 2 = 2 tiles x 8 waves.
+  // Measured at 8 pairs (18 launches): 1.563 / 1.703 / 1.521 ms.  Default: 2 tiles x 8 waves once that
+  // still gives a workgroup per CU (16 images x 4 heads x 4 query blocks = 256), else 1 tile x 8 waves.
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("URF_ATTN_VARIANT");
+    forced = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+  }
+  const int variant = forced >= 0 ? forced : (nimg >= 16 ? 2 : 0);
+  if (variant == 1) return launch_attn_h2_t<2, 4>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
+  if (variant == 2) return launch_attn_h2_t<2, 8>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
+  return launch_attn_h2_t<1, 8>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
 }
 
 }  // namespace urf
