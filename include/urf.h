@@ -258,6 +258,28 @@ int urf_fe_in_flight(urf_fe *h);
 urf_sp *urf_fe_superpoint(urf_fe *h);
 urf_pm *urf_fe_matcher(urf_fe *h, int i);
 
+/* ------------------------------------------------ map-point projection search -- */
+/* Mapping::SearchByProjection(frame, mappoints, thr, good_projections), src/mapping.cc:667-735
+ * (SURVEY.md section 8 f4): projection (include/camera.h:48-68), window search
+ * (Frame::FindNeighborKeypoints, src/frame.cc:320-353), descriptor distance (src/utils.cc:14-19),
+ * first-best-wins minimum and the 0.35 / 0.6 acceptance tests.  Host arrays in, host array out. */
+typedef struct {
+  double fx, fy, cx, cy;
+  double image_width, image_height;
+  double pose[16];            /* Twc = Frame::GetPose(), row-major 4x4 */
+  int thr;                    /* radius = 15 * thr */
+  int device;
+} urf_sbp_config;
+/* feat: column-major 259 x K f64 (Frame::GetAllFeatures); occupied: K flags, non-zero = the keypoint
+ * already has a good map point (NULL = none); mp_pos M x 3, mp_desc M x 256 f64, mp_valid M flags or
+ * NULL; best_idx[m] = keypoint index of an accepted projection, else -1. */
+int urf_search_by_projection(const urf_sbp_config *cfg, const double *feat, int K, const uint8_t *occupied,
+                             const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M, int *best_idx);
+/* same, features taken from a device feature slot (f32, widened exactly: what the host copy holds) */
+int urf_search_by_projection_slot(const urf_sbp_config *cfg, const void *d_slot, int K, const uint8_t *occupied,
+                                  const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M,
+                                  int *best_idx);
+
 /* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);

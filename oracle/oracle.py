@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "liburf_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c",
+    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c", "map_oracle.c",
                                               "urf_oracle.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -282,4 +282,29 @@ def cam_remap(img, map1, map2):
     out = np.empty((oh, ow), np.uint8)
     lib().ocam_remap(_p(img), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]), _p(map1), _p(map2), oh, ow,
                      _p(out), C.c_size_t(out.strides[0]))
+    return out
+
+
+class SbpConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("image_width", C.c_double), ("image_height", C.c_double), ("pose", C.c_double * 16), ("thr", C.c_int)]
+
+
+def sbp_config(fx, fy, cx, cy, width, height, pose, thr):
+    c = SbpConfig(fx, fy, cx, cy, width, height)
+    for i, v in enumerate(np.asarray(pose, np.float64).reshape(16)):
+        c.pose[i] = v
+    c.thr = int(thr)
+    return c
+
+
+def search_by_projection(cfg, feat, mp_pos, mp_desc, occupied=None, mp_valid=None):
+    """src/mapping.cc:667-735 -> best keypoint index per map point (-1 = rejected)"""
+    f = np.ascontiguousarray(feat, np.float64)
+    pos = np.ascontiguousarray(mp_pos, np.float64)
+    desc = np.ascontiguousarray(mp_desc, np.float64)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    val = None if mp_valid is None else np.ascontiguousarray(mp_valid, np.uint8)
+    out = np.full(pos.shape[0], -2, np.int32)
+    lib().osbp_search(C.byref(cfg), _p(f), f.shape[0], _p(occ), _p(pos), _p(desc), _p(val), pos.shape[0], _p(out))
     return out

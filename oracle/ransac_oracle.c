@@ -172,7 +172,7 @@ static void mat3_mul_f(const float *a, const float *b, float *o) {
 
 /* _normalize :735-780 with the canonical wave-strided float sums */
 static void normalize_pts(const float *pts, int n, float *out, float T[9]) {
-  float *tx = (float *)malloc(4 * (size_t)n), *ty = (float *)malloc(4 * (size_t)n);
+  float *tx = (float *)calloc((size_t)n + 1, 4), *ty = (float *)calloc((size_t)n + 1, 4);
   for (int i = 0; i < n; ++i) { tx[i] = pts[2 * i]; ty[i] = pts[2 * i + 1]; }
   const float meanX = om_wave_sum(tx, n) / (float)n, meanY = om_wave_sum(ty, n) / (float)n;
   for (int i = 0; i < n; ++i) {

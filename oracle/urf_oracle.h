@@ -135,6 +135,19 @@ int ocam_init_maps(const ocam_config *c, float *map1, float *map2);
 void ocam_remap(const uint8_t *img, int H, int W, size_t step, const float *map1, const float *map2, int oh, int ow,
                 uint8_t *out, size_t ostep);
 
+/* ---------------- map-point projection search ---------------- */
+typedef struct {
+  double fx, fy, cx, cy;              /* Camera::Project, include/camera.h:48-68 */
+  double image_width, image_height;
+  double pose[16];                    /* Twc, row-major 4x4 (Frame::GetPose) */
+  int thr;                            /* search radius = 15 * thr pixels (src/mapping.cc:680) */
+} osbp_config;
+/* Mapping::SearchByProjection src/mapping.cc:667-735.  feat: column-major 259 x K; occupied: K flags
+ * (keypoint already carries a good map point -> skipped, src/frame.cc:342) or NULL; mp_*: M map points.
+ * best_idx[m] = keypoint index of an accepted projection or -1. */
+int osbp_search(const osbp_config *c, const double *feat, int K, const uint8_t *occupied, const double *mp_pos,
+                const double *mp_desc, const uint8_t *mp_valid, int M, int *best_idx);
+
 /* canonical math probes (tests) */
 float o_exp(float x);
 float o_log(float x);

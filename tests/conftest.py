@@ -91,3 +91,40 @@ def two_view_scene(seed=0, n=400, noise=0.0, outliers=40, unmatched=30, planar=F
     if unmatched:
         m[rng.choice(n, unmatched, replace=False)] = -1
     return K, p0.astype(np.float32), k2.astype(np.float32), m, R, t
+
+
+def projection_scene(seed, K=400, M=300, W=640, H=480, duplicates=True):
+    """a frame (features [K,259]) and map points for Mapping::SearchByProjection: most map points are
+    keypoints back-projected along their ray with a noisy copy of the descriptor; some are behind the camera,
+    outside the image or invalid; some keypoints are occupied; duplicated descriptors force exact ties."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 420.0, 415.0, 321.5, 238.25
+    xy = np.stack([rng.integers(4, W - 4, K), rng.integers(4, H - 4, K)], 1).astype(np.float64)
+    d = rng.standard_normal((K, 256)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if duplicates:                                  # identical descriptors a few pixels apart: exact distance ties
+        for a_, b_ in ((5, 6), (40, 41), (100, 101)):
+            d[b_] = d[a_]
+            xy[b_] = xy[a_] + [6, -3]
+    feat = np.zeros((K, 259))
+    feat[:, 0] = rng.uniform(0.01, 1, K).astype(np.float32)
+    feat[:, 1:3] = xy
+    feat[:, 3:] = d
+    ang = 0.05
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.3, -0.1, 0.2])
+    pose = np.eye(4); pose[:3, :3] = R; pose[:3, 3] = t
+    src = rng.integers(0, K, M)
+    depth = rng.uniform(2, 20, M)
+    ray = np.stack([(xy[src, 0] + rng.normal(0, 3, M) - cx) / fx, (xy[src, 1] + rng.normal(0, 3, M) - cy) / fy, np.ones(M)], 1)
+    pc = ray * depth[:, None]
+    pc[::17, 2] *= -1                               # behind the camera
+    pc[5::23, 0] += 1e4                             # far outside the image
+    pos = pc @ R.T + t                              # pw = Rwc pc + twc
+    md = d[src].astype(np.float64) + rng.normal(0, 0.02, (M, 256))
+    md[7::11] = rng.standard_normal((len(md[7::11]), 256))          # unrelated descriptors: rejected by the 0.35 test
+    md /= np.linalg.norm(md, axis=1, keepdims=True)
+    md[::5] = d[src[::5]]                           # exact copies (distance of the true match ~ 0, ties with duplicates)
+    valid = (rng.uniform(size=M) > 0.05).astype(np.uint8)
+    occupied = (rng.uniform(size=K) < 0.1).astype(np.uint8)
+    return dict(cam=(fx, fy, cx, cy), size=(W, H), pose=pose, feat=feat, pos=pos, desc=md, valid=valid, occupied=occupied)

@@ -543,3 +543,46 @@ def test_c_abi_errors_are_negative_codes_with_text_and_leave_outputs_untouched(U
     assert len(m) > 4
     assert L.urf_match(pm._h, f0.ctypes.data_as(C.c_void_p), 50, f0.ctypes.data_as(C.c_void_p), 50, 0, out, 4) < 0
     assert b"cap" in L.urf_last_error()
+
+
+# ------------------------------------------------------------------ map-point projection search
+@pytest.mark.parametrize("seed,K,M,thr", [(1, 400, 300, 1), (2, 1000, 2000, 3), (3, 64, 5, 2), (4, 1, 1, 1)])
+def test_search_by_projection_bit_exact_vs_oracle(U, F, O, seed, K, M, thr):
+    from conftest import projection_scene
+    sc = projection_scene(seed, K=K, M=M, duplicates=K > 150)
+    cfg = O.sbp_config(*sc["cam"], *sc["size"], sc["pose"], thr)
+    want = O.search_by_projection(cfg, sc["feat"], sc["pos"], sc["desc"], sc["occupied"], sc["valid"])
+    got = F.SearchByProjection(sc["cam"], sc["size"], sc["pose"], sc["feat"], sc["pos"], sc["desc"], thr,
+                               occupied=sc["occupied"], mappoint_valid=sc["valid"])
+    assert np.array_equal(got, want)
+    if K >= 400:
+        assert (got >= 0).sum() > M // 10
+    # no flags at all
+    assert np.array_equal(F.SearchByProjection(sc["cam"], sc["size"], sc["pose"], sc["feat"], sc["pos"], sc["desc"], thr),
+                          O.search_by_projection(cfg, sc["feat"], sc["pos"], sc["desc"]))
+
+
+def test_search_by_projection_on_a_device_slot(U, F, O, sp_blob, sp640):
+    """features read straight from the device slot SuperPoint wrote (f32, widened exactly) == the host
+    feature matrix of the same frame"""
+    import torch
+    frame = U.synth.shift_stream(9, 1, 480, 640)[0]
+    d = torch.from_numpy(frame).cuda()
+    slot = torch.zeros(U._lib.lib().urf_slot_bytes() // 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp640.infer_device(d.data_ptr(), 1, 480, 640, slot.data_ptr())
+    sp640.sync()
+    feat = F.slot_to_host(slot.data_ptr())
+    K = feat.shape[0]
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, K, 500)
+    fx, fy, cx, cy = 420.0, 415.0, 321.5, 238.25
+    depth = rng.uniform(2, 20, 500)
+    pc = np.stack([(feat[src, 1] + rng.normal(0, 2, 500) - cx) / fx, (feat[src, 2] + rng.normal(0, 2, 500) - cy) / fy, np.ones(500)], 1) * depth[:, None]
+    desc = feat[src, 3:] + rng.normal(0, 0.01, (500, 256))
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    pose = np.eye(4)
+    cfg = O.sbp_config(fx, fy, cx, cy, 640, 480, pose, 1)
+    want = O.search_by_projection(cfg, feat, pc, desc)
+    got = F.SearchByProjection((fx, fy, cx, cy), (640, 480), pose, K, pc, desc, 1, d_slot=slot.data_ptr())
+    assert np.array_equal(got, want) and (got >= 0).sum() > 100

@@ -306,3 +306,87 @@ def test_camera_remap_is_opencv_fixed_point_bilinear(O):
     # non-finite and far-away coordinates are outside
     bad = u.copy(); bad[0, 0] = np.nan; bad[0, 1] = np.inf; bad[0, 2] = 1e9; bad[0, 3] = -1e9
     assert (O.cam_remap(img, bad, v)[0, :4] == 0).all()
+
+
+# ------------------------------------------------------------------ map-point projection search
+def _sbp_reference_walk(sc, thr):
+    """the reference's control flow (src/mapping.cc:667-735, src/frame.cc:70-80,320-353) written out with
+    an explicit feature grid, numpy doubles and math.fsum-free sequential arithmetic"""
+    import ctypes
+    import math
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fma.restype = ctypes.c_double
+    libm.fma.argtypes = [ctypes.c_double] * 3
+    fx, fy, cx, cy = sc["cam"]
+    W, H = sc["size"]
+    feat, pose = sc["feat"], sc["pose"]
+    gwi, ghi = 64.0 / W, 48.0 / H
+    grid = [[[] for _ in range(48)] for _ in range(64)]
+    for i in range(feat.shape[0]):
+        gx = min(max(0, int(round(feat[i, 1] * gwi))), 63)        # ties at .5 never occur for these coordinates
+        gy = min(max(0, int(round(feat[i, 2] * ghi))), 47)
+        grid[gx][gy].append(i)
+    Rwc, twc = pose[:3, :3], pose[:3, 3]
+    r = 15.0 * thr
+    out = []
+    for m in range(sc["pos"].shape[0]):
+        res = -1
+        if sc["valid"][m]:
+            dd = sc["pos"][m] - twc
+            pc = [(Rwc[0, i] * dd[0] + Rwc[1, i] * dd[1]) + Rwc[2, i] * dd[2] for i in range(3)]
+            if pc[2] > 0:
+                zi = 1.0 / pc[2]
+                u, v = (pc[0] * zi) * fx + cx, (pc[1] * zi) * fy + cy
+                if not (u <= 0 or u >= W or v <= 0 or v >= H):
+                    best, second, bi = 4.0, 4.0, -1
+                    for gx in range(max(0, math.floor((u - r) * gwi)), min(63, math.ceil((u + r) * gwi)) + 1):
+                        for gy in range(max(0, math.floor((v - r) * ghi)), min(47, math.ceil((v + r) * ghi)) + 1):
+                            for idx in grid[gx][gy]:
+                                if sc["occupied"][idx]:
+                                    continue
+                                if abs(feat[idx, 1] - u) < r and abs(feat[idx, 2] - v) < r:
+                                    dot = 0.0
+                                    for c in range(256):
+                                        dot = libm.fma(sc["desc"][m, c], feat[idx, 3 + c], dot)
+                                    dist = 2 * (1.0 - dot)
+                                    if dist < best:
+                                        second, best, bi = best, dist, idx
+                                    elif dist < second:
+                                        second = dist
+                    if best < 0.35 and best < 0.6 * second:
+                        res = bi
+        out.append(res)
+    return np.array(out, np.int32)
+
+
+def test_search_by_projection_follows_the_reference_walk(O):
+    from conftest import projection_scene
+    for seed, thr in ((1, 1), (2, 3)):
+        sc = projection_scene(seed, K=150, M=90)
+        cfg = O.sbp_config(*sc["cam"], *sc["size"], sc["pose"], thr)
+        got = O.search_by_projection(cfg, sc["feat"], sc["pos"], sc["desc"], sc["occupied"], sc["valid"])
+        assert (got >= -1).all() and (got >= 0).sum() > 15 and (got == -1).sum() > 15
+        assert (got[sc["valid"] == 0] == -1).all() and not sc["occupied"][got[got >= 0]].any()
+        assert np.array_equal(got, _sbp_reference_walk(sc, thr))      # bit-for-bit against the explicit-grid walk
+        # numpy restatement with a pairwise-summed dot product: same decisions except exact ties / last-ulp cases
+        feat = sc["feat"]
+        dots = sc["desc"] @ feat[:, 3:].T
+        fx, fy, cx, cy = sc["cam"]
+        pc = (sc["pos"] - sc["pose"][:3, 3]) @ sc["pose"][:3, :3]
+        agree = 0
+        for m in range(len(got)):
+            if not sc["valid"][m] or pc[m, 2] <= 0:
+                assert got[m] == -1
+                continue
+            u, v = pc[m, 0] / pc[m, 2] * fx + cx, pc[m, 1] / pc[m, 2] * fy + cy
+            if u <= 0 or u >= sc["size"][0] or v <= 0 or v >= sc["size"][1]:
+                assert got[m] == -1
+                continue
+            cand = np.where((np.abs(feat[:, 1] - u) < 15 * thr) & (np.abs(feat[:, 2] - v) < 15 * thr) & (sc["occupied"] == 0))[0]
+            dist = 2 * (1 - dots[m, cand])
+            order = np.argsort(dist, kind="stable")
+            ok = len(cand) > 0 and dist[order[0]] < 0.35 and dist[order[0]] < 0.6 * (dist[order[1]] if len(cand) > 1 else 4.0)
+            want = cand[order[0]] if ok else -1
+            agree += int(want == got[m]) if (len(cand) < 2 or abs(dist[order[1]] - dist[order[0]]) > 1e-9) else 1
+        assert agree == sum(1 for m in range(len(got)) if sc["valid"][m] and pc[m, 2] > 0 and 0 < pc[m, 0] / pc[m, 2] * fx + cx < sc["size"][0]
+                            and 0 < pc[m, 1] / pc[m, 2] * fy + cy < sc["size"][1])

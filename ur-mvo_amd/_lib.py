@@ -23,6 +23,7 @@ SYMBOLS = [
     "urf_cam_undistort_device", "urf_cam_sync",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
     "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
+    "urf_search_by_projection", "urf_search_by_projection_slot",
 ]
 
 
@@ -52,6 +53,12 @@ class CamConfig(C.Structure):
 class FEConfig(C.Structure):
     _fields_ = [("sp", SPConfig), ("sg", SGConfig), ("batch", C.c_int), ("matchers", C.c_int),
                 ("history_batches", C.c_int), ("outlier_rejection", C.c_int)]
+
+
+class SbpConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("image_width", C.c_double), ("image_height", C.c_double), ("pose", C.c_double * 16), ("thr", C.c_int),
+                ("device", C.c_int)]
 
 
 class DMatch(C.Structure):

@@ -418,6 +418,29 @@ class FrameStream:
         return _lib.lib().urf_fe_in_flight(self._h)
 
 
+def SearchByProjection(camera_fxfycxcy, image_size, pose, features, mappoint_positions, mappoint_descriptors, thr,
+                       occupied=None, mappoint_valid=None, d_slot=None, device=0):
+    """Mapping::SearchByProjection (src/mapping.cc:667-735): -> int32[M], accepted keypoint index or -1.
+    features: [K, 259] f64, or pass d_slot (device slot pointer) with features = K to read them on the GPU."""
+    c = _lib.SbpConfig(*[float(v) for v in camera_fxfycxcy], float(image_size[0]), float(image_size[1]))
+    for i, v in enumerate(np.asarray(pose, np.float64).reshape(16)):
+        c.pose[i] = v
+    c.thr, c.device = int(thr), int(device)
+    pos = np.ascontiguousarray(mappoint_positions, np.float64)
+    desc = np.ascontiguousarray(mappoint_descriptors, np.float64)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    val = None if mappoint_valid is None else np.ascontiguousarray(mappoint_valid, np.uint8)
+    out = np.full(pos.shape[0], -2, np.int32)
+    if d_slot is not None:
+        check(_lib.lib().urf_search_by_projection_slot(C.byref(c), C.c_void_p(d_slot), int(features), _p(occ), _p(pos), _p(desc),
+                                                       _p(val), pos.shape[0], _p(out)), "urf_search_by_projection_slot")
+    else:
+        f = np.ascontiguousarray(features, np.float64)
+        check(_lib.lib().urf_search_by_projection(C.byref(c), _p(f), f.shape[0], _p(occ), _p(pos), _p(desc), _p(val),
+                                                  pos.shape[0], _p(out)), "urf_search_by_projection")
+    return out
+
+
 def slot_to_host(d_slot_ptr):
     feat = np.zeros((CAP, 259), np.float64)
     K = C.c_int(0)
