@@ -9,7 +9,7 @@
 // a lexicographic minimum, which reproduces the reference's sequential scan
 // (strict <, candidates visited grid column, grid row, keypoint index).
 // Arithmetic left to Eigen by the reference is fixed by the written
-// specification of oracle/map_oracle.c (component sums ((a+b)+c), ascending fma
+// specification in DESIGN.md section 6 (component sums ((a+b)+c), ascending fma
 // chain for the dot product).
 #include <cmath>
 #include <cstring>
