@@ -288,6 +288,8 @@ int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int de
 int urf_probe_h2gemm_variant(int v);
 int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                      int reps, float *ms_out, int device);
+/* research probe: ncases independent v_mfma_f32_16x16x32_f16 (A 16x32 f16, B 32x16 f16, C/D 16x16 f32, row-major) */
+int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
 
 #ifdef __cplusplus

@@ -23,7 +23,7 @@ SYMBOLS = [
     "urf_cam_undistort_device", "urf_cam_sync",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
     "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
-    "urf_search_by_projection", "urf_search_by_projection_slot",
+    "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
 ]
 
 

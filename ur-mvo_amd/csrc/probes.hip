@@ -92,3 +92,46 @@ extern "C" int urf_probe_divsqrt(const float *a, const float *b, int n, float *q
   (void)hipFree(da); (void)hipFree(db); (void)hipFree(dq); (void)hipFree(ds); (void)hipFree(dqd); (void)hipFree(dsd);
   return 0;
 }
+
+// ---- one v_mfma_f32_16x16x32_f16 per case: D = A (16x32) B (32x16) + C, raw operands from the host.
+// Research probe for the numerics of the f16 matrix core (is its accumulation a reproducible model?).
+namespace urf {
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+__global__ void probe_mfma_f16_kernel(const _Float16 *A, const _Float16 *B, const float *C, float *D, int n) {
+  const int cs = blockIdx.x;
+  if (cs >= n) return;
+  const int l = threadIdx.x, px = l & 15, g = l >> 4;
+  const _Float16 *a = A + (size_t)cs * 512, *b = B + (size_t)cs * 512;
+  pf16x8 av, bv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    av[e] = a[px * 32 + 8 * g + e];          // A[row = px][k = 8g + e]
+    bv[e] = b[(8 * g + e) * 16 + px];        // B[k = 8g + e][col = px]
+  }
+  pf32x4 c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = C[(size_t)cs * 256 + (4 * g + r) * 16 + px];   // C[row = 4g + r][col = px]
+  const pf32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[(size_t)cs * 256 + (4 * g + r) * 16 + px] = d[r];
+}
+}  // namespace urf
+
+extern "C" int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device) {
+  URF_CHECK(A_f16 && B_f16 && C && D && ncases > 0, "probe_mfma_f16: bad argument");
+  URF_HIP(hipSetDevice(device));
+  _Float16 *dA, *dB;
+  float *dC, *dD;
+  const size_t nh = (size_t)ncases * 512 * 2, nf = (size_t)ncases * 256 * 4;
+  URF_HIP(hipMalloc((void **)&dA, nh)); URF_HIP(hipMalloc((void **)&dB, nh));
+  URF_HIP(hipMalloc((void **)&dC, nf)); URF_HIP(hipMalloc((void **)&dD, nf));
+  URF_HIP(hipMemcpy(dA, A_f16, nh, hipMemcpyHostToDevice));
+  URF_HIP(hipMemcpy(dB, B_f16, nh, hipMemcpyHostToDevice));
+  URF_HIP(hipMemcpy(dC, C, nf, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(urf::probe_mfma_f16_kernel, dim3(ncases), dim3(64), 0, 0, dA, dB, dC, dD, ncases);
+  URF_HIP(hipGetLastError());
+  URF_HIP(hipMemcpy(D, dD, nf, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+  return 0;
+}
