@@ -48,8 +48,8 @@ def sg_linear_gbytes(n0, n1, fast):
     written once at 4 B per element (fp32, or two f16 planes in the fast mode), weights once per step
     (counted by the caller).  Per GNN layer and keypoint: qkv 256 in + 768 out, merge 256 + 256 (exact
     mode only: the fast mode folds the merge weights into mlp0 at build time), mlp0 512 + 512,
-    mlp1 512 in + 256 residual + 256 out (+ 256 plane copy of x in the fast mode)."""
-    per_pt = 18 * (1024 + (0 if fast else 512) + 1024 + 1024 + (256 if fast else 0))
+    mlp1 512 in + 256 residual + 256 out (the fast mode keeps the residual stream in its two f16 planes only)."""
+    per_pt = 18 * (1024 + (0 if fast else 512) + 1024 + 1024)
     per_pt += (4 + 32) + (32 + 64) + (64 + 128) + (128 + 256) + (256 + 256 + 256) + (256 + 256)   # kenc, final proj
     return 4.0 * per_pt * (n0 + n1) / 1e9
 

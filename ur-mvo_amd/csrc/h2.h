@@ -16,6 +16,7 @@ struct H2Args {
   int ld_out;
   long out_bstride;
   const float *res;          // optional fp32 residual, same geometry as out
+  const _Float16 *resh, *resl;   // or: residual as split planes (same geometry as oh/ol), v += hi + lo
   int relu;
   const int *counts;
   // transposed split output (the V projection of attention): ohT/olT [Cout][ldT] per batch item,

@@ -63,7 +63,11 @@ __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2],
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
       }
-      if (a.res) {
+      if (a.resh) {
+        const f16x4 rh = *(const f16x4 *)(a.resh + ro + m * 16), rl = *(const f16x4 *)(a.resl + ro + m * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((float)rh[q] + (float)rl[q]) + v[q];
+      } else if (a.res) {
         const f32x4 rv = *(const f32x4 *)(a.res + ro + m * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = rv[q] + v[q];

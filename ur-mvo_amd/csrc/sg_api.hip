@@ -377,9 +377,17 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
     if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->oh, h->ol, 256, 256, h->H[l].w1, h->L[l].b1f, 512, nullptr, h->hh,
                   h->hl, 512, true, nullptr, false))
       return -1;
-    if (h2_linear(h, NI, h->hh, h->hl, 512, 512, nullptr, nullptr, 0, 0, h->H[l].w2, h->L[l].b2, 256, h->x, h->xh, h->xl,
-                  256, false, h->x, false))
-      return -1;
+    {  // second MLP layer + residual.  The residual stream lives in its two f16 planes only (22 bits, the
+       // precision every GEMM of the fast mode sees anyway): no fp32 copy of x is written or read per layer
+      H2Args a = {};
+      a.xh = h->hh; a.xl = h->hl; a.ldx = 512; a.x_bstride = (long)NP * 512;
+      a.rows = NP; a.Cin = 512;
+      a.wh = h->d_wh + h->H[l].w2; a.wl = h->d_wl + h->H[l].w2; a.bias = h->d_w + h->L[l].b2; a.Cout = 256;
+      a.counts = h->counts;
+      a.oh = h->xh; a.ol = h->xl; a.ld_out = 256; a.out_bstride = (long)NP * 256;
+      a.resh = h->xh; a.resl = h->xl;
+      if (launch_h2gemm(a, NI, st)) return -1;
+    }
   }
   return 0;
 }
