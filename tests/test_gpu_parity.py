@@ -300,6 +300,25 @@ def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
     assert d["matches_per_step"] > 8 * 600          # rank 0's 8 pairs, incl. the pair that crosses the batch seam
 
 
+def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
+    """URF_BENCH_FORCE_DIST=1: the N>1 exchange path of bench.py (RCCL all-gather on its own stream,
+    ordered against the SuperPoint and matcher streams by events only) in a process group of one rank.
+    The match lists must be the ones of the plain single-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = []
+    for force in ("0", "1"):
+        env = dict(os.environ, URF_BENCH_FORCE_DIST=force, MASTER_PORT="29541")
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                                       "--no-cpu-baseline", "--no-exact-check"], env=env, text=True, stderr=subprocess.DEVNULL)
+        res.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
+    assert res[0]["matches_per_step"] == res[1]["matches_per_step"] > 8 * 600
+    assert res[1]["n_gpus"] == 1 and res[1]["value"] > 0.5 * res[0]["value"]
+
+
 @pytest.mark.parametrize("kw,its", [(dict(seed=0, noise=0.0, outliers=40), 200), (dict(seed=2, noise=0.3, outliers=40), 200),
                                     (dict(seed=1, planar=True, outliers=20), 200),
                                     (dict(seed=33, planar=True, outliers=10, noise=0.1), 5),     # homography branch
