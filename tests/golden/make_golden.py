@@ -10,6 +10,7 @@ Fixtures are DATA (inputs + expected outputs), never reference source:
   sp_sparse_240x320.npz image, keypoints/scores/descriptors after the
                         reference post-processing restated with torch ops
   sp_sparse_376x1241.npz same at the KITTI size (valid width 1240)
+  sp_sparse_480x640.npz same at the size of BASELINE.json's headline configuration
   sg_n96.npz            two feature sets and the (n0+1)x(n1+1) log-assignment
 The seeded synthetic weights are regenerated bit-exactly by synth.py.
 """
@@ -72,10 +73,13 @@ def sp_post(scores, desc, k=1000, thr=0.0005, border=4):
 
 def main():
     m = sp_model()
-    img = synth.shift_stream(3, 1, 96, 128)[0]
-    s, d = sp_run(m, img)
-    np.savez_compressed(os.path.join(OUT, "sp_dense_96x128.npz"), image=img, scores=s, desc=d.astype(np.float32))
-    for (H, W, k, seed) in [(240, 320, 300, 4), (376, 1241, 1000, 5)]:
+    if not os.path.exists(os.path.join(OUT, "sp_dense_96x128.npz")) or "--force" in sys.argv:
+        img = synth.shift_stream(3, 1, 96, 128)[0]
+        s, d = sp_run(m, img)
+        np.savez_compressed(os.path.join(OUT, "sp_dense_96x128.npz"), image=img, scores=s, desc=d.astype(np.float32))
+    for (H, W, k, seed) in [(240, 320, 300, 4), (376, 1241, 1000, 5), (480, 640, 1000, 6)]:
+        if os.path.exists(os.path.join(OUT, f"sp_sparse_{H}x{W}.npz")) and "--force" not in sys.argv:
+            continue
         img = synth.shift_stream(seed, 1, H, W)[0]
         s, d = sp_run(m, img)
         xs, ys, sc, ds = sp_post(s, d, k=k)
@@ -84,6 +88,8 @@ def main():
                             n_candidates=np.int32(int((s.astype(np.float64) > 0.0005).sum())))
         print(H, W, "K", len(xs), "cands", int((s > 0.0005).sum()))
 
+    if os.path.exists(os.path.join(OUT, "sg_n96.npz")) and "--force" not in sys.argv:
+        return
     # ---- SuperGlue: public architecture (transformers) with the synthetic weights
     from transformers.models.superglue import modeling_superglue as MS
     from transformers.models.superglue.configuration_superglue import SuperGlueConfig

@@ -83,7 +83,7 @@ def test_superpoint_full_size_640x480_and_kitti(U, O, sp_blob, sp640):
         assert np.abs(np.linalg.norm(feat[:, 3:], axis=1) - 1).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz"])
+@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz", "sp_sparse_480x640.npz"])
 def test_superpoint_vs_reference_graph_golden(F, sp_blob, name):
     """HIP output vs the torch run of the reference's model.py (committed fixture)."""
     g = golden(name)

@@ -52,7 +52,7 @@ def test_sp_dense_matches_reference_graph(O, sp_blob):
     assert np.array_equal(o["scores"] > 0.0005, g["scores"] > 0.0005)
 
 
-@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz"])
+@pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz", "sp_sparse_480x640.npz"])
 def test_sp_infer_matches_reference_postprocess(O, sp_blob, name):
     g = golden(name)
     cfg = O.SPConfig(int(g["k"]), 0.0005, 4)
