@@ -9,6 +9,7 @@
 #include "h2.h"
 
 #include <float.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace urf {
@@ -121,7 +122,12 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 
-  for (int ch = 0; ch < nchunk; ++ch) {
+  // one 64-key chunk.  MASK = false for chunks whose 64 keys are all valid: no per-element bound test and no
+  // -FLT_MAX sentinel (the softmax VALU work, not the MFMAs, paces this kernel: ~250 -> ~150 instructions per
+  // 48 MFMAs).  The scores arrive in the log2 domain, already divided by sqrt(64): build() folds
+  // log2(e) / 8 into the Q projection, so p = 2^(s - m) is one v_exp_f32.
+  auto chunk = [&](int ch, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = ch & 1;
     if (ch + 1 < nchunk) issue(ch + 1);
     // ---- S^T = K Q^T for the 64 keys of this chunk
@@ -147,8 +153,10 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       const int kb0 = ch * 64 + kt * 16 + 4 * g;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        if (MASK) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = (kb0 + r < ns) ? acc[t][r] * 0.125f : -FLT_MAX;
+          for (int r = 0; r < 4; ++r) acc[t][r] = (kb0 + r < ns) ? acc[t][r] : -FLT_MAX;
+        }
         s[t][kt] = acc[t];
       }
     }
@@ -164,7 +172,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
       cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
       mn[t] = fmaxf(m[t], cm);
-      const float alpha = __expf(m[t] - mn[t]);
+      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn[t]);
       m[t] = mn[t];
       part[t] = part[t] * alpha;
 #pragma unroll
@@ -181,7 +189,8 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float sv = s[t][2 * kp + (e >> 2)][e & 3];
-          const float p = (sv == -FLT_MAX) ? 0.0f : __expf(sv - mn[t]);
+          float p = __builtin_amdgcn_exp2f(sv - mn[t]);
+          if (MASK) p = (sv == -FLT_MAX) ? 0.0f : p;
           part[t] = part[t] + p;
           const _Float16 h = (_Float16)p;
           ph[t][e] = h;
@@ -206,7 +215,10 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     }
     if (ch + 1 < nchunk) commit(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int nfull = ns >> 6;                          // chunks whose 64 keys are all valid
+  for (int ch = 0; ch < nfull; ++ch) chunk(ch, std::false_type{});
+  if (nfull < nchunk) chunk(nfull, std::true_type{});
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l = part[t] + __shfl_xor(part[t], 16, 64);

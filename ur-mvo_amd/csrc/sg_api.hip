@@ -35,6 +35,7 @@ enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC
 // stage_ms[PT_COUNT] additionally reports the attention kernels' share of PT_GNN
 }  // namespace urf
 using namespace urf;
+static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e) / sqrt(64), folded into the Q projection
 
 struct urf_pm {
   urf_sg_config cfg;
@@ -49,7 +50,7 @@ struct urf_pm {
   bool built = false;
   float *d_w = nullptr;
   size_t kw[5], kb[5];
-  struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2, b1f; } L[18];
+  struct { size_t wqkv, bqkv, wm, bm, w1, b1, w2, b2, b1f, bqkv_f; } L[18];
   size_t wf, bf;
   float bin_score = 1.0f;
   // fast precision mode (split-f16 MFMA): transposed weights as hi/lo f16 planes
@@ -160,6 +161,15 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     if (h->precision == 1) {
       // fast mode folds the merge layer into the first MLP layer (both linear, nothing in between):
       //   W0 [x ; Wm o + bm] + b0 = W0x x + (W0m Wm) o + (b0 + W0m bm)
+      // ... and log2(e) / sqrt(64) into the Q projection: the attention kernel then gets its scores already in
+      // the log2 domain and divided by sqrt(d), and p = 2^(s - max) is a single v_exp_f32
+      h->L[l].bqkv_f = put(nullptr, 768);
+      {
+        float *bqf = host.data() + h->L[l].bqkv_f;
+        for (int o = 0; o < 256; ++o) bqf[o] = (float)((double)bq[o] * kQScale);
+        memcpy(bqf + 256, bk, 1024);
+        memcpy(bqf + 512, bv, 1024);
+      }
       h->L[l].b1f = put(nullptr, 512);
       float *bf = host.data() + h->L[l].b1f;
       for (int o = 0; o < 512; ++o) {
@@ -197,7 +207,19 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       const float *wq = q, *wk = wq + 65536 + 256, *wv = wk + 65536 + 256, *wm = wv + 65536 + 256;
       const float *w1 = wm + 65536 + 256, *w2 = w1 + 262144 + 512;
       q = w2 + 131072 + 256;
-      h->H[l].qk = putT(wq, 256, 256);
+      {  // Q rows scaled by log2(e) / 8 (in f64, then split)
+        const size_t off = wh.size();
+        wh.resize(off + (size_t)256 * 256);
+        wl.resize(off + (size_t)256 * 256);
+        for (int o = 0; o < 256; ++o)
+          for (int c = 0; c < 256; ++c) {
+            const double v = (double)wq[(size_t)c * 256 + o] * kQScale;
+            const _Float16 hi = (_Float16)v;
+            wh[off + (size_t)o * 256 + c] = hi;
+            wl[off + (size_t)o * 256 + c] = (_Float16)(v - (double)hi);
+          }
+        h->H[l].qk = off;
+      }
       putT(wk, 256, 256);                 // rows 256..511 of the fused [512][256] matrix
       h->H[l].v = putT(wv, 256, 256);
       h->H[l].m = putT(wm, 256, 256);
@@ -364,7 +386,7 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
       H2Args a = {};
       a.xh = h->xh; a.xl = h->xl; a.ldx = 256; a.x_bstride = (long)NP * 256;
       a.rows = NP; a.Cin = 256;
-      a.wh = h->d_wh + h->H[l].qk; a.wl = h->d_wl + h->H[l].qk; a.bias = h->d_w + h->L[l].bqkv; a.Cout = 768;
+      a.wh = h->d_wh + h->H[l].qk; a.wl = h->d_wl + h->H[l].qk; a.bias = h->d_w + h->L[l].bqkv_f; a.Cout = 768;
       a.counts = h->counts;
       a.oh = h->qkh; a.ol = h->qkl; a.ld_out = 512; a.out_bstride = (long)NP * 512;
       a.ohT = h->vth; a.olT = h->vtl; a.ldT = NP; a.outT_bstride = (long)256 * NP; a.t_from = 512;
