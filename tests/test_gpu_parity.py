@@ -605,3 +605,19 @@ def test_search_by_projection_on_a_device_slot(U, F, O, sp_blob, sp640):
     want = O.search_by_projection(cfg, feat, pc, desc)
     got = F.SearchByProjection((fx, fy, cx, cy), (640, 480), pose, K, pc, desc, 1, d_slot=slot.data_ptr())
     assert np.array_equal(got, want) and (got >= 0).sum() > 100
+
+
+def test_fast_mode_degenerate_keypoint_counts(F, sg_blob):
+    """0, 1 and 65 keypoints (one full chunk + one masked key) through the fast matcher: no NaN leaks into the
+    match lists, and a one-to-one planted pair still matches"""
+    rng = np.random.default_rng(21)
+    pmf = F.PointMatching(F.SuperGlueConfig(), max_pairs=1, precision=1)
+    assert pmf.build(sg_blob)
+    f1 = make_features(rng, 65)
+    assert pmf.MatchingPoints(np.zeros((0, 259)), f1, True) == []
+    assert pmf.MatchingPoints(f1, np.zeros((0, 259)), False) == []
+    one = make_features(rng, 1)
+    m = pmf.MatchingPoints(one, one, False)
+    assert len(m) <= 1 and all(np.isfinite(d) for _, _, d in m)
+    m = pmf.MatchingPoints(f1, f1, False)
+    assert len(m) >= 60 and all(q == t and np.isfinite(d) for q, t, d in m)
