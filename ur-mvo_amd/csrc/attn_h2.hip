@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 
   // staging: virtual thread vt -> (tensor sk: 0 = K, 1 = V^T; plane sp; row sr (+16u); 16-byte piece sj)
   f16x8 pf[NV][4];
-  auto issue = [&](int ch) {
+  // BOUND = false: all 64 keys of the chunk are valid -- no per-key tests, no zeroing of stale tokens
+  auto issue = [&](int ch, auto bound_tag) {
+    constexpr bool BOUND = decltype(bound_tag)::value;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int vt = tid + NT * v;
@@ -64,8 +66,12 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int key = ch * 64 + sr + 16 * u;
-          pf[v][u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (key < ns) pf[v][u] = *(const f16x8 *)(base + (size_t)key * 512 + 8 * sj);
+          if (BOUND) {
+            pf[v][u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (key < ns) pf[v][u] = *(const f16x8 *)(base + (size_t)key * 512 + 8 * sj);
+          } else {
+            pf[v][u] = *(const f16x8 *)(base + (size_t)key * 512 + 8 * sj);
+          }
         }
       } else {
         const _Float16 *base = (sp ? vtl : vth) + ((size_t)sm * 256 + head * 64) * ANP;
@@ -73,14 +79,18 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         for (int u = 0; u < 4; ++u) {
           const int d = sr + 16 * u;
           const int key0 = ch * 64 + 8 * sj;
-          f16x8 x = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (key0 < ns) {
-            x = *(const f16x8 *)(base + (size_t)d * ANP + key0);
+          if (BOUND) {
+            f16x8 x = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (key0 < ns) {
+              x = *(const f16x8 *)(base + (size_t)d * ANP + key0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (key0 + e >= ns) x[e] = (_Float16)0.0f;   // stale tokens beyond the count
+              for (int e = 0; e < 8; ++e)
+                if (key0 + e >= ns) x[e] = (_Float16)0.0f;   // stale tokens beyond the count
+            }
+            pf[v][u] = x;
+          } else {
+            pf[v][u] = *(const f16x8 *)(base + (size_t)d * ANP + key0);
           }
-          pf[v][u] = x;
         }
       }
     }
@@ -99,7 +109,8 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     }
   };
 
-  issue(0);
+  if (ns >= 64) issue(0, std::false_type{});
+  else issue(0, std::true_type{});
   f16x8 qh[QT][2], ql[QT][2];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -126,10 +137,10 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
   // -FLT_MAX sentinel (the softmax VALU work, not the MFMAs, paces this kernel: ~250 -> ~150 instructions per
   // 48 MFMAs).  The scores arrive in the log2 domain, already divided by sqrt(64): build() folds
   // log2(e) / 8 into the Q projection, so p = 2^(s - m) is one v_exp_f32.
-  auto chunk = [&](int ch, auto mask_tag) {
+  auto chunk = [&](int ch, auto mask_tag, auto next_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = ch & 1;
-    if (ch + 1 < nchunk) issue(ch + 1);
+    if (ch + 1 < nchunk) issue(ch + 1, next_tag);
     // ---- S^T = K Q^T for the 64 keys of this chunk
     f32x4 s[QT][4];
     const _Float16 *kph = kbuf[buf][0] + px * AS + 8 * g;
@@ -138,14 +149,13 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 acc[QT];
 #pragma unroll
-      for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const f16x8 ah = *(const f16x8 *)(kph + kt * 16 * AS + 32 * ks);
         const f16x8 al = *(const f16x8 *)(kpl + kt * 16 * AS + 32 * ks);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t][ks], acc[t], 0, 0, 0);
+          // the first product of a tile takes the constant 0 as its C operand (no zeroed registers)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t][ks], ks == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[t][ks], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t][ks], acc[t], 0, 0, 0);
         }
@@ -217,8 +227,9 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     __syncthreads();
   };
   const int nfull = ns >> 6;                          // chunks whose 64 keys are all valid
-  for (int ch = 0; ch < nfull; ++ch) chunk(ch, std::false_type{});
-  if (nfull < nchunk) chunk(nfull, std::true_type{});
+  for (int ch = 0; ch + 1 < nfull; ++ch) chunk(ch, std::false_type{}, std::false_type{});
+  if (nfull > 0) chunk(nfull - 1, std::false_type{}, std::true_type{});   // its successor (if any) is the partial chunk
+  if (nfull < nchunk) chunk(nfull, std::true_type{}, std::true_type{});
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l = part[t] + __shfl_xor(part[t], 16, 64);
