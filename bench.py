@@ -81,7 +81,7 @@ def pmc_traffic(kernel_label, resolution, prec):
         return None, "no committed PMC summary for this resolution"
     d = json.load(open(files[-1]))
     fam = ("h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
-           else "h2conv_kernel<pool,fuse1a>")
+           else "sinkhorn_half_kernel" if "inkhorn" in kernel_label else "h2conv_kernel<pool,fuse1a>")
     k = d["kernels"].get(fam)
     if not k:
         return None, f"{os.path.basename(files[-1])} has no {fam}"
@@ -341,6 +341,11 @@ def main():
                  sg_linear_gbytes(n_avg, n_avg, PREC == 1) * BATCH + SG_WEIGHT_GB),
             ("SuperGlue attention (attn_h2_kernel)" if PREC else "SuperGlue attention (attn_kernel)"):
                 (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH, sg_attn_gbytes(n_avg, n_avg) * BATCH),
+            # log-Sinkhorn: 2 passes per iteration, each streams one (n0+1) x (n1+1) f32 matrix (C or C^T) once
+            # (SURVEY section 8d); ~6 flop per element (add, sub, exp, add, max)
+            "Sinkhorn (sinkhorn_half_kernel x %d)" % (2 * SINK_ITERS):
+                (np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 6 / 1e9,
+                 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 4 / 1e9),
         }
         dom = max(per_step, key=lambda k: per_step[k][0])
         ms, gf, gb = per_step[dom]
@@ -350,6 +355,7 @@ def main():
         issue = 3 if PREC == 1 else 1
 
         def roofs(ms_, gf_, gb_):
+            # (the few VALU flops of Sinkhorn are priced at the MFMA roof too: either way its HBM roof binds)
             t_mfma, t_hbm = gf_ * issue / peak_tf, gb_ / HBM_PEAK_GBS * 1e3      # ms at each roof
             return ("hbm" if t_hbm > t_mfma else "mfma"), t_mfma, t_hbm
 
