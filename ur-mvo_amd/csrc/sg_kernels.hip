@@ -339,9 +339,8 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 
 // One Sinkhorn half-iteration (src/super_glue.cpp:436-451, max-stabilised):
 //   out[r] = log_marg[r] - LSE_c( M[r][c] + add[c] ),  r < R, c < Cn
-// SK_RW rows per wave.  Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5
-// per row); `add` is staged once per workgroup in LDS; the sum is the canonical
-// wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
+// Lane l holds the columns 256t + 4l + r (16-byte loads, <= 5 per row) of the row and of `add`;
+// the sum is the canonical wave-strided-by-4 sum.  ROWPASS: M=C, R=n0+1, Cn=n1+1, add=v, out=u.
 // Grid-stride over rows: wave w of the launch handles rows w, w + W, w + 2W, ... (W = waves in the
 // pair's grid slice) with the next row's five 16-byte loads in flight while the current row is
 // reduced.  The launch is sized to about four 4-wave workgroups per CU instead of one wave per
@@ -350,35 +349,35 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 template <bool ROWPASS, bool FAST>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
-  __shared__ __attribute__((aligned(16))) float sadd[LDC + 256];
+  // No LDS, no barrier, one memory round trip: the row's five 16-byte pieces, the lane's 20 values of the
+  // other side's vector (the same columns for every row of the wave; L1/L2 hits) and the two counts are all
+  // requested before anything is waited for.  Bounds are applied afterwards: every piece below LDC is inside
+  // the allocation whatever the counts are.
   const int p = blockIdx.y;
-  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
-  const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
+  const int lane = threadIdx.x & 63;
   const int nw = gridDim.x * 4;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blockIdx.x * 4 >= R) return;
-  const int lane = threadIdx.x & 63;
   const float *Mp = M + (size_t)p * (NP + 1) * LDC;
+  const float *ad = add + (size_t)p * LDC;
   auto load_row = [&](int r, f32x4 (&mv)[5]) {
-    const bool live = r < R;
-    const float *mr = Mp + (size_t)(live ? r : 0) * LDC;
+    const float *mr = Mp + (size_t)(r <= NP ? r : 0) * LDC;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int c = 256 * t + 4 * lane;
       mv[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (live && c < Cn) mv[t] = *(const f32x4 *)(mr + c);  // LDC = 1028 >= c + 4: stays inside the row
+      if (c + 4 <= LDC) mv[t] = *(const f32x4 *)(mr + c);
     }
   };
-  // the first row's loads go out before the vector is staged: they do not depend on it
-  f32x4 cur[5], nxt[5];
+  f32x4 cur[5], nxt[5], av[5];
   load_row(row, cur);
-  const float *ad = add + (size_t)p * LDC;
-  for (int i = threadIdx.x; i < (LDC + 256) / 4; i += 256) {
-    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (4 * i < LDC) v = *(const f32x4 *)(ad + 4 * i);
-    *(f32x4 *)(sadd + 4 * i) = v;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int c = 256 * t + 4 * lane;
+    av[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (c + 4 <= LDC) av[t] = *(const f32x4 *)(ad + c);
   }
-  __syncthreads();
+  const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const int R = (ROWPASS ? n0 : n1) + 1, Cn = (ROWPASS ? n1 : n0) + 1;
   const float norm = -log_c((float)(n0 + n1));
   for (; row < R; row += nw) {
     if (row + nw < R) load_row(row + nw, nxt);
@@ -388,12 +387,9 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
     for (int t = 0; t < 5; ++t) {
       const int c = 256 * t + 4 * lane;
       x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-      if (c < Cn) {
-        const f32x4 av = *(const f32x4 *)(sadd + c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c + r < Cn) { x[t][r] = cur[t][r] + av[r]; m = fmaxf(m, x[t][r]); }
-      }
+      for (int r = 0; r < 4; ++r)
+        if (c + r < Cn) { x[t][r] = cur[t][r] + av[t][r]; m = fmaxf(m, x[t][r]); }
     }
     m = bfly64_max(m);
     float s = 0.0f;
