@@ -319,6 +319,35 @@ def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
     assert res[1]["n_gpus"] == 1 and res[1]["value"] > 0.5 * res[0]["value"]
 
 
+def test_bench_json_line_follows_the_contract():
+    """one JSON line with the driver's keys, the roofline object of the dominant kernel and the cpu_baseline
+    object; `traffic` comes from the committed PMC summary"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                                  text=True, stderr=subprocess.DEVNULL)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 3 * 8 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] in (8000.0, 2500.0, 157.3)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert isinstance(r["traffic"], int) and r["traffic"] > 1e8
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and 0 < c["value"] < 50 and 1 <= c["cores"] <= 32 and c["sample"]
+    assert d["exact_mode"]["value"] > 100 and d["exact_mode"]["match_jaccard_fast_vs_exact"] > 0.99
+
+
 @pytest.mark.parametrize("kw,its", [(dict(seed=0, noise=0.0, outliers=40), 200), (dict(seed=2, noise=0.3, outliers=40), 200),
                                     (dict(seed=1, planar=True, outliers=20), 200),
                                     (dict(seed=33, planar=True, outliers=10, noise=0.1), 5),     # homography branch
