@@ -128,3 +128,23 @@ def projection_scene(seed, K=400, M=300, W=640, H=480, duplicates=True):
     valid = (rng.uniform(size=M) > 0.05).astype(np.uint8)
     occupied = (rng.uniform(size=K) < 0.1).astype(np.uint8)
     return dict(cam=(fx, fy, cx, cy), size=(W, H), pose=pose, feat=feat, pos=pos, desc=md, valid=valid, occupied=occupied)
+
+
+def sg_golden_features(n, planted, seed):
+    """the two feature sets of tests/golden/sg_n*.npz (shared with tests/golden/make_golden.py so that the larger
+    fixtures only store the seed): random unit descriptors, `planted` true correspondences shifted by 5 px"""
+    rng = np.random.default_rng(seed)
+
+    def mk():
+        f = np.zeros((n, 259))
+        f[:, 0] = rng.uniform(0.001, 1, n).astype(np.float32)
+        f[:, 1] = rng.integers(4, 636, n)
+        f[:, 2] = rng.integers(4, 476, n)
+        dd = rng.standard_normal((n, 256))
+        f[:, 3:] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+        return f
+
+    f0, f1 = mk(), mk()
+    f1[:planted, 3:] = f0[:planted, 3:]
+    f1[:planted, 1:3] = f0[:planted, 1:3] + 5
+    return f0, f1

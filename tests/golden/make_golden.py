@@ -12,6 +12,7 @@ Fixtures are DATA (inputs + expected outputs), never reference source:
   sp_sparse_376x1241.npz same at the KITTI size (valid width 1240)
   sp_sparse_480x640.npz same at the size of BASELINE.json's headline configuration
   sg_n96.npz            two feature sets and the (n0+1)x(n1+1) log-assignment
+  sg_n320.npz           same at n = 320 (features regenerated from the stored seed: conftest.sg_golden_features)
 The seeded synthetic weights are regenerated bit-exactly by synth.py.
 """
 import importlib.util
@@ -27,6 +28,8 @@ spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ur-mv
 synth = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(synth)
 import model  # noqa: E402  (reference graph)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import sg_golden_features  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -88,7 +91,9 @@ def main():
                             n_candidates=np.int32(int((s.astype(np.float64) > 0.0005).sum())))
         print(H, W, "K", len(xs), "cands", int((s > 0.0005).sum()))
 
-    if os.path.exists(os.path.join(OUT, "sg_n96.npz")) and "--force" not in sys.argv:
+    sg_cases = [(96, 40, 7, "sg_n96.npz"), (320, 150, 8, "sg_n320.npz")]
+    sg_cases = [c for c in sg_cases if "--force" in sys.argv or not os.path.exists(os.path.join(OUT, c[3]))]
+    if not sg_cases:
         return
     # ---- SuperGlue: public architecture (transformers) with the synthetic weights
     from transformers.models.superglue import modeling_superglue as MS
@@ -125,41 +130,32 @@ def main():
             g.mlp[1].weight.copy_(T(W1)); g.mlp[1].bias.copy_(T(b1))
         Wf, bf = w["final"]
         fin.final_proj.weight.copy_(T(Wf)); fin.final_proj.bias.copy_(T(bf))
-    n = 96
-    rng = np.random.default_rng(7)
+    for (n, planted, seed, name) in sg_cases:
 
-    def mk():
-        f = np.zeros((n, 259))
-        f[:, 0] = rng.uniform(0.001, 1, n).astype(np.float32)
-        f[:, 1] = rng.integers(4, 636, n)
-        f[:, 2] = rng.integers(4, 476, n)
-        dd = rng.standard_normal((n, 256))
-        f[:, 3:] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
-        return f
+        f0, f1 = sg_golden_features(n, planted, seed)
 
-    f0, f1 = mk(), mk()
-    f1[:40, 3:] = f0[:40, 3:]
-    f1[:40, 1:3] = f0[:40, 1:3] + 5
+        def norm(f):  # src/point_matching.cc:63-76
+            g = f.copy()
+            g[:, 1] = (f[:, 1] - 640 // 2) / (640 * 0.7)
+            g[:, 2] = (f[:, 2] - 512 // 2) / (640 * 0.7)
+            return g
 
-    def norm(f):  # src/point_matching.cc:63-76
-        g = f.copy()
-        g[:, 1] = (f[:, 1] - 640 // 2) / (640 * 0.7)
-        g[:, 2] = (f[:, 2] - 512 // 2) / (640 * 0.7)
-        return g
+        nf0, nf1 = norm(f0), norm(f1)
+        with torch.no_grad():
+            kp = T(np.stack([nf0[:, 1:3], nf1[:, 1:3]]).astype(np.float32))
+            sc = T(np.stack([nf0[:, 0], nf1[:, 0]]).astype(np.float32))
+            ds = T(np.stack([nf0[:, 3:], nf1[:, 3:]]).astype(np.float32))
+            enc, _ = kenc(kp, sc)
+            x, _, _ = gnn(ds + enc, mask=None)
+            pr = fin(x)
+            S = pr[0:1] @ pr[1:2].transpose(1, 2) / 16.0
+            Z = MS.log_optimal_transport(S, torch.tensor(float(w["bin_score"])), 100)[0].numpy()
+        np.savez_compressed(os.path.join(OUT, name), **({} if n > 96 else dict(f0=f0, f1=f1)),   # larger: regenerated from the seed
+                            n=np.int32(n), seed=np.int32(seed), Z=Z.astype(np.float32),
+                            final0=pr[0].numpy().astype(np.float16 if n > 96 else np.float32),
+                            final1=pr[1].numpy().astype(np.float16 if n > 96 else np.float32), planted=np.int32(planted))
+        print(name, "Z range", Z.min(), Z.max())
 
-    nf0, nf1 = norm(f0), norm(f1)
-    with torch.no_grad():
-        kp = T(np.stack([nf0[:, 1:3], nf1[:, 1:3]]).astype(np.float32))
-        sc = T(np.stack([nf0[:, 0], nf1[:, 0]]).astype(np.float32))
-        ds = T(np.stack([nf0[:, 3:], nf1[:, 3:]]).astype(np.float32))
-        enc, _ = kenc(kp, sc)
-        x, _, _ = gnn(ds + enc, mask=None)
-        pr = fin(x)
-        S = pr[0:1] @ pr[1:2].transpose(1, 2) / 16.0
-        Z = MS.log_optimal_transport(S, torch.tensor(float(w["bin_score"])), 100)[0].numpy()
-    np.savez_compressed(os.path.join(OUT, "sg_n96.npz"), f0=f0, f1=f1, Z=Z.astype(np.float32),
-                        final0=pr[0].numpy(), final1=pr[1].numpy())
-    print("sg Z range", Z.min(), Z.max())
 
 
 if __name__ == "__main__":

@@ -176,9 +176,12 @@ def test_superglue_bit_exact_vs_oracle(F, O, sg_blob, n0, n1, seed):
     assert np.array_equal(m0, om0) and np.array_equal(m1, om1)
 
 
-def test_superglue_vs_public_architecture_golden(F, O, sg_blob):
-    g = golden("sg_n96.npz")
-    nf0, nf1 = O.sg_normalize(g["f0"], 640, 512), O.sg_normalize(g["f1"], 640, 512)
+@pytest.mark.parametrize("name", ["sg_n96.npz", "sg_n320.npz"])
+def test_superglue_vs_public_architecture_golden(F, O, sg_blob, name):
+    from conftest import sg_golden_features
+    g = golden(name)
+    f0, f1 = (g["f0"], g["f1"]) if "f0" in g else sg_golden_features(int(g["n"]), int(g["planted"]), int(g["seed"]))
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
     sg = F.SuperGlue(F.SuperGlueConfig())
     assert sg.build(sg_blob)
     i0, i1, m0, m1, Z = sg.infer(nf0, nf1, want_scores=True)

@@ -131,19 +131,24 @@ def test_sp_postprocess_edge_cases(O, sp_blob):
     assert [(int(r[1]), int(r[2])) for r in f] == [(10, 10), (30, 10)]
 
 
-def test_sg_graph_matches_public_architecture(O, sg_blob):
+@pytest.mark.parametrize("name", ["sg_n96.npz", "sg_n320.npz"])
+def test_sg_graph_matches_public_architecture(O, sg_blob, name):
     """oracle SuperGlue vs the transformers implementation of the public graph
-    (fixture sg_n96.npz).  The reference's own graph is missing: unpinned."""
-    g = golden("sg_n96.npz")
-    nf0, nf1 = O.sg_normalize(g["f0"], 640, 512), O.sg_normalize(g["f1"], 640, 512)
+    (fixtures sg_n96.npz, sg_n320.npz).  The reference's own graph is missing: unpinned."""
+    from conftest import sg_golden_features
+    g = golden(name)
+    f0, f1 = (g["f0"], g["f1"]) if "f0" in g else sg_golden_features(int(g["n"]), int(g["planted"]), int(g["seed"]))
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
     Z, m0, m1 = O.sg_graph(sg_blob, 100, nf0, nf1, want_final=True)
-    scale = np.abs(g["final0"]).max()
-    assert np.abs(m0 - g["final0"]).max() < 1e-5 * scale and np.abs(m1 - g["final1"]).max() < 1e-5 * scale
+    scale = np.abs(g["final0"].astype(np.float32)).max()
+    tol = 1e-5 if g["final0"].dtype == np.float32 else 1e-3          # the larger fixture stores f16 projections
+    assert np.abs(m0 - g["final0"]).max() < tol * scale and np.abs(m1 - g["final1"]).max() < tol * scale
     assert np.abs(Z - g["Z"]).max() < 1e-3
     i0, i1, ms0, ms1 = O.sg_decode(Z, 0.5)
     j0, j1, _, _ = O.sg_decode(g["Z"], 0.5)
     assert np.array_equal(i0, j0) and np.array_equal(i1, j1)
-    assert (i0[:40] == np.arange(40)).sum() >= 38   # planted matches are found
+    planted = int(g["planted"]) if "planted" in g else 40
+    assert (i0[:planted] == np.arange(planted)).sum() >= planted - 2 - planted // 50   # planted matches are found
 
 
 def test_sg_decode_follows_reference_semantics(O):
