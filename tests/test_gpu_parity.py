@@ -83,19 +83,27 @@ def test_superpoint_full_size_640x480_and_kitti(U, O, sp_blob, sp640):
         assert np.abs(np.linalg.norm(feat[:, 3:], axis=1) - 1).max() < 1e-12
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz", "sp_sparse_480x640.npz"])
-def test_superpoint_vs_reference_graph_golden(F, sp_blob, name):
-    """HIP output vs the torch run of the reference's model.py (committed fixture)."""
+def test_superpoint_vs_reference_graph_golden(F, sp_blob, name, prec):
+    """HIP output vs the torch run of the reference's model.py (committed fixture).  Exact mode: the same
+    keypoint set.  Fast mode (not bit-reproducible): at most 1 % of the keypoints may differ -- scores that
+    are near-ties at the top-k cut or at the threshold -- and every common keypoint is within tolerance."""
     g = golden(name)
     H, W = g["image"].shape
-    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=int(g["k"])), max_height=H, max_width=W)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=int(g["k"])), max_height=H, max_width=W, precision=prec)
     assert sp.build(sp_blob)
     f = sp.infer(g["image"])
     ko = {(int(r[1]), int(r[2])): j for j, r in enumerate(f)}
-    assert set(ko) == {(int(x), int(y)) for x, y in zip(g["x"], g["y"])}            # same keypoint set
-    perm = np.array([ko[(int(x), int(y))] for x, y in zip(g["x"], g["y"])])
-    np.testing.assert_allclose(f[perm, 0], g["score"], rtol=1e-3, atol=1e-5)
-    assert np.abs(f[perm, 3:] - g["desc"].astype(np.float64)).max() < 1e-3
+    want = {(int(x), int(y)): j for j, (x, y) in enumerate(zip(g["x"], g["y"]))}
+    if prec == 0:
+        assert set(ko) == set(want)                                                   # same keypoint set
+    else:
+        assert len(set(ko) ^ set(want)) <= 0.01 * len(want)
+    common = sorted(set(ko) & set(want))
+    pf = np.array([ko[c] for c in common]); pg = np.array([want[c] for c in common])
+    np.testing.assert_allclose(f[pf, 0], g["score"][pg], rtol=1e-3, atol=1e-5)
+    assert np.abs(f[pf, 3:] - g["desc"][pg].astype(np.float64)).max() < 1e-3
 
 
 def test_superpoint_dense_golden(F, sp_blob):
@@ -176,13 +184,16 @@ def test_superglue_bit_exact_vs_oracle(F, O, sg_blob, n0, n1, seed):
     assert np.array_equal(m0, om0) and np.array_equal(m1, om1)
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("name", ["sg_n96.npz", "sg_n320.npz"])
-def test_superglue_vs_public_architecture_golden(F, O, sg_blob, name):
+def test_superglue_vs_public_architecture_golden(F, O, sg_blob, name, prec):
+    """both precision modes against the public implementation's log-assignment (north_star: scores within
+    1e-3, match indices identical)"""
     from conftest import sg_golden_features
     g = golden(name)
     f0, f1 = (g["f0"], g["f1"]) if "f0" in g else sg_golden_features(int(g["n"]), int(g["planted"]), int(g["seed"]))
     nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
-    sg = F.SuperGlue(F.SuperGlueConfig())
+    sg = F.SuperGlue(F.SuperGlueConfig(), precision=prec)
     assert sg.build(sg_blob)
     i0, i1, m0, m1, Z = sg.infer(nf0, nf1, want_scores=True)
     assert np.abs(Z - g["Z"]).max() < 1e-3                          # north_star tolerance on the score tensor
