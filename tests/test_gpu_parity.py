@@ -664,3 +664,21 @@ def test_fast_mode_degenerate_keypoint_counts(F, sg_blob):
     assert len(m) <= 1 and all(np.isfinite(d) for _, _, d in m)
     m = pmf.MatchingPoints(f1, f1, False)
     assert len(m) >= 60 and all(q == t and np.isfinite(d) for q, t, d in m)
+
+
+def test_first_call_on_a_fresh_handle_is_not_racing_the_arena_memset(U, F, sp_blob, sg_blob):
+    """regression: build() zeroes the arena with hipMemset on the null stream, the handle works on a non-blocking
+    stream; without a device synchronisation at the end of build() the first call of a handle created while the
+    GPU is busy could run before its buffers were cleared (observed: 0 matches for the first pair)"""
+    frames = U.synth.shift_stream(100, 4, 480, 640)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=480, max_width=640, precision=1)
+    assert sp.build(sp_blob)
+    f = [sp.infer(x) for x in frames]
+    ref = None
+    for rep in range(4):
+        pm0 = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=8, precision=rep & 1)
+        assert pm0.build(sg_blob)                       # big arena (8 pairs) right before the first call
+        first = pm0.MatchingPoints(f[rep % 3], f[rep % 3 + 1], False)
+        again = pm0.MatchingPoints(f[rep % 3], f[rep % 3 + 1], False)
+        assert first == again and len(first) > 600, (rep, len(first), len(again))
+        del pm0

@@ -97,6 +97,7 @@ extern "C" int urf_fe_build(urf_fe *h, const float *sp_blob, size_t sp_floats, c
   URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
   h->ev_K.resize(h->NB);
   for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  URF_HIP(hipDeviceSynchronize());   // the null-stream memset above is not ordered against the handles' streams
   h->built = true;
   return 0;
 }
@@ -114,6 +115,7 @@ extern "C" int urf_fe_build_files(urf_fe *h, const char *sp_engine_file, const c
   URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
   h->ev_K.resize(h->NB);
   for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  URF_HIP(hipDeviceSynchronize());   // the null-stream memset above is not ordered against the handles' streams
   h->built = true;
   return 0;
 }

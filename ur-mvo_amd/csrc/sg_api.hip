@@ -307,6 +307,9 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_HIP(hipHostMalloc((void **)&h->h_slotptrs, NI * sizeof(float *), hipHostMallocDefault));
   for (int i = 0; i <= PT_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
   for (int i = 0; i < 18; ++i) { URF_HIP(hipEventCreate(&h->ev_attn[i][0])); URF_HIP(hipEventCreate(&h->ev_attn[i][1])); }
+  // the arena was zeroed with hipMemset on the null stream, which the handle's non-blocking stream does not wait
+  // for: without this a first call could run before (or while) its buffers are being cleared
+  URF_HIP(hipDeviceSynchronize());
   h->built = true;
   return 0;
 }

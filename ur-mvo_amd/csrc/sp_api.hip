@@ -272,6 +272,9 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   for (int k = 0; k < 4; ++k)
     for (int i = 0; i <= ST_COUNT; ++i) URF_HIP(hipEventCreate(&h->evs[k][i]));
   h->ev = h->evs[0];
+  // the arena was zeroed with hipMemset on the null stream, which the handle's non-blocking stream does not wait
+  // for: without this a first call could run before (or while) its buffers are being cleared
+  URF_HIP(hipDeviceSynchronize());
   h->built = true;
   return 0;
 }
