@@ -222,11 +222,39 @@ static float check_F(const float *F, const float *p0, const float *p1, int n, fl
   return om_bfly64_sum(part);
 }
 
-float oransac_find_F(const float *pts0, const float *pts1, int n, const oransac_config *cfg,
+/* Canonical order of the correspondences (written spec, DESIGN.md "RANSAC"): the sampler, the
+ * normalisation sums and the score sums walk the matches sorted by (x0, y0, x1, y1) -- float values
+ * compared through their order-preserving integer images, original index as the last key -- so that the
+ * result does not depend on the order in which the matcher lists them (keypoints are score-sorted, and
+ * near-tied scores may swap between arithmetic variants).  The inlier flags are per correspondence and
+ * come out in the caller's order. */
+static uint32_t okey(float f) { uint32_t u = om_f2bits(f); return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u); }
+typedef struct { uint32_t k[4]; int idx; } rs_ent;
+static int rs_cmp(const void *a, const void *b) {
+  const rs_ent *x = (const rs_ent *)a, *y = (const rs_ent *)b;
+  for (int i = 0; i < 4; ++i)
+    if (x->k[i] != y->k[i]) return x->k[i] < y->k[i] ? -1 : 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+float oransac_find_F(const float *pts0_in, const float *pts1_in, int n, const oransac_config *cfg,
                      uint8_t *inliers, float *F21) {
   for (int i = 0; i < n; ++i) inliers[i] = 0;
   for (int k = 0; k < 9; ++k) F21[k] = 0.0f;
   if (n < 8) return 0.0f;
+  rs_ent *ent = (rs_ent *)malloc(sizeof(rs_ent) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    ent[i].k[0] = okey(pts0_in[2 * i]); ent[i].k[1] = okey(pts0_in[2 * i + 1]);
+    ent[i].k[2] = okey(pts1_in[2 * i]); ent[i].k[3] = okey(pts1_in[2 * i + 1]);
+    ent[i].idx = i;
+  }
+  qsort(ent, (size_t)n, sizeof(rs_ent), rs_cmp);
+  float *pts0 = (float *)malloc(8 * (size_t)n), *pts1 = (float *)malloc(8 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    pts0[2 * i] = pts0_in[2 * ent[i].idx]; pts0[2 * i + 1] = pts0_in[2 * ent[i].idx + 1];
+    pts1[2 * i] = pts1_in[2 * ent[i].idx]; pts1[2 * i + 1] = pts1_in[2 * ent[i].idx + 1];
+  }
+  free(ent);
   float *pn0 = (float *)malloc(8 * (size_t)n), *pn1 = (float *)malloc(8 * (size_t)n);
   float T1[9], T2[9], T2t[9];
   normalize_pts(pts0, n, pn0, T1);
@@ -256,9 +284,9 @@ float oransac_find_F(const float *pts0, const float *pts1, int n, const oransac_
     if (sc[it] > best) { best = sc[it]; best_it = it; } /* strict >, first wins :197 */
   if (best_it >= 0) {
     for (int k = 0; k < 9; ++k) F21[k] = Fall[9 * (size_t)best_it + k];
-    check_F(F21, pts0, pts1, n, cfg->sigma, inliers);
+    check_F(F21, pts0_in, pts1_in, n, cfg->sigma, inliers);   /* per-point test, caller's order */
   }
-  free(pn0); free(pn1); free(Fall); free(sc);
+  free(pn0); free(pn1); free(Fall); free(sc); free(pts0); free(pts1);
   return best;
 }
 

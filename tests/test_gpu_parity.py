@@ -682,3 +682,22 @@ def test_first_call_on_a_fresh_handle_is_not_racing_the_arena_memset(U, F, sp_bl
         again = pm0.MatchingPoints(f[rep % 3], f[rep % 3 + 1], False)
         assert first == again and len(first) > 600, (rep, len(first), len(again))
         del pm0
+
+
+def test_ransac_does_not_depend_on_the_order_of_the_matches(F, O, pm):
+    """the sampler and every order-dependent float sum walk the correspondences in canonical (sorted) order:
+    permuting the match list permutes the inlier flags and nothing else -- on the GPU and in the oracle"""
+    from conftest import two_view_scene
+    _, k1, k2, m12, _, _ = two_view_scene(seed=5, noise=0.4, outliers=60)
+    sel = np.where(m12 >= 0)[0]
+    p0, p1 = k1[sel], k2[m12[sel]]
+    n = len(p0)
+    cfg = O.RansacConfig(200, 1.0, 0)
+    s_ref, inl_ref, F_ref = pm.find_F(p0, p1)
+    so, io, Fo = O.ransac_find_F(p0, p1, cfg)
+    assert s_ref == so and np.array_equal(inl_ref, io) and np.array_equal(F_ref, Fo.reshape(3, 3)) and 200 < inl_ref.sum() < n
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        perm = rng.permutation(n)
+        s, inl, Fm = pm.find_F(p0[perm], p1[perm])
+        assert s == s_ref and np.array_equal(Fm, F_ref) and np.array_equal(inl, inl_ref[perm])

@@ -197,6 +197,60 @@ __device__ __forceinline__ float wave_sum_strided(const float *x, int stride, in
   return bfly64_sum(a);
 }
 
+// Canonical order of the correspondences (DESIGN.md "RANSAC"): normalisation sums, the sampler and the score
+// sums walk the matches sorted by (x0, y0, x1, y1) (floats through their order-preserving integer images,
+// original index last), so the outcome does not depend on the order in which the matcher lists them.
+// One workgroup per pair: bitonic sort of <= 1024 (key, index) entries in LDS, sorted copies of the points out.
+__device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__global__ void __launch_bounds__(1024) ransac_sort_kernel(const int *nmatch, const float *pts0, const float *pts1,
+                                                           float *ps0, float *ps1) {
+  __shared__ uint32_t k0[RNP], k1[RNP], k2[RNP], k3[RNP];
+  __shared__ int id[RNP];
+  const int p = blockIdx.x, i = threadIdx.x;
+  const int n = nmatch[p];
+  if (n < 8) return;
+  const float *q0 = pts0 + (size_t)p * RNP * 2, *q1 = pts1 + (size_t)p * RNP * 2;
+  if (i < n) {
+    k0[i] = order_key(q0[2 * i]); k1[i] = order_key(q0[2 * i + 1]);
+    k2[i] = order_key(q1[2 * i]); k3[i] = order_key(q1[2 * i + 1]);
+  } else {
+    k0[i] = k1[i] = k2[i] = k3[i] = 0xffffffffu;     // padding sorts behind every real entry (index >= n breaks ties)
+  }
+  id[i] = i;
+  __syncthreads();
+  for (int k = 2; k <= RNP; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = i ^ j;
+      if (o > i) {
+        const bool up = (i & k) == 0;
+        bool gt;   // entry i > entry o ?
+        if (k0[i] != k0[o]) gt = k0[i] > k0[o];
+        else if (k1[i] != k1[o]) gt = k1[i] > k1[o];
+        else if (k2[i] != k2[o]) gt = k2[i] > k2[o];
+        else if (k3[i] != k3[o]) gt = k3[i] > k3[o];
+        else gt = id[i] > id[o];
+        if (gt == up) {
+          uint32_t t;
+          t = k0[i]; k0[i] = k0[o]; k0[o] = t;
+          t = k1[i]; k1[i] = k1[o]; k1[o] = t;
+          t = k2[i]; k2[i] = k2[o]; k2[o] = t;
+          t = k3[i]; k3[i] = k3[o]; k3[o] = t;
+          const int ti = id[i]; id[i] = id[o]; id[o] = ti;
+        }
+      }
+      __syncthreads();
+    }
+  if (i < n) {
+    const int src = id[i];
+    float *s0 = ps0 + (size_t)p * RNP * 2, *s1 = ps1 + (size_t)p * RNP * 2;
+    s0[2 * i] = q0[2 * src]; s0[2 * i + 1] = q0[2 * src + 1];
+    s1[2 * i] = q1[2 * src]; s1[2 * i + 1] = q1[2 * src + 1];
+  }
+}
+
 // _normalize (:735-780); wave 0 = image 1 points, wave 1 = image 2 points
 __global__ void __launch_bounds__(128) ransac_normalize_kernel(const int *nmatch, const float *pts0,
                                                                const float *pts1, float *pn0, float *pn1,
@@ -543,14 +597,17 @@ int launch_epipolar_search(const float *keys1, int n1, const float *keys2, int n
   return 0;
 }
 
-int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *pn0, float *pn1, float *T, float *F,
-                  float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
-                  int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st) {
+int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
+                  float *pn1, float *T, float *F, float *score, uint32_t seed, int iters, float sigma, int enable,
+                  const void *matches, void *out, int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P,
+                  hipStream_t st) {
   if (enable) {
-    hipLaunchKernelGGL(ransac_normalize_kernel, dim3(P), dim3(128), 0, st, nmatch, pts0, pts1, pn0, pn1, T);
+    // ps0 / ps1: the correspondences in canonical order; the final per-point inlier test runs on the caller's order
+    hipLaunchKernelGGL(ransac_sort_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, ps0, ps1);
+    hipLaunchKernelGGL(ransac_normalize_kernel, dim3(P), dim3(128), 0, st, nmatch, ps0, ps1, pn0, pn1, T);
     hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, P), dim3(64), 0, st, nmatch, pn0, pn1, T, seed, iters,
                        F);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, P), dim3(256), 0, st, nmatch, pts0, pts1, F, sigma,
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, P), dim3(256), 0, st, nmatch, ps0, ps1, F, sigma,
                        iters, score);
   }
   hipLaunchKernelGGL(ransac_select_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, F, score, sigma, iters,

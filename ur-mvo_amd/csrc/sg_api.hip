@@ -26,7 +26,7 @@ int launch_decode(const int *counts, const float *C, const float *Ct, const floa
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int P,
                   hipStream_t st);
-int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *pn0, float *pn1, float *T, float *F,
+int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0, float *pn1, float *T, float *F,
                   float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
                   int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st);
 
@@ -69,6 +69,7 @@ struct urf_pm {
   float *mv0 = nullptr, *mv1 = nullptr;
   double *ms0 = nullptr, *ms1 = nullptr;
   urf_dmatch *matches = nullptr, *fmatches = nullptr;
+  float *ps0 = nullptr, *ps1 = nullptr;   // RANSAC: correspondences in canonical (sorted) order
   float *pts0 = nullptr, *pts1 = nullptr, *pn0 = nullptr, *pn1 = nullptr, *T = nullptr, *F = nullptr, *score = nullptr,
         *Fbest = nullptr, *best_score = nullptr;
   uint8_t *inliers = nullptr;
@@ -293,6 +294,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->nfinal, P)) return -1;
   if (dalloc(&h->pts0, P * NP * 2)) return -1;
   if (dalloc(&h->pts1, P * NP * 2)) return -1;
+  if (dalloc(&h->ps0, P * NP * 2)) return -1;
+  if (dalloc(&h->ps1, P * NP * 2)) return -1;
   if (dalloc(&h->pn0, P * NP * 2)) return -1;
   if (dalloc(&h->pn1, P * NP * 2)) return -1;
   if (dalloc(&h->T, P * 18)) return -1;
@@ -328,7 +331,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->mh, h->ml, h->hh, h->hl,
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
-                    h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F,
+                    h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs};
     for (void *p : bufs) (void)hipFree(p);
     (void)hipHostFree(h->h_matches);
@@ -463,7 +466,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
                     want_Z ? h->Z : nullptr, P, st))
     return -1;
   mark(PT_RANSAC);
-  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
                     h->r_sigma, ransac ? 1 : 0, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest,
                     h->best_score, P, st))
     return -1;
@@ -638,7 +641,7 @@ extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1
   URF_HIP(hipMemcpyAsync(h->pts0, pts0, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
   URF_HIP(hipMemcpyAsync(h->pts1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
-  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
                     h->r_sigma, 1, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, 1, h->st))
     return -1;
   URF_HIP(hipMemcpyAsync(inliers, h->inliers, n, hipMemcpyDeviceToHost, h->st));
