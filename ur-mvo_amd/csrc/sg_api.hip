@@ -56,10 +56,10 @@ struct urf_pm {
   // fast precision mode (split-f16 MFMA): transposed weights as hi/lo f16 planes
   int precision = 0;
   _Float16 *d_wh = nullptr, *d_wl = nullptr;
-  struct { size_t qk, v, m, w1, w2; } H[18];
+  struct { size_t qk, v, w1, w2; } H[18];   // w1: first MLP layer with the merge layer folded in
   size_t hwf = 0;
   _Float16 *xh = nullptr, *xl = nullptr, *qkh = nullptr, *qkl = nullptr, *vth = nullptr, *vtl = nullptr, *oh = nullptr,
-           *ol = nullptr, *mh = nullptr, *ml = nullptr, *hh = nullptr, *hl = nullptr;
+           *ol = nullptr, *hh = nullptr, *hl = nullptr;
   // activations
   int *counts = nullptr;
   float *kin = nullptr, *kxy = nullptr, *x = nullptr, *tA = nullptr, *tB = nullptr, *qkv = nullptr, *o = nullptr,
@@ -223,7 +223,6 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       }
       putT(wk, 256, 256);                 // rows 256..511 of the fused [512][256] matrix
       h->H[l].v = putT(wv, 256, 256);
-      h->H[l].m = putT(wm, 256, 256);
       {  // first MLP layer with the merge layer folded in: input = [x (256) ; attention output o (256, head-major)]
         std::vector<double> wc((size_t)512 * 512);   // [cin][cout]
         for (int c = 0; c < 256; ++c)
@@ -260,7 +259,6 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     if (dalloc(&h->qkh, NI * NP * 512) || dalloc(&h->qkl, NI * NP * 512)) return -1;
     if (dalloc(&h->vth, NI * NP * 256) || dalloc(&h->vtl, NI * NP * 256)) return -1;
     if (dalloc(&h->oh, NI * NP * 256) || dalloc(&h->ol, NI * NP * 256)) return -1;
-    if (dalloc(&h->mh, NI * NP * 256) || dalloc(&h->ml, NI * NP * 256)) return -1;
     if (dalloc(&h->hh, NI * NP * 512) || dalloc(&h->hl, NI * NP * 512)) return -1;
   }
   if (dalloc(&h->counts, NI)) return -1;
@@ -328,7 +326,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
-    void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->mh, h->ml, h->hh, h->hl,
+    void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->hh, h->hl,
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
