@@ -17,6 +17,15 @@
 #endif
 #include "urf.h"
 
+#ifndef URF_SHIM_PRECISION_DEFINED
+#define URF_SHIM_PRECISION_DEFINED
+#include <cstdlib>
+inline int urf_shim_precision() {   // URF_PRECISION = 0 (exact, default) | 1 (fast); see super_point.h
+  const char *e = std::getenv("URF_PRECISION");
+  return (e && e[0] == '1') ? 1 : 0;
+}
+#endif
+
 class SuperGlue {
  public:
   explicit SuperGlue(const SuperGlueConfig &superglue_config) : superglue_config_(superglue_config) {}
@@ -68,6 +77,7 @@ class SuperGlue {
     c.image_width = superglue_config_.image_width;
     c.image_height = superglue_config_.image_height;
     c.matching_threshold = superglue_config_.matching_threshold;
+    c.precision = urf_shim_precision();
     if (urf_pm_create(&c, &h_) != 0) { report("create"); return false; }
     return true;
   }

@@ -22,6 +22,18 @@
 #endif
 #include "urf.h"
 
+// Precision mode of the handles the shims create (the reference's config structs have no such field):
+// environment variable URF_PRECISION = 0 (exact fp32, bit-identical to the oracle; default) or 1 (fast:
+// split-f16 matrix-core path, fp32-equivalent accuracy, ~2.5x the throughput).
+#ifndef URF_SHIM_PRECISION_DEFINED
+#define URF_SHIM_PRECISION_DEFINED
+#include <cstdlib>
+inline int urf_shim_precision() {
+  const char *e = std::getenv("URF_PRECISION");
+  return (e && e[0] == '1') ? 1 : 0;
+}
+#endif
+
 class SuperPoint {
  public:
   explicit SuperPoint(const SuperPointConfig &super_point_config) : super_point_config_(super_point_config) {}
@@ -38,7 +50,7 @@ class SuperPoint {
     c.keypoint_threshold = super_point_config_.keypoint_threshold;
     c.remove_borders = super_point_config_.remove_borders;
     c.max_height = 1500; c.max_width = 1500;  // TensorRT profile maximum, :55-60
-    c.max_batch = 1; c.device = 0;
+    c.max_batch = 1; c.device = 0; c.precision = urf_shim_precision();
     if (urf_sp_create(&c, &h_) != 0) { report("create"); return false; }
     if (!deserialize_engine()) { urf_sp_destroy(h_); h_ = nullptr; return false; }
     return true;
@@ -49,7 +61,7 @@ class SuperPoint {
     c.max_keypoints = super_point_config_.max_keypoints;
     c.keypoint_threshold = super_point_config_.keypoint_threshold;
     c.remove_borders = super_point_config_.remove_borders;
-    c.max_height = max_h; c.max_width = max_w; c.max_batch = 1; c.device = 0;
+    c.max_height = max_h; c.max_width = max_w; c.max_batch = 1; c.device = 0; c.precision = urf_shim_precision();
     if (urf_sp_create(&c, &h_) != 0) { report("create"); return false; }
     if (urf_sp_build(h_, blob, n_floats) != 0) { report("build"); urf_sp_destroy(h_); h_ = nullptr; return false; }
     return true;
