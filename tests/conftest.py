@@ -148,3 +148,17 @@ def sg_golden_features(n, planted, seed):
     f1[:planted, 3:] = f0[:planted, 3:]
     f1[:planted, 1:3] = f0[:planted, 1:3] + 5
     return f0, f1
+
+
+def check_sg_n1000(g, Z, i0, i1, m0, m1):
+    """a SuperGlue result at n = 1000 against tests/golden/sg_n1000.npz (public architecture run by
+    transformers, tests/golden/make_golden.py): every 8th row of the log-assignment and both dustbins within the
+    north_star tolerance 1e-3, the decode of the FULL tensor (indices) identical, matching scores within 1e-3"""
+    assert Z.shape == (1001, 1001)
+    assert np.abs(Z[::8] - g["Zrows"]).max() < 1e-3
+    assert np.abs(Z[-1] - g["Zbin_row"]).max() < 1e-3 and np.abs(Z[:, -1] - g["Zbin_col"]).max() < 1e-3
+    assert np.abs(Z[:-1, :-1].max(1) - g["rowmax"]).max() < 1e-3 and np.abs(Z[:-1, :-1].max(0) - g["colmax"]).max() < 1e-3
+    assert np.array_equal(i0, g["indices0"]) and np.array_equal(i1, g["indices1"])
+    assert np.abs(m0 - g["mscores0"]).max() < 1e-3 and np.abs(m1 - g["mscores1"]).max() < 1e-3
+    planted = int(g["planted"])
+    assert (i0[:planted] == np.arange(planted)).sum() >= planted - 2 - planted // 50

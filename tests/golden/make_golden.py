@@ -13,6 +13,9 @@ Fixtures are DATA (inputs + expected outputs), never reference source:
   sp_sparse_480x640.npz same at the size of BASELINE.json's headline configuration
   sg_n96.npz            two feature sets and the (n0+1)x(n1+1) log-assignment
   sg_n320.npz           same at n = 320 (features regenerated from the stored seed: conftest.sg_golden_features)
+  sg_n1000.npz          n = 1000 (the bench size): every 8th row of the log-assignment in f32 (Zrows), the full
+                        dustbin row/column, and the decode of the FULL tensor (indices0/1, mscores0/1 as
+                        src/super_glue.cpp:303-430 computes them) -- 0.6 MB instead of 4 MB
 The seeded synthetic weights are regenerated bit-exactly by synth.py.
 """
 import importlib.util
@@ -91,7 +94,7 @@ def main():
                             n_candidates=np.int32(int((s.astype(np.float64) > 0.0005).sum())))
         print(H, W, "K", len(xs), "cands", int((s > 0.0005).sum()))
 
-    sg_cases = [(96, 40, 7, "sg_n96.npz"), (320, 150, 8, "sg_n320.npz")]
+    sg_cases = [(96, 40, 7, "sg_n96.npz"), (320, 150, 8, "sg_n320.npz"), (1000, 600, 9, "sg_n1000.npz")]
     sg_cases = [c for c in sg_cases if "--force" in sys.argv or not os.path.exists(os.path.join(OUT, c[3]))]
     if not sg_cases:
         return
@@ -150,6 +153,24 @@ def main():
             pr = fin(x)
             S = pr[0:1] @ pr[1:2].transpose(1, 2) / 16.0
             Z = MS.log_optimal_transport(S, torch.tensor(float(w["bin_score"])), 100)[0].numpy()
+        if n >= 1000:
+            # decode of the full tensor, restated with numpy (src/super_glue.cpp:303-430): argmax over the inner block,
+            # first maximum wins, mutual check, exp, threshold 0.5
+            inner = Z[:-1, :-1]
+            a0, a1 = inner.argmax(1), inner.argmax(0)
+            mut0 = a1[a0] == np.arange(n)
+            ms0 = np.where(mut0, np.exp(inner[np.arange(n), a0].astype(np.float64)), 0.0)
+            i0 = np.where(mut0 & (ms0 > 0.5), a0, -1).astype(np.int32)
+            mut1 = a0[a1] == np.arange(n)
+            ms1 = np.where(mut1, ms0[a1], 0.0)
+            i1 = np.where(mut1 & (i0[a1] >= 0), a1, -1).astype(np.int32)
+            np.savez_compressed(os.path.join(OUT, name), n=np.int32(n), seed=np.int32(seed), planted=np.int32(planted),
+                                Zrows=Z[::8].astype(np.float32), Zbin_row=Z[-1].astype(np.float32),
+                                Zbin_col=Z[:, -1].astype(np.float32), indices0=i0, indices1=i1,
+                                mscores0=ms0.astype(np.float32), mscores1=ms1.astype(np.float32),
+                                rowmax=inner.max(1).astype(np.float32), colmax=inner.max(0).astype(np.float32))
+            print(name, "matches", int((i0 >= 0).sum()), "Z range", Z.min(), Z.max())
+            continue
         np.savez_compressed(os.path.join(OUT, name), **({} if n > 96 else dict(f0=f0, f1=f1)),   # larger: regenerated from the seed
                             n=np.int32(n), seed=np.int32(seed), Z=Z.astype(np.float32),
                             final0=pr[0].numpy().astype(np.float16 if n > 96 else np.float32),

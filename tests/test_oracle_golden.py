@@ -151,6 +151,16 @@ def test_sg_graph_matches_public_architecture(O, sg_blob, name):
     assert (i0[:planted] == np.arange(planted)).sum() >= planted - 2 - planted // 50   # planted matches are found
 
 
+def test_sg_n1000_matches_public_architecture(O, sg_blob):
+    """the bench size: oracle SuperGlue at n = 1000 vs the transformers run (fixture sg_n1000.npz)"""
+    from conftest import check_sg_n1000, sg_golden_features
+    g = golden("sg_n1000.npz")
+    f0, f1 = sg_golden_features(int(g["n"]), int(g["planted"]), int(g["seed"]))
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
+    i0, i1, m0, m1, Z = O.sg_infer(sg_blob, O.SGConfig(640, 512, 0.5, 100), nf0, nf1)
+    check_sg_n1000(g, Z, i0, i1, m0, m1)
+
+
 def test_sg_decode_follows_reference_semantics(O):
     """decode() src/super_glue.cpp:401-430 vs a brute-force restatement."""
     rng = np.random.default_rng(3)
