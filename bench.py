@@ -437,7 +437,7 @@ def main():
             feats = [O.sp_infer(spb, ocfg, f) for f in fr]
             t_sp = (time.perf_counter() - t) / NS
             t = time.perf_counter()
-            oms = [O.match_points(sgb, O.SGConfig(640, 512, 0.5, 100), O.RansacConfig(200, 1.0, 0), feats[j], feats[j + 1], True)
+            oms = [O.match_points(sgb, O.SGConfig(640, 512, 0.5, 100), O.ref_ransac(), feats[j], feats[j + 1], True)
                    for j in range(NS - 1)]
             t_pm = (time.perf_counter() - t) / (NS - 1)
             cpu = {"value": round(1.0 / (t_sp + t_pm), 4), "unit": "frames/s", "cores": O.threads(),

@@ -98,14 +98,25 @@ typedef struct {
   int sinkhorn_iterations;    /* 0 -> 100 (src/super_glue.cpp:463) */
   int max_pairs;              /* pairs per batched call; 0 -> 1 */
   int device;
-  /* outlier stage: EpipolarGeometry(K, sigma=1.0, iterations=200), src/tracking.cc:52-55 */
-  int ransac_iterations;      /* 0 -> 200 */
-  float ransac_sigma;         /* 0 -> 1.0 */
+  /* outlier stage (replaces cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask),
+   * src/point_matching.cc:50, with the in-tree 8-point search of src/epipolar_geometry.cc:161-205) */
+  int ransac_iterations;      /* hypotheses at most; 0 -> 200 (EpipolarGeometry's default, src/tracking.cc:52-55) */
+  float ransac_sigma;         /* inlier gate as EpipolarGeometry states it: squared distance to the epipolar line
+                               * <= 3.841 sigma^2 in both images; 0 -> derived from ransac_threshold_px */
   uint32_t ransac_seed;
   /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the 18 GNN
    * layers run on the f16 matrix core with split operands (fp32-equivalent
    * accuracy, not bit-reproducible) */
   int precision;
+  /* the reference call's own parameters (appended fields; all-zero = the reference's values):
+   * ransac_threshold_px: distance to the epipolar line in pixels, findFundamentalMat's 3rd argument.  Used when
+   *   ransac_sigma == 0: sigma = px / sqrt(3.841), i.e. the same gate "both distances <= px"; 0 -> 3.0.
+   * ransac_confidence: findFundamentalMat's 4th argument.  The hypotheses are walked in order and every new
+   *   best one shrinks the number still evaluated to the smallest k with (1 - w^8)^k <= 1 - confidence
+   *   (w = its inlier ratio; OpenCV's RANSACUpdateNumIters for 8 model points).  0 -> 0.99; < 0 -> off: all
+   *   ransac_iterations hypotheses count (EpipolarGeometry::_find_F). */
+  float ransac_threshold_px;
+  float ransac_confidence;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -165,6 +176,19 @@ void *urf_pm_stream(urf_pm *h);
  * *score = best score, inliers n bytes, F21 9 floats row-major. */
 int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n,
                       uint8_t *inliers, float *F21, float *score);
+/* The same search over EXPLICIT minimal sets -- the reference's _vSets (src/epipolar_geometry.cc:52-71):
+ * sets[it*8 + j] indexes the n correspondences as given; the matches are walked in the caller's order (no
+ * canonical sort) and all `iterations` hypotheses count.  With the sets of urf_minimal_sets(URF_SAMPLER_GLIBC,
+ * 0, ...) this evaluates exactly the hypotheses of the reference's first reconstruct() call in a process. */
+int urf_ransac_find_F_sets(urf_pm *h, const float *pts0, const float *pts1, int n, const int *sets, int iterations,
+                           uint8_t *inliers, float *F21, float *score);
+/* Minimal-set samplers (host).  URF_SAMPLER_HASH: the counter hash of this build (order-independent, parallel).
+ * URF_SAMPLER_GLIBC: the reference's own stream -- Random::RandomInt over glibc rand() after srand(seed)
+ * (src/epipolar_geometry.cc:56-71,100-117; glibc's TYPE_3 additive feedback generator restated in
+ * epipolar_api.hip) with the swap-with-back draw without replacement.  sets: iterations x 8 indices < n. */
+#define URF_SAMPLER_HASH 0
+#define URF_SAMPLER_GLIBC 1
+int urf_minimal_sets(int sampler, uint32_t seed, int n, int iterations, int *sets);
 
 /* EpipolarGeometry(K, sigma, iterations) + reconstruct(vKeys1, vKeys2,
  * vMatches12, T21, vP3D, vbTriangulated), include/epipolar_geometry.h:20-40,
@@ -174,10 +198,51 @@ int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n,
  * homography won, 1 = the fundamental matrix; scores[2] = {SH, SF}.
  * Returns 1 if the initialisation is accepted, 0 if not, <0 on error.  The
  * explicit seed replaces the process-global srand(0) (:100-112). */
-typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; } urf_epi_config;
+typedef struct {
+  float K[9]; float sigma; int iterations; uint32_t seed;
+  int sampler;   /* 0 = URF_SAMPLER_HASH, the default; 1 = URF_SAMPLER_GLIBC, the rand stream of the reference restarted from the seed */
+} urf_epi_config;
 int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
                              const float *keys2, int n2, const int *matches12, float *T21,
                              float *P3D, uint8_t *triangulated, int *model, float *scores);
+/* same with explicit minimal sets (cfg->iterations x 8 indices into the list of valid matches, in vMatches12 order) */
+int urf_epipolar_reconstruct_sets(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
+                                  const float *keys2, int n2, const int *matches12, const int *sets, float *T21,
+                                  float *P3D, uint8_t *triangulated, int *model, float *scores);
+
+/* ------------------------------------------------------------- exchange (N GPUs) -- */
+/* The data-parallel layer around the path (SURVEY.md section 8 e): the caller of SuperPoint / PointMatching,
+ * Tracking::ExtractFeatureAndMatch (src/tracking.cc:338-377), sharded over the GPUs of one node.  Rank r (a
+ * process, or a device of one process) runs SuperPoint on frames [r*n, (r+1)*n) of a step, ONE all-gather of
+ * the feature slots (RCCL over xGMI) makes every frame's features local everywhere, rank r matches the pairs
+ * whose second frame it owns, and the match lists are gathered to the rank that runs the serial tracker.
+ * world == 1 without an id never touches RCCL (librccl is dlopen'ed by the first real communicator). */
+#define URF_COMM_ID_BYTES 128
+typedef struct urf_comm urf_comm;
+/* rank 0: ncclGetUniqueId; ship the 128 bytes to the other ranks over any host channel */
+int urf_comm_unique_id(void *id);
+/* one rank per process.  id == NULL is allowed for world == 1 only (plain device copies, no RCCL);
+ * with an id a world of one still runs the RCCL calls (tests) */
+int urf_comm_init(int world, int rank, int device, const void *id, urf_comm **out);
+/* one process driving ndev devices: out[i] is the communicator of devices[i] (ncclCommInitAll) */
+int urf_comm_init_all(int ndev, const int *devices, urf_comm **out);
+void urf_comm_destroy(urf_comm *c);
+int urf_comm_world(const urf_comm *c);
+int urf_comm_rank(const urf_comm *c);
+/* d_all[world * nslots] <- every rank's d_local[nslots] feature slots (urf_slot_bytes() each), in rank order =
+ * global frame order; enqueued on `stream` (hipStream_t): order it against urf_sp_stream / urf_pm_stream with
+ * events, the host never waits */
+int urf_comm_allgather_slots(urf_comm *c, const void *d_local, int nslots, void *d_all, void *stream);
+/* `root` receives every rank's `bytes` at d_recv + rank * bytes (device memory; e.g. the buffers of
+ * urf_pm_device_results); the other ranks may pass d_recv = NULL */
+int urf_comm_gather(urf_comm *c, const void *d_send, size_t bytes, void *d_recv, int root, void *stream);
+/* pairs (first[j], second[j]), j < per_rank, that `rank` matches in one step, as indices into the gathered
+ * slots (global frame g = rank * per_rank + j against g - 1); first[0] == -1 on rank 0 = the last frame of the
+ * previous step, carried by the caller.  Host-only. */
+int urf_comm_plan_pairs(int world, int rank, int per_rank, int *first, int *second);
+/* device buffers holding the last batch of a matcher: matches [max_pairs][URF_MAX_KEYPOINTS] urf_dmatch and
+ * counts [max_pairs] int (valid after the batch's kernels; order with urf_pm_stream) */
+int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */

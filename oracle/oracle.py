@@ -32,7 +32,17 @@ class SGConfig(C.Structure):
 
 
 class RansacConfig(C.Structure):
-    _fields_ = [("iterations", C.c_int), ("sigma", C.c_float), ("seed", C.c_uint32)]
+    """(iterations, sigma, seed, confidence): confidence <= 0 (default) = every hypothesis counts"""
+    _fields_ = [("iterations", C.c_int), ("sigma", C.c_float), ("seed", C.c_uint32), ("confidence", C.c_float)]
+
+
+SIGMA_3PX = float(np.float32(3.0 / np.sqrt(3.841)))   # the 3 px gate of the reference's cv::findFundamentalMat call
+
+
+def ref_ransac(iterations=200, seed=0):
+    """the outlier stage's defaults = the parameters of the reference call
+    cv::findFundamentalMat(..., cv::FM_RANSAC, 3, 0.99, mask), src/point_matching.cc:50"""
+    return RansacConfig(iterations, SIGMA_3PX, seed, 0.99)
 
 
 class DMatch(C.Structure):
@@ -64,6 +74,8 @@ def lib():
         _lib.o_log.argtypes = [C.c_float]
         _lib.o_wave_sum.restype = C.c_float
         _lib.oransac_find_F.restype = C.c_float
+        _lib.oransac_find_F_sets.restype = C.c_float
+        _lib.oransac_minimal_sets.restype = None
     return _lib
 
 
@@ -200,6 +212,25 @@ def ransac_find_F(p0, p1, cfg):
     return float(s), inl, F.reshape(3, 3)
 
 
+def minimal_sets(sampler, seed, n, iterations):
+    """sampler 0: counter hash; 1: the C library's srand(seed)/rand() stream the reference draws from"""
+    sets = np.zeros((iterations, 8), np.int32)
+    lib().oransac_minimal_sets(int(sampler), C.c_uint32(seed), int(n), int(iterations), _p(sets))
+    return sets
+
+
+def ransac_find_F_sets(p0, p1, cfg, sets):
+    p0 = np.ascontiguousarray(p0, np.float32)
+    p1 = np.ascontiguousarray(p1, np.float32)
+    sets = np.ascontiguousarray(sets, np.int32)
+    assert sets.shape == (cfg.iterations, 8)
+    n = p0.shape[0]
+    inl = np.zeros(n, np.uint8)
+    F = np.zeros(9, np.float32)
+    s = lib().oransac_find_F_sets(_p(p0), _p(p1), n, C.byref(cfg), _p(sets), _p(inl), _p(F))
+    return float(s), inl, F.reshape(3, 3)
+
+
 def match_points(sg_blob, cfg, rcfg, f0, f1, outlier_rejection=True):
     f0 = np.ascontiguousarray(f0, np.float64)
     f1 = np.ascontiguousarray(f1, np.float64)
@@ -224,12 +255,14 @@ def fma_gemm(A, B, C0=None):
 
 
 class EpiConfig(C.Structure):
-    _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32)]
+    _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32),
+                ("sampler", C.c_int)]
 
 
-def epi_reconstruct(K, keys1, keys2, matches12, sigma=1.0, iterations=200, seed=0):
-    """EpipolarGeometry::reconstruct.  Returns (ok, T21[4,4], P3D[n1,3], tri[n1], model, (SH, SF))."""
-    cfg = EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed)
+def epi_reconstruct(K, keys1, keys2, matches12, sigma=1.0, iterations=200, seed=0, sampler=0, sets=None):
+    """EpipolarGeometry::reconstruct.  Returns (ok, T21[4,4], P3D[n1,3], tri[n1], model, (SH, SF)).
+    sampler 1 = the reference's rand() stream; sets = explicit minimal sets [iterations, 8]."""
+    cfg = EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed, sampler)
     k1 = np.ascontiguousarray(keys1, np.float32)
     k2 = np.ascontiguousarray(keys2, np.float32)
     m = np.ascontiguousarray(matches12, np.int32)
@@ -239,7 +272,13 @@ def epi_reconstruct(K, keys1, keys2, matches12, sigma=1.0, iterations=200, seed=
     tri = np.zeros(n1, np.uint8)
     model = C.c_int(-1)
     sc = np.zeros(2, np.float32)
-    ok = lib().oepi_reconstruct(C.byref(cfg), _p(k1), n1, _p(k2), n2, _p(m), _p(T), _p(P), _p(tri), C.byref(model), _p(sc))
+    if sets is not None:
+        sets = np.ascontiguousarray(sets, np.int32)
+        assert sets.shape == (iterations, 8)
+        ok = lib().oepi_reconstruct_sets(C.byref(cfg), _p(k1), n1, _p(k2), n2, _p(m), _p(sets), _p(T), _p(P), _p(tri),
+                                         C.byref(model), _p(sc))
+    else:
+        ok = lib().oepi_reconstruct(C.byref(cfg), _p(k1), n1, _p(k2), n2, _p(m), _p(T), _p(P), _p(tri), C.byref(model), _p(sc))
     return bool(ok), T.reshape(4, 4), P, tri, model.value, (float(sc[0]), float(sc[1]))
 
 

@@ -52,6 +52,49 @@ static void draw_set(uint32_t seed, int it, int n, int set[8]) {
   }
 }
 
+/* sampler 0: the counter hash above; sampler 1: the reference's own stream -- the C library's srand(seed) and
+   rand() through Random::RandomInt (:100-117), drawn serially like the reference (:56-71).  NOT reentrant
+   (rand() is process-global, exactly the reference's situation). */
+void oransac_minimal_sets(int sampler, uint32_t seed, int n, int iterations, int *sets) {
+  if (sampler == 0) {
+    for (int it = 0; it < iterations; ++it) draw_set(seed, it, n, sets + 8 * it);
+    return;
+  }
+  srand(seed);
+  int *avail = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int it = 0; it < iterations; ++it) {
+    for (int i = 0; i < n; ++i) avail[i] = i;
+    int size = n;
+    for (int j = 0; j < 8; ++j) {
+      const int d = (size - 1) - 0 + 1;
+      const int randi = (int)(((double)rand() / ((double)RAND_MAX + 1.0)) * d) + 0;
+      sets[8 * it + j] = avail[randi];
+      avail[randi] = avail[size - 1];
+      --size;
+    }
+  }
+  free(avail);
+}
+
+/* hypotheses that count under a confidence-driven stop (spec: urf_oracle.h, oransac_config.confidence) */
+static int confident_prefix(const float *score, const int *ninl, int n, int iters, double confidence) {
+  int niters = iters;
+  float best = 0.0f;
+  for (int it = 0; it < iters && it < niters; ++it) {
+    if (score[it] > best) {
+      best = score[it];
+      const double wr = (double)ninl[it] / (double)n;
+      double w8 = wr * wr; w8 = w8 * w8; w8 = w8 * w8;
+      const double q = 1.0 - w8, tgt = 1.0 - confidence;
+      int k = 1;
+      double acc = q;
+      while (acc > tgt && k < iters) { acc = acc * q; ++k; }
+      if (k < niters) niters = k;
+    }
+  }
+  return niters;
+}
+
 /* cyclic Jacobi on a symmetric n x n (n<=9) matrix, double; V accumulates the
    rotations (columns = eigenvectors).  Fixed sweep count => data-independent
    control flow except the tiny-pivot skip. */
@@ -189,13 +232,18 @@ static void normalize_pts(const float *pts, int n, float *out, float T[9]) {
 
 /* _check_F :372-449, per-match terms; score summed in canonical wave order:
    lane l = matches l, l+64, ... each adding its chi terms in source order. */
-static float check_F(const float *F, const float *p0, const float *p1, int n, float sigma,
-                     uint8_t *inl) {
+static float check_F_count(const float *F, const float *p0, const float *p1, int n, float sigma, uint8_t *inl, int *count);
+static float check_F(const float *F, const float *p0, const float *p1, int n, float sigma, uint8_t *inl) {
+  return check_F_count(F, p0, p1, n, sigma, inl, NULL);
+}
+static float check_F_count(const float *F, const float *p0, const float *p1, int n, float sigma,
+                           uint8_t *inl, int *count) {
   const float f11 = F[0], f12 = F[1], f13 = F[2], f21 = F[3], f22 = F[4], f23 = F[5],
               f31 = F[6], f32 = F[7], f33 = F[8];
   const float th = 3.841f, thScore = 5.991f;
   const float invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));
   float part[64];
+  int cnt = 0;
   for (int l = 0; l < 64; ++l) {
     float score = 0.0f;
     for (int i = l; i < n; i += 64) {
@@ -216,9 +264,11 @@ static float check_F(const float *F, const float *p0, const float *p1, int n, fl
       const float chiSquare2 = squareDist2 * invSigmaSquare;
       if (chiSquare2 > th) bIn = 0; else score = score + (thScore - chiSquare2);
       if (inl) inl[i] = (uint8_t)bIn;
+      cnt += bIn;
     }
     part[l] = score;
   }
+  if (count) *count = cnt;
   return om_bfly64_sum(part);
 }
 
@@ -237,24 +287,28 @@ static int rs_cmp(const void *a, const void *b) {
   return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
-float oransac_find_F(const float *pts0_in, const float *pts1_in, int n, const oransac_config *cfg,
-                     uint8_t *inliers, float *F21) {
+static float find_F_impl(const float *pts0_in, const float *pts1_in, int n, const oransac_config *cfg, const int *sets,
+                         uint8_t *inliers, float *F21) {
   for (int i = 0; i < n; ++i) inliers[i] = 0;
   for (int k = 0; k < 9; ++k) F21[k] = 0.0f;
   if (n < 8) return 0.0f;
-  rs_ent *ent = (rs_ent *)malloc(sizeof(rs_ent) * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    ent[i].k[0] = okey(pts0_in[2 * i]); ent[i].k[1] = okey(pts0_in[2 * i + 1]);
-    ent[i].k[2] = okey(pts1_in[2 * i]); ent[i].k[3] = okey(pts1_in[2 * i + 1]);
-    ent[i].idx = i;
-  }
-  qsort(ent, (size_t)n, sizeof(rs_ent), rs_cmp);
   float *pts0 = (float *)malloc(8 * (size_t)n), *pts1 = (float *)malloc(8 * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    pts0[2 * i] = pts0_in[2 * ent[i].idx]; pts0[2 * i + 1] = pts0_in[2 * ent[i].idx + 1];
-    pts1[2 * i] = pts1_in[2 * ent[i].idx]; pts1[2 * i + 1] = pts1_in[2 * ent[i].idx + 1];
+  if (sets) {            /* explicit sets index the caller's order: no canonical sort */
+    memcpy(pts0, pts0_in, 8 * (size_t)n); memcpy(pts1, pts1_in, 8 * (size_t)n);
+  } else {
+    rs_ent *ent = (rs_ent *)malloc(sizeof(rs_ent) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+      ent[i].k[0] = okey(pts0_in[2 * i]); ent[i].k[1] = okey(pts0_in[2 * i + 1]);
+      ent[i].k[2] = okey(pts1_in[2 * i]); ent[i].k[3] = okey(pts1_in[2 * i + 1]);
+      ent[i].idx = i;
+    }
+    qsort(ent, (size_t)n, sizeof(rs_ent), rs_cmp);
+    for (int i = 0; i < n; ++i) {
+      pts0[2 * i] = pts0_in[2 * ent[i].idx]; pts0[2 * i + 1] = pts0_in[2 * ent[i].idx + 1];
+      pts1[2 * i] = pts1_in[2 * ent[i].idx]; pts1[2 * i + 1] = pts1_in[2 * ent[i].idx + 1];
+    }
+    free(ent);
   }
-  free(ent);
   float *pn0 = (float *)malloc(8 * (size_t)n), *pn1 = (float *)malloc(8 * (size_t)n);
   float T1[9], T2[9], T2t[9];
   normalize_pts(pts0, n, pn0, T1);
@@ -263,10 +317,12 @@ float oransac_find_F(const float *pts0_in, const float *pts1_in, int n, const or
   float best = 0.0f; int best_it = -1;
   float *Fall = (float *)malloc(sizeof(float) * 9 * (size_t)cfg->iterations);
   float *sc = (float *)malloc(sizeof(float) * (size_t)cfg->iterations);
+  int *cnt = (int *)malloc(sizeof(int) * (size_t)cfg->iterations);
 #pragma omp parallel for schedule(static)
   for (int it = 0; it < cfg->iterations; ++it) {
     int set[8];
-    draw_set(cfg->seed, it, n, set);
+    if (sets) memcpy(set, sets + 8 * (size_t)it, sizeof(set));
+    else draw_set(cfg->seed, it, n, set);
     float a[16], b[16];
     for (int j = 0; j < 8; ++j) {
       a[2 * j] = pn0[2 * set[j]]; a[2 * j + 1] = pn0[2 * set[j] + 1];
@@ -278,16 +334,26 @@ float oransac_find_F(const float *pts0_in, const float *pts1_in, int n, const or
     for (int k = 0; k < 9; ++k) Fnf[k] = (float)Fn[k];
     mat3_mul_f(T2t, Fnf, M);                 /* F21i = T2t * Fn * T1 :193 */
     mat3_mul_f(M, T1, Fall + 9 * (size_t)it);
-    sc[it] = check_F(Fall + 9 * (size_t)it, pts0, pts1, n, cfg->sigma, NULL);
+    sc[it] = check_F_count(Fall + 9 * (size_t)it, pts0, pts1, n, cfg->sigma, NULL, cnt + it);
   }
-  for (int it = 0; it < cfg->iterations; ++it)
+  const int counted = (!sets && cfg->confidence > 0.0f) ? confident_prefix(sc, cnt, n, cfg->iterations, (double)cfg->confidence)
+                                                        : cfg->iterations;
+  for (int it = 0; it < counted; ++it)
     if (sc[it] > best) { best = sc[it]; best_it = it; } /* strict >, first wins :197 */
   if (best_it >= 0) {
     for (int k = 0; k < 9; ++k) F21[k] = Fall[9 * (size_t)best_it + k];
     check_F(F21, pts0_in, pts1_in, n, cfg->sigma, inliers);   /* per-point test, caller's order */
   }
-  free(pn0); free(pn1); free(Fall); free(sc); free(pts0); free(pts1);
+  free(pn0); free(pn1); free(Fall); free(sc); free(cnt); free(pts0); free(pts1);
   return best;
+}
+
+float oransac_find_F(const float *pts0, const float *pts1, int n, const oransac_config *cfg, uint8_t *inliers, float *F21) {
+  return find_F_impl(pts0, pts1, n, cfg, NULL, inliers, F21);
+}
+float oransac_find_F_sets(const float *pts0, const float *pts1, int n, const oransac_config *cfg, const int *sets,
+                          uint8_t *inliers, float *F21) {
+  return find_F_impl(pts0, pts1, n, cfg, sets, inliers, F21);
 }
 
 /* ======================================================================
@@ -504,6 +570,11 @@ static int check_R_T(const float *R, const float *t, const float *keys1, int n1,
 /* returns 1 on success. model: 0 = homography, 1 = fundamental.  SH/SF scores out. */
 int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
                      const int *matches12, float *T21, float *P3D, uint8_t *tri, int *model, float *scores) {
+  return oepi_reconstruct_sets(cfg, keys1, n1, keys2, n2, matches12, NULL, T21, P3D, tri, model, scores);
+}
+int oepi_reconstruct_sets(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
+                          const int *matches12, const int *sets_in, float *T21, float *P3D, uint8_t *tri, int *model,
+                          float *scores) {
   for (int k = 0; k < 16; ++k) T21[k] = (k % 5 == 0) ? 1.0f : 0.0f;
   for (int i = 0; i < n1; ++i) tri[i] = 0;
   int *mp = (int *)malloc(sizeof(int) * 2 * (size_t)(n1 > 0 ? n1 : 1));
@@ -526,12 +597,19 @@ int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const f
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T2t[i * 3 + j] = T2[j * 3 + i];
   mat3_inv_f(T2, T2inv);
   const int its = cfg->iterations;
+  int *own_sets = NULL;
+  if (!sets_in && cfg->sampler == 1) {   /* the reference's stream, drawn serially before the searches (:56-71) */
+    own_sets = (int *)malloc(sizeof(int) * 8 * (size_t)its);
+    oransac_minimal_sets(1, cfg->seed, nm, its, own_sets);
+    sets_in = own_sets;
+  }
   float *Fall = (float *)malloc(36 * (size_t)its), *Hall = (float *)malloc(36 * (size_t)its), *Hinv = (float *)malloc(36 * (size_t)its);
   float *scF = (float *)malloc(4 * (size_t)its), *scH = (float *)malloc(4 * (size_t)its);
 #pragma omp parallel for schedule(static)
   for (int it = 0; it < its; ++it) {
     int set[8];
-    draw_set(cfg->seed, it, nm, set);
+    if (sets_in) memcpy(set, sets_in + 8 * (size_t)it, sizeof(set));
+    else draw_set(cfg->seed, it, nm, set);
     float a[16], b[16];
     for (int j = 0; j < 8; ++j) {
       a[2 * j] = q0[2 * set[j]]; a[2 * j + 1] = q0[2 * set[j] + 1];
@@ -659,6 +737,7 @@ int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const f
       free(gds); free(Ps);
     }
   }
+  free(own_sets);
   free(mp); free(p0); free(p1); free(q0); free(q1); free(Fall); free(Hall); free(Hinv); free(scF); free(scH);
   free(inl); free(gd); free(P);
   return ok;

@@ -92,9 +92,19 @@ typedef struct { int queryIdx, trainIdx; float distance; } o_dmatch;
 
 typedef struct {
   int iterations;   /* EpipolarGeometry(K, sigma, iterations): src/tracking.cc:52-55 -> 200 */
-  float sigma;      /* 1.0 */
+  float sigma;      /* 1.0; the reference call's 3 px gate (src/point_matching.cc:50) is sigma = 3 / sqrt(3.841) */
   uint32_t seed;    /* explicit, replaces process-global srand(0) (src/epipolar_geometry.cc:100-112) */
+  float confidence; /* <= 0: every hypothesis counts (_find_F); else the sequential loop of cv::findFundamentalMat's
+                     * 4th argument: hypotheses walked in order, each new best shrinks the count to the smallest k with
+                     * (1 - w^8)^k <= 1 - confidence (OpenCV RANSACUpdateNumIters, 8 model points) */
 } oransac_config;
+
+/* minimal sets: sampler 0 = the build's counter hash, 1 = the reference's stream, i.e. the C library's own
+ * srand(seed) / rand() through Random::RandomInt (src/epipolar_geometry.cc:56-71,100-117). sets: iterations x 8 */
+void oransac_minimal_sets(int sampler, uint32_t seed, int n, int iterations, int *sets);
+/* _find_F over explicit minimal sets (the reference's _vSets), matches walked in the caller's order */
+float oransac_find_F_sets(const float *pts0, const float *pts1, int n, const oransac_config *cfg, const int *sets,
+                          uint8_t *inliers, float *F21);
 
 /* EpipolarGeometry::_find_F (+_normalize,_compute_F21,_check_F)
  * src/epipolar_geometry.cc:161-205,247-283,372-449,735-780 on n matched pixel
@@ -114,9 +124,13 @@ int omatch_points(const float *sg_blob, const osg_config *cfg,
  * keys: n x (x,y) pixel coords; matches12[n1]: index into keys2 or -1.
  * T21: 4x4 row-major; P3D: n1 x 3; tri: n1 flags; model: 0 = H, 1 = F;
  * scores[2] = {SH, SF}.  Returns 1 when the initialisation is accepted. */
-typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; } oepi_config;
+typedef struct { float K[9]; float sigma; int iterations; uint32_t seed; int sampler; } oepi_config;
 int oepi_reconstruct(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
                      const int *matches12, float *T21, float *P3D, uint8_t *tri, int *model, float *scores);
+/* same over explicit minimal sets (cfg->iterations x 8 indices into the list of valid matches) */
+int oepi_reconstruct_sets(const oepi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
+                          const int *matches12, const int *sets, float *T21, float *P3D, uint8_t *tri, int *model,
+                          float *scores);
 
 /* ---------------- camera ---------------- */
 typedef struct {

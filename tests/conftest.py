@@ -162,3 +162,39 @@ def check_sg_n1000(g, Z, i0, i1, m0, m1):
     assert np.abs(m0 - g["mscores0"]).max() < 1e-3 and np.abs(m1 - g["mscores1"]).max() < 1e-3
     planted = int(g["planted"])
     assert (i0[:planted] == np.arange(planted)).sum() >= planted - 2 - planted // 50
+
+
+RANSAC_GOLDEN = ["ransac_general.npz", "ransac_general2.npz", "ransac_planar.npz", "ransac_allmatched.npz"]
+
+
+def check_reconstruct_golden(g, result):
+    """an EpipolarGeometry::reconstruct result (ok, T21, P3D, tri, model, (SH, SF)) over the fixture's minimal sets
+    against tests/golden/ransac_*.npz -- the numpy / LAPACK-SVD restatement of the reference's formulas
+    (tests/golden/make_ransac_golden.py).  Tolerances are what f32 SVD vs f64 Jacobi allow."""
+    ok, T, P, tri, model, (SH, SF) = result
+    assert abs(SF - g["SF"]) <= 2e-4 * g["SF"] and abs(SH - g["SH"]) <= 2e-4 * g["SH"], (SH, SF, g["SH"], g["SF"])
+    assert model == int(g["model"]) and ok == bool(g["ok"])
+    if ok:
+        assert np.abs(T - g["T21"]).max() < 1e-3
+        gt = g["tri"].astype(bool)
+        assert (tri.astype(bool) != gt).sum() <= max(1, len(gt) // 200)
+        both = tri.astype(bool) & gt
+        assert both.sum() > 50
+        assert np.abs(P[both] - g["P3D"][both]).max() <= 2e-2 * np.abs(g["P3D"][both]).max()
+        # and the motion is the scene's (rotation to 1e-2, translation direction to 5e-2)
+        assert np.abs(T[:3, :3] - g["R_true"]).max() < 1e-2
+        tn = g["t_true"] / np.linalg.norm(g["t_true"])
+        assert np.abs(T[:3, 3] - tn).max() < 5e-2
+    else:
+        assert np.array_equal(T, np.eye(4, dtype=T.dtype)) and not tri.any()
+
+
+def check_find_F_golden(g, score, inliers, F):
+    """_find_F over the fixture's minimal sets (all keypoints matched, so the search sees exactly the reference's
+    normalisation): best score, inlier mask (up to correspondences within 1e-2 of the chi-square gate) and the
+    fundamental matrix up to scale and sign"""
+    assert abs(score - g["SF"]) <= 2e-4 * g["SF"]
+    diff = inliers.astype(bool) != g["inlF"]
+    assert not (diff & (g["marginF"] > 1e-2)).any() and diff.sum() <= 3
+    a, b = F.reshape(-1) / np.linalg.norm(F), g["F21"].reshape(-1) / np.linalg.norm(g["F21"])
+    assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-3

@@ -172,3 +172,24 @@ def test_superglue_state_dict_import_folds_batchnorm_and_reorders_heads(U, tmp_p
     W.write_onnx(p, folded, nodes)
     got = W.superglue_from_onnx(p)
     assert got.shape == blob.shape and np.array_equal(got, blob)
+
+
+def test_minimal_sets_glibc_stream_equals_the_c_library(U, O):
+    """urf_minimal_sets(URF_SAMPLER_GLIBC): the product restates glibc's rand() (TYPE_3 additive feedback generator)
+    to draw the reference's minimal sets (src/epipolar_geometry.cc:56-71,100-117); the oracle calls the C
+    library's own srand()/rand().  Also the counter-hash sampler against the oracle's."""
+    import ctypes as C
+    F = U.frontend
+    for (seed, n, its) in [(0, 8, 5), (0, 431, 200), (7, 1000, 200), (123456, 50, 37), (1, 9, 3)]:
+        a, b = F.minimal_sets(1, seed, n, its), O.minimal_sets(1, seed, n, its)
+        assert np.array_equal(a, b), (seed, n, its)
+        assert a.min() >= 0 and a.max() < n and all(len(set(r)) == 8 for r in a)      # without replacement
+        assert np.array_equal(F.minimal_sets(0, seed, n, its), O.minimal_sets(0, seed, n, its))
+    # srand(0) is srand(1) in glibc, and the first draw follows Random::RandomInt
+    assert np.array_equal(F.minimal_sets(1, 0, 100, 4), F.minimal_sets(1, 1, 100, 4))
+    libc = C.CDLL("libc.so.6")
+    libc.srand(0)
+    r = libc.rand()
+    assert F.minimal_sets(1, 0, 100, 1)[0, 0] == int((r / 2147483648.0) * 100)
+    with pytest.raises(RuntimeError):
+        F.minimal_sets(1, 0, 7, 1)              # fewer than 8 matches cannot seed a hypothesis

@@ -58,3 +58,26 @@ def test_world1_is_a_noop():
     t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     assert U.dist.all_gather_slots(t, 1) is t
     assert U.dist.max_over_ranks(3.5, torch.device("cpu"), 1) == 3.5
+
+
+def test_pair_ownership_plan_of_the_c_abi():
+    """urf_comm_plan_pairs (host-only, no process group): over all ranks every frame of a step is the second frame of
+    exactly one pair, each pair's first frame is its predecessor in global order, the only carried frame (-1) is the
+    predecessor of the step's first frame -- and the plan equals the Python sharding helpers used by the gloo rig"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    U = load_pkg()
+    for world, per in [(1, 8), (2, 8), (8, 4), (8, 8), (3, 5)]:
+        seconds = []
+        for rank in range(world):
+            a, b = U.dist.plan_pairs(world, rank, per)
+            lo, hi = U.dist.shard_range(per * world, rank, world)
+            assert list(b) == list(range(lo, hi)) and list(a) == [t - 1 for t in range(lo, hi)]
+            assert [(int(x), int(y)) for x, y in zip(a, b)] == U.dist.pairs_for_rank(per * world, rank, world)
+            seconds += list(b)
+        assert sorted(seconds) == list(range(world * per))
+    a, _ = U.dist.plan_pairs(4, 0, 4)
+    assert a[0] == -1 and (U.dist.plan_pairs(4, 1, 4)[0] >= 0).all()
+    import pytest
+    with pytest.raises(RuntimeError):
+        U.dist.plan_pairs(2, 2, 4)

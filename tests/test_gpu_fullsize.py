@@ -43,7 +43,7 @@ def pm_pair(F, sg_blob):
     """(exact, fast) PointMatching handles, one pair per call, sigma = 1.0 (the oracle configuration of these tests)"""
     out = []
     for prec in (0, 1):
-        p = F.PointMatching(F.SuperGlueConfig(), precision=prec, ransac_sigma=1.0)
+        p = F.PointMatching(F.SuperGlueConfig(), precision=prec, ransac_sigma=1.0, ransac_confidence=-1)
         assert p.build(sg_blob)
         out.append(p)
     return out
@@ -109,7 +109,7 @@ def test_device_resident_pipeline_vs_oracle(U, F, O, sp_blob, sg_blob, H, W, pre
     frames, ofeats, olists = _oracle_stream(U, O, sp_blob, sg_blob, H, W)
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=prec)
     assert sp.build(sp_blob)
-    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=8, precision=prec, ransac_sigma=1.0)
+    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=8, precision=prec, ransac_sigma=1.0, ransac_confidence=-1)
     assert pm.build(sg_blob)
     d = torch.from_numpy(np.stack(frames)).cuda()
     slots = torch.zeros((9, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")

@@ -30,6 +30,14 @@ def pm(F, sg_blob):
     return p
 
 
+@pytest.fixture(scope="module")
+def pm_sigma1(F, sg_blob):
+    """a matcher whose outlier stage is stated like EpipolarGeometry(K, sigma = 1, 200 iterations), every hypothesis counting"""
+    p = F.PointMatching(F.SuperGlueConfig(), ransac_sigma=1.0, ransac_confidence=-1)
+    assert p.build(sg_blob)
+    return p
+
+
 # ------------------------------------------------------------------ primitives
 def test_mfma_f32_is_an_ordered_fma_chain(F, O):
     """v_mfma_f32_16x16x4_f32 accumulates k in order, one rounding per product:
@@ -226,7 +234,7 @@ def test_matching_points_and_ransac_bit_exact_vs_oracle(U, F, O, sp_blob, sg_blo
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=500), max_height=240, max_width=320)
     assert sp.build(sp_blob)
     f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])
-    cfg, rc = O.SGConfig(640, 512, 0.5, 100), O.RansacConfig(200, 1.0, 0)
+    cfg, rc = O.SGConfig(640, 512, 0.5, 100), O.ref_ransac()
     g_raw, g_rej = pm.MatchingPoints(f0, f1, False), pm.MatchingPoints(f0, f1, True)
     assert g_raw == O.match_points(sg_blob, cfg, rc, f0, f1, False)
     assert g_rej == O.match_points(sg_blob, cfg, rc, f0, f1, True)
@@ -240,6 +248,28 @@ def test_matching_points_and_ransac_bit_exact_vs_oracle(U, F, O, sp_blob, sg_blo
     assert s == so and np.array_equal(inl, inlo) and np.array_equal(Fm, Fo)
     s7, inl7, _ = pm.find_F(f0[q[:7], 1:3], f1[t[:7], 1:3])
     assert s7 == 0 and inl7.sum() == 0                                   # fewer than 8 points
+
+
+def test_outlier_stage_configurations_bit_exact_vs_oracle(U, F, O, pm, pm_sigma1):
+    """the reference call's parameters (3 px, confidence 0.99: default), a pixel threshold of 1.5, and
+    EpipolarGeometry's own statement (sigma = 1, every hypothesis): each equals the oracle configured alike,
+    and the confidence stop really shortens the search"""
+    from conftest import two_view_scene
+    _, k1, k2, m12, _, _ = two_view_scene(seed=5, noise=0.4, outliers=60)
+    sel = np.where(m12 >= 0)[0]
+    p0, p1 = k1[sel], k2[m12[sel]]
+    got = {}
+    for name, h, oc in (("default", pm, O.ref_ransac()), ("sigma1", pm_sigma1, O.RansacConfig(200, 1.0, 0, 0.0))):
+        s, inl, Fm = h.find_F(p0, p1)
+        so, io, Fo = O.ransac_find_F(p0, p1, oc)
+        assert s == so and np.array_equal(inl, io) and np.array_equal(Fm, Fo), name
+        got[name] = inl.sum()
+    assert got["default"] > got["sigma1"] > 200                # the 3 px gate keeps more matches than the 1.96 px one
+    hp = F.PointMatching(F.SuperGlueConfig(), ransac_threshold_px=1.5, ransac_confidence=0.9)
+    assert hp.build(U.synth.pack_sg(U.synth.sg_weights(0)))
+    s, inl, Fm = hp.find_F(p0, p1)
+    so, io, Fo = O.ransac_find_F(p0, p1, O.RansacConfig(200, float(np.float32(1.5 / np.sqrt(3.841))), 0, 0.9))
+    assert s == so and np.array_equal(inl, io) and np.array_equal(Fm, Fo)
 
 
 def test_device_resident_batch_equals_host_path(U, F, sp_blob, sg_blob, sp640, pm):
@@ -387,6 +417,30 @@ def test_epipolar_reconstruct_bit_exact_vs_oracle(F, O, pm, kw, its):
     assert np.array_equal(T, oT) and np.array_equal(tri, otri) and np.array_equal(P, oP)
     ok7, *_ = eg.reconstruct(k1[:7], k2, np.arange(7, dtype=np.int32))
     assert not ok7
+
+
+@pytest.mark.parametrize("name", ["ransac_general.npz", "ransac_general2.npz", "ransac_planar.npz", "ransac_allmatched.npz"])
+def test_reconstruct_over_the_reference_minimal_sets(F, O, pm, pm_sigma1, name):
+    """the HIP searches + host tail over the REFERENCE's minimal sets (glibc srand(0)/rand(), restated in the
+    product: urf_minimal_sets) -- against the numpy / LAPACK-SVD restatement of the reference (fixture) and, bit
+    for bit, against the oracle; explicit sets and sampler = URF_SAMPLER_GLIBC are the same run"""
+    from conftest import check_find_F_golden, check_reconstruct_golden
+    g = golden(name)
+    its, m = int(g["iterations"]), g["matches12"]
+    nm = int((m >= 0).sum())
+    assert np.array_equal(F.minimal_sets(1, 0, nm, its), g["sets"])
+    eg = F.EpipolarGeometry(pm, g["K"], 1.0, its, seed=0, sampler=1)
+    res = eg.reconstruct(g["keys1"], g["keys2"], m)
+    check_reconstruct_golden(g, res)
+    res2 = F.EpipolarGeometry(pm, g["K"], 1.0, its).reconstruct(g["keys1"], g["keys2"], m, sets=g["sets"])
+    ores = O.epi_reconstruct(g["K"], g["keys1"], g["keys2"], m, iterations=its, sets=g["sets"])
+    for a, b, c in zip(res, res2, ores):
+        assert np.array_equal(np.asarray(a), np.asarray(b)) and np.array_equal(np.asarray(a), np.asarray(c))
+    if name == "ransac_allmatched.npz":       # every keypoint matched, in order: _find_F alone sees the same problem
+        s, inl, Fm = pm_sigma1.find_F_sets(g["keys1"], g["keys2"], g["sets"])
+        check_find_F_golden(g, s, inl, Fm)
+        so, io, Fo = O.ransac_find_F_sets(g["keys1"], g["keys2"], O.RansacConfig(its, 1.0, 0, 0.0), g["sets"])
+        assert s == so and np.array_equal(inl, io) and np.array_equal(Fm, Fo)
 
 
 # ------------------------------------------------ fast precision mode (split-f16)
@@ -698,7 +752,7 @@ def test_ransac_does_not_depend_on_the_order_of_the_matches(F, O, pm):
     sel = np.where(m12 >= 0)[0]
     p0, p1 = k1[sel], k2[m12[sel]]
     n = len(p0)
-    cfg = O.RansacConfig(200, 1.0, 0)
+    cfg = O.ref_ransac()
     s_ref, inl_ref, F_ref = pm.find_F(p0, p1)
     so, io, Fo = O.ransac_find_F(p0, p1, cfg)
     assert s_ref == so and np.array_equal(inl_ref, io) and np.array_equal(F_ref, Fo.reshape(3, 3)) and 200 < inl_ref.sum() < n

@@ -257,6 +257,58 @@ def test_epipolar_reconstruct_recovers_the_motion(O):
     assert not ok
 
 
+@pytest.mark.parametrize("name", ["ransac_general.npz", "ransac_general2.npz", "ransac_planar.npz", "ransac_allmatched.npz"])
+def test_reconstruct_vs_the_numpy_svd_restatement_of_the_reference(O, name):
+    """oracle EpipolarGeometry over the REFERENCE's minimal sets (the C library's srand(0)/rand() stream, stored in the
+    fixture) against the independent numpy restatement with LAPACK SVDs (tests/golden/make_ransac_golden.py)"""
+    from conftest import check_find_F_golden, check_reconstruct_golden
+    g = golden(name)
+    its, m = int(g["iterations"]), g["matches12"]
+    nm = int((m >= 0).sum())
+    assert np.array_equal(O.minimal_sets(1, 0, nm, its), g["sets"])         # the oracle draws the same stream itself
+    res = O.epi_reconstruct(g["K"], g["keys1"], g["keys2"], m, iterations=its, sets=g["sets"])
+    check_reconstruct_golden(g, res)
+    assert O.epi_reconstruct(g["K"], g["keys1"], g["keys2"], m, iterations=its, sampler=1)[1].tobytes() == res[1].tobytes()
+    if name == "ransac_allmatched.npz":
+        s, inl, F = O.ransac_find_F_sets(g["keys1"], g["keys2"], O.RansacConfig(its, 1.0, 0, 0.0), g["sets"])
+        check_find_F_golden(g, s, inl, F)
+
+
+def test_confidence_stop_follows_the_sequential_ransac_bound(O):
+    """oransac_config.confidence: hypotheses are walked in order and every new best shrinks the count to the
+    smallest k with (1 - w^8)^k <= 1 - confidence (cv::findFundamentalMat's 4th argument, OpenCV RANSACUpdateNumIters)"""
+    from conftest import two_view_scene
+    _, k1, k2, m12, _, _ = two_view_scene(seed=5, noise=0.4, outliers=60)
+    sel = np.where(m12 >= 0)[0]
+    p0, p1 = k1[sel], k2[m12[sel]]
+    n = len(p0)
+    full = O.ransac_find_F(p0, p1, O.RansacConfig(200, 1.0, 0, 0.0))
+    # emulate: per-hypothesis scores and inlier counts from one-hypothesis runs over explicit sets
+    sets = O.minimal_sets(0, 0, n, 200)
+    order = np.lexsort((np.arange(n), p1[:, 1], p1[:, 0], p0[:, 1], p0[:, 0]))      # the canonical order the sampler indexes
+    q0, q1 = p0[order], p1[order]
+    sc, cnt = [], []
+    for it in range(200):
+        s, inl, _ = O.ransac_find_F_sets(q0, q1, O.RansacConfig(1, 1.0, 0, 0.0), sets[it:it + 1])
+        sc.append(s); cnt.append(int(inl.sum()))
+    assert max(sc) == full[0]
+    niters, best = 200, 0.0
+    for it in range(200):
+        if it >= niters:
+            break
+        if sc[it] > best:
+            best = sc[it]
+            q, acc, k = 1.0 - (cnt[it] / n) ** 8, 1.0, 0
+            while True:
+                acc *= q; k += 1
+                if acc <= 0.01 or k >= 200:
+                    break
+            niters = min(niters, k)
+    want = max(sc[:niters])
+    got = O.ransac_find_F(p0, p1, O.RansacConfig(200, 1.0, 0, 0.99))
+    assert niters < 200 and got[0] == want
+
+
 # ------------------------------------------------------------------ camera (SURVEY section 8, row f2)
 # OpenCV is a third-party dependency that is not in the image and the reference holds no vectors
 # for it (parity unpinned): the restatement is checked against the closed forms it must satisfy.

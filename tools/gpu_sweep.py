@@ -44,7 +44,7 @@ for c in range(N):
     f1 = make_features(rng, n1, planted_from=f0, m=int(min(n0, n1) * rng.uniform(0, 0.9))) if min(n0, n1) > 0 else make_features(rng, n1)
     ransac = bool(rng.integers(0, 2))
     got = pm.MatchingPoints(f0, f1, ransac)
-    want = O.match_points(sgb, O.SGConfig(640, 512, 0.5, 100), O.RansacConfig(200, 1.0, 0), f0, f1, ransac)
+    want = O.match_points(sgb, O.SGConfig(640, 512, 0.5, 100), O.ref_ransac(), f0, f1, ransac)
     ok = got == want
     bad += not ok
     print(f"PM  n0={n0:4d} n1={n1:4d} ransac={int(ransac)} matches={len(want):4d} {'ok' if ok else 'MISMATCH'}", flush=True)

@@ -24,6 +24,9 @@ SYMBOLS = [
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
     "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
+    "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
+    "urf_comm_unique_id", "urf_comm_init", "urf_comm_init_all", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
+    "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results",
 ]
 
 
@@ -37,11 +40,12 @@ class SGConfig(C.Structure):
     _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("matching_threshold", C.c_double),
                 ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
-                ("precision", C.c_int)]
+                ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float)]
 
 
 class EpiConfig(C.Structure):
-    _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32)]
+    _fields_ = [("K", C.c_float * 9), ("sigma", C.c_float), ("iterations", C.c_int), ("seed", C.c_uint32),
+                ("sampler", C.c_int)]
 
 
 class CamConfig(C.Structure):
@@ -96,6 +100,7 @@ def lib():
         L.urf_pm_destroy.restype = None
         L.urf_cam_destroy.restype = None
         L.urf_fe_destroy.restype = None
+        L.urf_comm_destroy.restype = None
         L.urf_fe_superpoint.restype = C.c_void_p
         L.urf_fe_matcher.restype = C.c_void_p
         L.urf_sp_stream.restype = C.c_void_p

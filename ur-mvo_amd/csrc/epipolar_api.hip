@@ -1,9 +1,13 @@
-// epipolar_api.hip -- EpipolarGeometry::reconstruct behind the C ABI
-// (src/epipolar_geometry.cc:18-98).  The two 200-hypothesis RANSAC searches
-// (_find_H, _find_F) run on the GPU (ransac_kernels.hip); the once-per-sequence
-// tail -- model selection, _reconstruct_F/_H, _decompose_E, _check_R_T,
-// _triangulate (:451-950) -- is host C++ exactly as in the reference, with
-// Eigen::JacobiSVD replaced by Jacobi eigen-solvers on the Gram matrix (f64).
+// epipolar_api.hip -- EpipolarGeometry::reconstruct behind the C ABI (src/epipolar_geometry.cc:18-98).
+// The two RANSAC searches (_find_H, _find_F: 2 x `iterations` minimal-set solves and their scores) run on
+// the GPU (ransac_kernels.hip).  What follows them happens once per sequence and stays on the host like in
+// the reference: model selection (:86-97), the motion candidates of the winning model (_reconstruct_F
+// :451-562 with _decompose_E :900-926, or _reconstruct_H :564-733, Faugeras' eight solutions) and their
+// cheirality / reprojection / parallax tally (_check_R_T :782-898 with _triangulate :928-950).
+//
+// Structure of this file: small value types (M3, Pose), one `tally()` per motion candidate, one selection
+// rule per model.  Arithmetic spec (DESIGN.md "RANSAC"): float where the reference computes in float, sums
+// associated left to right; Eigen::JacobiSVD replaced by cyclic Jacobi (12 sweeps) on the Gram matrix in f64.
 #include "../../include/urf.h"
 #include "urf_common.h"
 
@@ -11,199 +15,412 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <vector>
 
 namespace urf {
 int launch_epipolar_search(const float *keys1, int n1, const float *keys2, int n2, const float *pts0, const float *pts1,
                            const int *d_nm, int nm, float *pn0, float *pn1, float *T, float *F, float *scoreF,
-                           float *H, float *scoreH, uint32_t seed, int iters, float sigma, hipStream_t st);
+                           float *H, float *scoreH, uint32_t seed, int iters, float sigma, const int *d_sets,
+                           hipStream_t st);
 
 namespace epi {
-static const int kSweeps = 12;
-static void jacobi_sym(double *a, double *v, int n) {
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < kSweeps; ++sweep)
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = a[p * n + q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          const double akp = a[k * n + p], akq = a[k * n + q];
-          a[k * n + p] = c * akp - s * akq;
-          a[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double apk = a[p * n + k], aqk = a[q * n + k];
-          a[p * n + k] = c * apk - s * aqk;
-          a[q * n + k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = v[k * n + p], vkq = v[k * n + q];
-          v[k * n + p] = c * vkp - s * vkq;
-          v[k * n + q] = s * vkp + c * vkq;
-        }
+
+// ------------------------------------------------------------------ glibc rand(), restated
+// The reference draws its minimal sets with rand() after srand(0) (src/epipolar_geometry.cc:100-117).
+// glibc's default generator (stdlib/random_r.c, TYPE_3): 31 words, x[i] = x[i-31] + x[i-3] (mod 2^32),
+// output x[i] >> 1; seeded by the Lehmer sequence 16807 * x mod (2^31 - 1) (Schrage's form), seed 0 -> 1,
+// first 310 outputs discarded.  tests/test_abi_cpu.py checks it against the C library's own rand().
+class GlibcRand {
+ public:
+  explicit GlibcRand(uint32_t seed) {
+    int32_t word = seed ? (int32_t)seed : 1;
+    ring_[0] = (uint32_t)word;
+    for (int i = 1; i < 31; ++i) {
+      const int32_t hi = word / 127773, lo = word % 127773;
+      word = 16807 * lo - 2836 * hi;
+      if (word < 0) word += 2147483647;
+      ring_[i] = (uint32_t)word;
+    }
+    front_ = 3; rear_ = 0;
+    for (int i = 0; i < 310; ++i) (void)next();
+  }
+  uint32_t next() {
+    ring_[front_] += ring_[rear_];
+    const uint32_t out = ring_[front_] >> 1;
+    front_ = (front_ + 1) % 31;
+    rear_ = (rear_ + 1) % 31;
+    return out;
+  }
+  // Random::RandomInt :114-117 (RAND_MAX = 2^31 - 1)
+  int uniform_int(int lo, int hi) { return (int)(((double)next() / 2147483648.0) * (hi - lo + 1)) + lo; }
+
+ private:
+  uint32_t ring_[31];
+  int front_, rear_;
+};
+
+static uint32_t hash_counter(uint32_t seed, uint32_t ctr) {   // the sampler of ransac_kernels.hip (rs_hash)
+  uint32_t x = seed ^ (ctr * 0x9E3779B9u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+// :52-71: per iteration 8 draws without replacement, swap-with-back on the list of all match indices
+static void minimal_sets(int sampler, uint32_t seed, int n, int iterations, int *sets) {
+  GlibcRand libc(seed);
+  std::vector<int> avail((size_t)n);
+  for (int it = 0; it < iterations; ++it) {
+    for (int i = 0; i < n; ++i) avail[i] = i;
+    int size = n;
+    for (int j = 0; j < 8; ++j) {
+      int pick;
+      if (sampler == URF_SAMPLER_GLIBC) {
+        pick = libc.uniform_int(0, size - 1);
+      } else {
+        const uint32_t r = hash_counter(seed, (uint32_t)(it * 8 + j)) >> 1;
+        pick = (int)(((double)r / 2147483648.0) * size);
+      }
+      sets[it * 8 + j] = avail[pick];
+      avail[pick] = avail[size - 1];
+      --size;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ small linear algebra
+struct M3 {
+  float v[9];
+  float operator()(int r, int c) const { return v[3 * r + c]; }
+  float &operator()(int r, int c) { return v[3 * r + c]; }
+};
+static M3 from(const float *p) { M3 m; memcpy(m.v, p, sizeof(m.v)); return m; }
+static M3 operator*(const M3 &a, const M3 &b) {
+  M3 o;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) o(r, c) = (a(r, 0) * b(0, c) + a(r, 1) * b(1, c)) + a(r, 2) * b(2, c);
+  return o;
+}
+static M3 transposed(const M3 &a) {
+  M3 o;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) o(r, c) = a(c, r);
+  return o;
+}
+static M3 inverse(const M3 &m) {   // adjugate / determinant, float (K.inverse() of a calibration matrix)
+  const float c00 = m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1);
+  const float c01 = -(m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0));
+  const float c02 = m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0);
+  const float inv_det = 1.0f / ((m(0, 0) * c00 + m(0, 1) * c01) + m(0, 2) * c02);
+  M3 o;
+  o(0, 0) = c00 * inv_det;
+  o(0, 1) = -(m(0, 1) * m(2, 2) - m(0, 2) * m(2, 1)) * inv_det;
+  o(0, 2) = (m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * inv_det;
+  o(1, 0) = c01 * inv_det;
+  o(1, 1) = (m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * inv_det;
+  o(1, 2) = -(m(0, 0) * m(1, 2) - m(0, 2) * m(1, 0)) * inv_det;
+  o(2, 0) = c02 * inv_det;
+  o(2, 1) = -(m(0, 0) * m(2, 1) - m(0, 1) * m(2, 0)) * inv_det;
+  o(2, 2) = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * inv_det;
+  return o;
+}
+template <typename T>
+static double det3(const T *m) {
+  return ((double)m[0] * ((double)m[4] * m[8] - (double)m[5] * m[7]) - (double)m[1] * ((double)m[3] * m[8] - (double)m[5] * m[6])) +
+         (double)m[2] * ((double)m[3] * m[7] - (double)m[4] * m[6]);
+}
+
+// symmetric eigen-decomposition, cyclic Jacobi with a fixed number of sweeps: on return the diagonal of `a`
+// holds the eigenvalues and the columns of `vec` the eigenvectors
+template <int N>
+static void jacobi(std::array<double, N * N> &a, std::array<double, N * N> &vec) {
+  vec.fill(0.0);
+  for (int i = 0; i < N; ++i) vec[i * N + i] = 1.0;
+  auto rotate = [](double &x, double &y, double c, double s) {
+    const double x0 = x, y0 = y;
+    x = c * x0 - s * y0;
+    y = s * x0 + c * y0;
+  };
+  for (int sweep = 0; sweep < 12; ++sweep)
+    for (int p = 0; p + 1 < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        const double off = a[p * N + q];
+        if (fabs(off) < 1e-300) continue;
+        const double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * off);
+        const double tn = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tn * tn + 1.0), s = tn * c;
+        for (int k = 0; k < N; ++k) rotate(a[k * N + p], a[k * N + q], c, s);   // columns p, q
+        for (int k = 0; k < N; ++k) rotate(a[p * N + k], a[q * N + k], c, s);   // rows p, q
+        for (int k = 0; k < N; ++k) rotate(vec[k * N + p], vec[k * N + q], c, s);
       }
 }
-static int argmin_diag(const double *a, int n) {
+template <int N>
+static int weakest(const std::array<double, N * N> &a) {
   int m = 0;
-  for (int i = 1; i < n; ++i)
-    if (a[i * n + i] < a[m * n + m]) m = i;
+  for (int i = 1; i < N; ++i)
+    if (a[i * N + i] < a[m * N + m]) m = i;
   return m;
 }
-static void mul3(const float *a, const float *b, float *o) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      o[i * 3 + j] = (a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j]) + a[i * 3 + 2] * b[2 * 3 + j];
-}
-static void inv3(const float *m, float *o) {
-  const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
-  const float det = (a * A + b * B) + c * C;
-  const float id = 1.0f / det;
-  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
-  o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
-  o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
-}
-static double det3(const double *m) {
-  return (m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6])) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-}
-// A = U diag(w) V^T, w descending (Jacobi on A^T A, f64)
-static void svd3(const float *Af, double U[9], double w[3], double V[9]) {
-  double A[9], g[9], W[9];
-  for (int k = 0; k < 9; ++k) A[k] = (double)Af[k];
+
+// A = U diag(w) V^T with w descending, through the eigenvectors of A^T A; the third left vector is u0 x u1,
+// oriented along A v2 (exactly orthogonal also when w2 ~ 0: essential matrices)
+struct Svd3 { double U[9], w[3], V[9]; };
+static Svd3 svd(const M3 &Af) {
+  Svd3 out;
+  double A[9];
+  for (int k = 0; k < 9; ++k) A[k] = (double)Af.v[k];
+  std::array<double, 9> gram, evec;
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s = s + A[k * 3 + r] * A[k * 3 + c];
-      g[r * 3 + c] = s;
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + A[k * 3 + r] * A[k * 3 + c];
+      gram[r * 3 + c] = acc;
     }
-  jacobi_sym(g, W, 3);
-  int ord[3] = {0, 1, 2};
-  for (int a = 0; a < 2; ++a)
-    for (int b = a + 1; b < 3; ++b)
-      if (g[ord[b] * 3 + ord[b]] > g[ord[a] * 3 + ord[a]]) std::swap(ord[a], ord[b]);
+  jacobi<3>(gram, evec);
+  int order[3] = {0, 1, 2};
+  for (int x = 0; x < 2; ++x)
+    for (int y = x + 1; y < 3; ++y)
+      if (gram[order[y] * 4] > gram[order[x] * 4]) std::swap(order[x], order[y]);
   for (int j = 0; j < 3; ++j) {
-    const double ev = g[ord[j] * 3 + ord[j]];
-    w[j] = ev > 0.0 ? sqrt(ev) : 0.0;
-    for (int k = 0; k < 3; ++k) V[k * 3 + j] = W[k * 3 + ord[j]];
+    const double ev = gram[order[j] * 4];
+    out.w[j] = ev > 0.0 ? sqrt(ev) : 0.0;
+    for (int k = 0; k < 3; ++k) out.V[k * 3 + j] = evec[k * 3 + order[j]];
   }
+  auto A_times_vcol = [&](int r, int j) { return (A[r * 3] * out.V[j] + A[r * 3 + 1] * out.V[3 + j]) + A[r * 3 + 2] * out.V[6 + j]; };
   for (int j = 0; j < 2; ++j)
-    for (int r = 0; r < 3; ++r)
-      U[r * 3 + j] = ((A[r * 3 + 0] * V[0 * 3 + j] + A[r * 3 + 1] * V[1 * 3 + j]) + A[r * 3 + 2] * V[2 * 3 + j]) / w[j];
-  /* third left vector: u0 x u1 (exactly orthogonal even when w2 ~ 0, as for an
-     essential matrix), oriented along A v2 */
-  {
-    const double c0 = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
-    const double c1 = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
-    const double c2 = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
-    double av[3];
-    for (int r = 0; r < 3; ++r) av[r] = (A[r * 3 + 0] * V[0 * 3 + 2] + A[r * 3 + 1] * V[1 * 3 + 2]) + A[r * 3 + 2] * V[2 * 3 + 2];
-    const double sgn = ((av[0] * c0 + av[1] * c1) + av[2] * c2) < 0.0 ? -1.0 : 1.0;
-    U[0 * 3 + 2] = sgn * c0; U[1 * 3 + 2] = sgn * c1; U[2 * 3 + 2] = sgn * c2;
-  }
+    for (int r = 0; r < 3; ++r) out.U[r * 3 + j] = A_times_vcol(r, j) / out.w[j];
+  const double cx = out.U[3] * out.U[7] - out.U[6] * out.U[4];
+  const double cy = out.U[6] * out.U[1] - out.U[0] * out.U[7];
+  const double cz = out.U[0] * out.U[4] - out.U[3] * out.U[1];
+  const double along = (A_times_vcol(0, 2) * cx + A_times_vcol(1, 2) * cy) + A_times_vcol(2, 2) * cz;
+  const double sign = along < 0.0 ? -1.0 : 1.0;
+  out.U[2] = sign * cx; out.U[5] = sign * cy; out.U[8] = sign * cz;
+  return out;
 }
-// _check_F / _check_H per-match tests (same float expressions as the kernels)
-static bool in_F(const float *F, float u1, float v1, float u2, float v2, float inv) {
-  const float th = 3.841f;
-  bool bIn = true;
-  const float a2 = (F[0] * u1 + F[1] * v1) + F[2], b2 = (F[3] * u1 + F[4] * v1) + F[5], c2 = (F[6] * u1 + F[7] * v1) + F[8];
-  const float num2 = (a2 * u2 + b2 * v2) + c2;
-  if (((num2 * num2) / (a2 * a2 + b2 * b2)) * inv > th) bIn = false;
-  const float a1 = (F[0] * u2 + F[3] * v2) + F[6], b1 = (F[1] * u2 + F[4] * v2) + F[7], c1 = (F[2] * u2 + F[5] * v2) + F[8];
-  const float num1 = (a1 * u1 + b1 * v1) + c1;
-  if (((num1 * num1) / (a1 * a1 + b1 * b1)) * inv > th) bIn = false;
-  return bIn;
+
+// ------------------------------------------------------------------ the two-view problem
+struct Pose { M3 R; float t[3]; };
+
+struct TwoView {
+  const float *keys1, *keys2;
+  int n1;
+  std::vector<std::array<int, 2>> pairs;     // _vMatches12: (index in image 1, index in image 2)
+  std::vector<uint8_t> inlier;               // of the winning model, per pair
+  M3 K;
+  float sigma2;
+};
+
+// per-correspondence symmetric transfer tests: the float expressions of _check_F :372-449 / _check_H :285-370
+// (the same ones the scoring kernels evaluate)
+static bool fits_F(const M3 &F, const float *x1, const float *x2, float inv_sigma2) {
+  const float l2a = (F(0, 0) * x1[0] + F(0, 1) * x1[1]) + F(0, 2);
+  const float l2b = (F(1, 0) * x1[0] + F(1, 1) * x1[1]) + F(1, 2);
+  const float l2c = (F(2, 0) * x1[0] + F(2, 1) * x1[1]) + F(2, 2);
+  const float r2 = (l2a * x2[0] + l2b * x2[1]) + l2c;
+  const bool ok2 = !(((r2 * r2) / (l2a * l2a + l2b * l2b)) * inv_sigma2 > 3.841f);
+  const float l1a = (F(0, 0) * x2[0] + F(1, 0) * x2[1]) + F(2, 0);
+  const float l1b = (F(0, 1) * x2[0] + F(1, 1) * x2[1]) + F(2, 1);
+  const float l1c = (F(0, 2) * x2[0] + F(1, 2) * x2[1]) + F(2, 2);
+  const float r1 = (l1a * x1[0] + l1b * x1[1]) + l1c;
+  const bool ok1 = !(((r1 * r1) / (l1a * l1a + l1b * l1b)) * inv_sigma2 > 3.841f);
+  return ok1 && ok2;
 }
-static bool in_H(const float *H21, const float *H12, float u1, float v1, float u2, float v2, float inv) {
-  const float th = 5.991f;
-  bool bIn = true;
-  const float w2 = (float)(1.0 / (double)((H12[6] * u2 + H12[7] * v2) + H12[8]));
-  const float u2in1 = ((H12[0] * u2 + H12[1] * v2) + H12[2]) * w2, v2in1 = ((H12[3] * u2 + H12[4] * v2) + H12[5]) * w2;
-  if (((u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1)) * inv > th) bIn = false;
-  const float w1 = (float)(1.0 / (double)((H21[6] * u1 + H21[7] * v1) + H21[8]));
-  const float u1in2 = ((H21[0] * u1 + H21[1] * v1) + H21[2]) * w1, v1in2 = ((H21[3] * u1 + H21[4] * v1) + H21[5]) * w1;
-  if (((u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2)) * inv > th) bIn = false;
-  return bIn;
+static bool fits_H(const M3 &H21, const M3 &H12, const float *x1, const float *x2, float inv_sigma2) {
+  auto transfer_error = [&](const M3 &H, const float *from, const float *to) {
+    const float wi = (float)(1.0 / (double)((H(2, 0) * from[0] + H(2, 1) * from[1]) + H(2, 2)));
+    const float px = ((H(0, 0) * from[0] + H(0, 1) * from[1]) + H(0, 2)) * wi;
+    const float py = ((H(1, 0) * from[0] + H(1, 1) * from[1]) + H(1, 2)) * wi;
+    return ((to[0] - px) * (to[0] - px) + (to[1] - py) * (to[1] - py)) * inv_sigma2;
+  };
+  const bool ok1 = !(transfer_error(H12, x2, x1) > 5.991f);
+  const bool ok2 = !(transfer_error(H21, x1, x2) > 5.991f);
+  return ok1 && ok2;
 }
-// _triangulate :928-950
-static bool triangulate(const float *x1, const float *x2, const float *P1, const float *P2, float X[3]) {
-  float Af[16];
+
+// _triangulate :928-950: null vector of the 4x4 DLT matrix
+static bool triangulate(const float *x1, const float *x2, const float (&P1)[12], const float (&P2)[12], float X[3]) {
+  float D[16];
   for (int c = 0; c < 4; ++c) {
-    Af[0 * 4 + c] = x1[0] * P1[2 * 4 + c] - P1[0 * 4 + c];
-    Af[1 * 4 + c] = x1[1] * P1[2 * 4 + c] - P1[1 * 4 + c];
-    Af[2 * 4 + c] = x2[0] * P2[2 * 4 + c] - P2[0 * 4 + c];
-    Af[3 * 4 + c] = x2[1] * P2[2 * 4 + c] - P2[1 * 4 + c];
+    D[c] = x1[0] * P1[8 + c] - P1[c];
+    D[4 + c] = x1[1] * P1[8 + c] - P1[4 + c];
+    D[8 + c] = x2[0] * P2[8 + c] - P2[c];
+    D[12 + c] = x2[1] * P2[8 + c] - P2[4 + c];
   }
-  double g[16], V[16];
+  std::array<double, 16> gram, evec;
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) {
-      double s = 0.0;
-      for (int k = 0; k < 4; ++k) s = s + (double)Af[k * 4 + r] * (double)Af[k * 4 + c];
-      g[r * 4 + c] = s;
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc = acc + (double)D[k * 4 + r] * (double)D[k * 4 + c];
+      gram[r * 4 + c] = acc;
     }
-  jacobi_sym(g, V, 4);
-  const int m = argmin_diag(g, 4);
-  const float h[4] = {(float)V[0 * 4 + m], (float)V[1 * 4 + m], (float)V[2 * 4 + m], (float)V[3 * 4 + m]};
-  if (h[3] == 0.0f) return false;
-  X[0] = h[0] / h[3]; X[1] = h[1] / h[3]; X[2] = h[2] / h[3];
+  jacobi<4>(gram, evec);
+  const int m = weakest<4>(gram);
+  const float hx = (float)evec[m], hy = (float)evec[4 + m], hz = (float)evec[8 + m], hw = (float)evec[12 + m];
+  if (hw == 0.0f) return false;
+  X[0] = hx / hw; X[1] = hy / hw; X[2] = hz / hw;
   return true;
 }
-// _check_R_T :782-898
-static int check_R_T(const float *R, const float *t, const float *keys1, int n1, const float *keys2, const int *mp, int nm,
-                     const uint8_t *inl, const float *K, float *P3D, float th2, uint8_t *good, float *parallax) {
-  const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  std::fill(good, good + n1, (uint8_t)0);
-  std::vector<float> cosv;
-  cosv.reserve(nm);
-  float P1[12], P2[12], Rt[12];
-  for (int k = 0; k < 12; ++k) P1[k] = 0.0f;
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) P1[r * 4 + c] = K[r * 3 + c];
-  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[r * 4 + c] = R[r * 3 + c]; Rt[r * 4 + 3] = t[r]; }
+
+// _check_R_T :782-898 for one motion candidate
+struct Tally {
+  int good = 0;
+  float parallax = 0.0f;
+  std::vector<uint8_t> triangulated;   // per keypoint of image 1
+  std::vector<float> points;           // 3 per keypoint of image 1
+};
+static Tally tally(const TwoView &tv, const Pose &pose) {
+  Tally out;
+  out.triangulated.assign((size_t)std::max(tv.n1, 1), 0);
+  out.points.assign(3 * (size_t)std::max(tv.n1, 1), 0.0f);
+  const M3 &K = tv.K, &R = pose.R;
+  const float *t = pose.t;
+  const float fx = K(0, 0), fy = K(1, 1), cx = K(0, 2), cy = K(1, 2);
+  const float th2 = 4.0f * tv.sigma2;
+  float P1[12] = {0}, P2[12];
   for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 4; ++c)
-      P2[r * 4 + c] = (K[r * 3 + 0] * Rt[0 * 4 + c] + K[r * 3 + 1] * Rt[1 * 4 + c]) + K[r * 3 + 2] * Rt[2 * 4 + c];
-  float O2[3];
-  for (int r = 0; r < 3; ++r) O2[r] = -((R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1]) + R[2 * 3 + r] * t[2]);
-  int nGood = 0;
-  for (int i = 0; i < nm; ++i) {
-    if (!inl[i]) continue;
-    const int i1 = mp[2 * i], i2 = mp[2 * i + 1];
-    const float x1[2] = {keys1[2 * i1], keys1[2 * i1 + 1]}, x2[2] = {keys2[2 * i2], keys2[2 * i2 + 1]};
-    float p[3] = {0, 0, 0};
-    triangulate(x1, x2, P1, P2, p);
-    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { good[i1] = 0; continue; }
-    const float dist1 = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
-    const float n2[3] = {p[0] - O2[0], p[1] - O2[1], p[2] - O2[2]};
-    const float dist2 = sqrtf((n2[0] * n2[0] + n2[1] * n2[1]) + n2[2] * n2[2]);
-    const float cosParallax = ((p[0] * n2[0] + p[1] * n2[1]) + p[2] * n2[2]) / (dist1 * dist2);
-    if (p[2] <= 0 && cosParallax < 0.99998f) continue;
-    float q[3];
-    for (int r = 0; r < 3; ++r) q[r] = ((R[r * 3 + 0] * p[0] + R[r * 3 + 1] * p[1]) + R[r * 3 + 2] * p[2]) + t[r];
-    if (q[2] <= 0 && cosParallax < 0.99998f) continue;
-    const float invZ1 = (float)(1.0 / (double)p[2]);
-    const float im1x = fx * p[0] * invZ1 + cx, im1y = fy * p[1] * invZ1 + cy;
-    if ((im1x - x1[0]) * (im1x - x1[0]) + (im1y - x1[1]) * (im1y - x1[1]) > th2) continue;
-    const float invZ2 = (float)(1.0 / (double)q[2]);
-    const float im2x = fx * q[0] * invZ2 + cx, im2y = fy * q[1] * invZ2 + cy;
-    if ((im2x - x2[0]) * (im2x - x2[0]) + (im2y - x2[1]) * (im2y - x2[1]) > th2) continue;
-    cosv.push_back(cosParallax);
-    P3D[3 * i1] = p[0]; P3D[3 * i1 + 1] = p[1]; P3D[3 * i1 + 2] = p[2];
-    nGood++;
-    if (cosParallax < 0.99998f) good[i1] = 1;
+    for (int c = 0; c < 3; ++c) P1[r * 4 + c] = K(r, c);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      auto Rt = [&](int rr) { return c < 3 ? R(rr, c) : t[rr]; };
+      P2[r * 4 + c] = (K(r, 0) * Rt(0) + K(r, 1) * Rt(1)) + K(r, 2) * Rt(2);
+    }
+  float centre2[3];   // O2 = -R^T t
+  for (int r = 0; r < 3; ++r) centre2[r] = -((R(0, r) * t[0] + R(1, r) * t[1]) + R(2, r) * t[2]);
+  std::vector<float> cosines;
+  cosines.reserve(tv.pairs.size());
+  for (size_t m = 0; m < tv.pairs.size(); ++m) {
+    if (!tv.inlier[m]) continue;
+    const int i1 = tv.pairs[m][0], i2 = tv.pairs[m][1];
+    const float *x1 = tv.keys1 + 2 * i1, *x2 = tv.keys2 + 2 * i2;
+    float X[3] = {0.0f, 0.0f, 0.0f};
+    triangulate(x1, x2, P1, P2, X);
+    if (!std::isfinite(X[0]) || !std::isfinite(X[1]) || !std::isfinite(X[2])) { out.triangulated[i1] = 0; continue; }
+    const float ray2[3] = {X[0] - centre2[0], X[1] - centre2[1], X[2] - centre2[2]};
+    const float len1 = sqrtf((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
+    const float len2 = sqrtf((ray2[0] * ray2[0] + ray2[1] * ray2[1]) + ray2[2] * ray2[2]);
+    const float cos_parallax = ((X[0] * ray2[0] + X[1] * ray2[1]) + X[2] * ray2[2]) / (len1 * len2);
+    const bool wide = cos_parallax < 0.99998f;
+    if (X[2] <= 0 && wide) continue;                            // behind camera 1
+    float Y[3];                                                 // the point in camera 2
+    for (int r = 0; r < 3; ++r) Y[r] = ((R(r, 0) * X[0] + R(r, 1) * X[1]) + R(r, 2) * X[2]) + t[r];
+    if (Y[2] <= 0 && wide) continue;                            // behind camera 2
+    auto reprojection2 = [&](const float *Pc, const float *x) {
+      const float iz = (float)(1.0 / (double)Pc[2]);
+      const float ex = (fx * Pc[0] * iz + cx) - x[0], ey = (fy * Pc[1] * iz + cy) - x[1];
+      return ex * ex + ey * ey;
+    };
+    if (reprojection2(X, x1) > th2) continue;
+    if (reprojection2(Y, x2) > th2) continue;
+    cosines.push_back(cos_parallax);
+    memcpy(&out.points[3 * (size_t)i1], X, sizeof(X));
+    ++out.good;
+    if (wide) out.triangulated[i1] = 1;
   }
-  if (nGood > 0) {
-    std::sort(cosv.begin(), cosv.end());
-    const int idx = std::min(50, (int)cosv.size() - 1);
-    *parallax = (float)(acos((double)cosv[idx]) * 180.0 / 3.1415926535897932384626433832795);
-  } else {
-    *parallax = 0.0f;
+  if (out.good > 0) {
+    std::sort(cosines.begin(), cosines.end());
+    const size_t idx = std::min<size_t>(50, cosines.size() - 1);
+    out.parallax = (float)(acos((double)cosines[idx]) * 180.0 / 3.1415926535897932384626433832795);
   }
-  return nGood;
+  return out;
 }
+
+// _reconstruct_F :451-562 (+ _decompose_E :900-926): four candidates (R1|R2) x (+t|-t)
+static bool motion_from_F(TwoView &tv, const M3 &F21, const float *p0, const float *p1, const Pose **chosen_pose,
+                          std::array<Pose, 8> &cands, Tally &chosen) {
+  const float inv = (float)(1.0 / (double)tv.sigma2);
+  int N = 0;
+  for (size_t m = 0; m < tv.pairs.size(); ++m) { tv.inlier[m] = fits_F(F21, p0 + 2 * m, p1 + 2 * m, inv); N += tv.inlier[m]; }
+  const M3 E = (transposed(tv.K) * F21) * tv.K;
+  const Svd3 d = svd(E);
+  M3 U, Vt;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { U(r, c) = (float)d.U[r * 3 + c]; Vt(r, c) = (float)d.V[c * 3 + r]; }
+  float t[3];
+  {
+    const float len = sqrtf((U(0, 2) * U(0, 2) + U(1, 2) * U(1, 2)) + U(2, 2) * U(2, 2));
+    for (int r = 0; r < 3; ++r) t[r] = U(r, 2) / len;
+  }
+  const M3 W = {{0, -1, 0, 1, 0, 0, 0, 0, 1}}, Wt = {{0, 1, 0, -1, 0, 0, 0, 0, 1}};
+  M3 R1 = (U * W) * Vt, R2 = (U * Wt) * Vt;
+  if (det3(R1.v) < 0) for (float &x : R1.v) x = -x;
+  if (det3(R2.v) < 0) for (float &x : R2.v) x = -x;
+  for (int c = 0; c < 4; ++c) {
+    cands[c].R = (c & 1) ? R2 : R1;
+    for (int r = 0; r < 3; ++r) cands[c].t[r] = (c & 2) ? -t[r] : t[r];
+  }
+  Tally res[4];
+  int most = 0;
+  for (int c = 0; c < 4; ++c) { res[c] = tally(tv, cands[c]); most = std::max(most, res[c].good); }
+  const int need = std::max((int)(0.9 * N), 50);
+  int similar = 0;
+  for (int c = 0; c < 4; ++c) similar += res[c].good > 0.7 * most;
+  if (most < need || similar > 1) return false;
+  for (int c = 0; c < 4; ++c)
+    if (res[c].good == most) {
+      if (!(res[c].parallax > 1.0f)) return false;
+      chosen = std::move(res[c]);
+      *chosen_pose = &cands[c];
+      return true;
+    }
+  return false;
+}
+
+// _reconstruct_H :564-733: Faugeras' decomposition, eight candidates
+static bool motion_from_H(TwoView &tv, const M3 &H21, const M3 &H12, const float *p0, const float *p1,
+                          const Pose **chosen_pose, std::array<Pose, 8> &cands, Tally &chosen) {
+  const float inv = (float)(1.0 / (double)tv.sigma2);
+  int N = 0;
+  for (size_t m = 0; m < tv.pairs.size(); ++m) { tv.inlier[m] = fits_H(H21, H12, p0 + 2 * m, p1 + 2 * m, inv); N += tv.inlier[m]; }
+  const M3 A = (inverse(tv.K) * H21) * tv.K;
+  const Svd3 d = svd(A);
+  double Vt_d[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Vt_d[r * 3 + c] = d.V[c * 3 + r];
+  const float s = (float)(det3(d.U) * det3(Vt_d));
+  const float d1 = (float)d.w[0], d2 = (float)d.w[1], d3 = (float)d.w[2];
+  if (d1 / d2 < 1.00001f || d2 / d3 < 1.00001f) return false;
+  M3 U, Vt;
+  for (int k = 0; k < 9; ++k) { U.v[k] = (float)d.U[k]; Vt.v[k] = (float)Vt_d[k]; }
+  const float span = d1 * d1 - d3 * d3;
+  const float e1 = sqrtf((d1 * d1 - d2 * d2) / span), e3 = sqrtf((d2 * d2 - d3 * d3) / span);
+  const float root = sqrtf((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3));
+  const float sin_theta = root / ((d1 + d3) * d2), cos_theta = (d2 * d2 + d1 * d3) / ((d1 + d3) * d2);
+  const float sin_phi = root / ((d1 - d3) * d2), cos_phi = (d1 * d3 - d2 * d2) / ((d1 - d3) * d2);
+  static const float sx1[4] = {1, 1, -1, -1}, sx3[4] = {1, -1, 1, -1}, ssin[4] = {1, -1, -1, 1};
+  for (int c = 0; c < 8; ++c) {
+    const int i = c & 3;
+    const float x1 = sx1[i] * e1, x3 = sx3[i] * e3;
+    M3 Rp = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    float tp[3] = {0.0f, 0.0f, 0.0f};
+    if (c < 4) {          // d' > 0
+      const float sn = ssin[i] * sin_theta;
+      Rp(0, 0) = cos_theta; Rp(0, 2) = -sn; Rp(1, 1) = 1.0f; Rp(2, 0) = sn; Rp(2, 2) = cos_theta;
+      tp[0] = x1 * (d1 - d3); tp[2] = -x3 * (d1 - d3);
+    } else {              // d' < 0
+      const float sn = ssin[i] * sin_phi;
+      Rp(0, 0) = cos_phi; Rp(0, 2) = sn; Rp(1, 1) = -1.0f; Rp(2, 0) = sn; Rp(2, 2) = -cos_phi;
+      tp[0] = x1 * (d1 + d3); tp[2] = x3 * (d1 + d3);
+    }
+    const M3 R = (U * Rp) * Vt;
+    for (int k = 0; k < 9; ++k) cands[c].R.v[k] = s * R.v[k];
+    float tt[3];
+    for (int r = 0; r < 3; ++r) tt[r] = (U(r, 0) * tp[0] + U(r, 1) * tp[1]) + U(r, 2) * tp[2];
+    const float len = sqrtf((tt[0] * tt[0] + tt[1] * tt[1]) + tt[2] * tt[2]);
+    for (int r = 0; r < 3; ++r) cands[c].t[r] = tt[r] / len;
+  }
+  int best = 0, runner_up = 0, best_c = -1;
+  Tally best_res;
+  for (int c = 0; c < 8; ++c) {
+    Tally r = tally(tv, cands[c]);
+    if (r.good > best) { runner_up = best; best = r.good; best_c = c; best_res = std::move(r); }
+    else if (r.good > runner_up) runner_up = r.good;
+  }
+  if (!(runner_up < 0.75 * best && best_res.parallax >= 1.0f && best > 50 && best > 0.9 * N)) return false;
+  chosen = std::move(best_res);
+  *chosen_pose = &cands[best_c];
+  return true;
+}
+
 }  // namespace epi
 }  // namespace urf
 using namespace urf;
@@ -211,9 +428,24 @@ using namespace urf;
 extern "C" void *urf_pm_stream_(urf_pm *h);
 extern "C" int urf_pm_device_(urf_pm *h);
 
-extern "C" int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
-                                        const float *keys2, int n2, const int *matches12, float *T21, float *P3D,
-                                        uint8_t *tri, int *model, float *scores) {
+extern "C" int urf_minimal_sets(int sampler, uint32_t seed, int n, int iterations, int *sets) {
+  URF_CHECK(sets && n >= 8 && iterations >= 1, "urf_minimal_sets: need n >= 8 matches, iterations >= 1");
+  URF_CHECK(sampler == URF_SAMPLER_HASH || sampler == URF_SAMPLER_GLIBC, "urf_minimal_sets: unknown sampler %d", sampler);
+  epi::minimal_sets(sampler, seed, n, iterations, sets);
+  return 0;
+}
+
+// device scratch of one reconstruct call (freed on every exit path)
+namespace {
+struct DeviceScratch {
+  float *p = nullptr;
+  ~DeviceScratch() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static int reconstruct_impl(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1, const float *keys2, int n2,
+                            const int *matches12, const int *sets, float *T21, float *P3D, uint8_t *tri, int *model,
+                            float *scores) {
   URF_CHECK(h && cfg && keys1 && keys2 && matches12 && T21 && P3D && tri && model && scores,
             "urf_epipolar_reconstruct: null argument");
   URF_CHECK(n1 >= 0 && n1 <= kCap && n2 >= 0 && n2 <= kCap, "keypoint counts (%d,%d) outside [0,%d]", n1, n2, kCap);
@@ -222,164 +454,100 @@ extern "C" int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, co
   for (int k = 0; k < 16; ++k) T21[k] = (k % 5 == 0) ? 1.0f : 0.0f;
   std::fill(tri, tri + n1, (uint8_t)0);
   *model = -1; scores[0] = scores[1] = 0.0f;
-  std::vector<int> mp;
+
+  epi::TwoView tv;
+  tv.keys1 = keys1; tv.keys2 = keys2; tv.n1 = n1;
   for (int i = 0; i < n1; ++i)
-    if (matches12[i] >= 0) { URF_CHECK(matches12[i] < n2, "match index out of range"); mp.push_back(i); mp.push_back(matches12[i]); }
-  const int nm = (int)mp.size() / 2;
+    if (matches12[i] >= 0) {
+      URF_CHECK(matches12[i] < n2, "match index out of range");
+      tv.pairs.push_back({i, matches12[i]});
+    }
+  const int nm = (int)tv.pairs.size();
   if (nm < 8) return 0;
   const int its = cfg->iterations > 0 ? cfg->iterations : 200;
   const float sigma = cfg->sigma > 0 ? cfg->sigma : 1.0f;
-  std::vector<float> p0(2 * nm), p1(2 * nm);
-  for (int i = 0; i < nm; ++i) {
-    p0[2 * i] = keys1[2 * mp[2 * i]]; p0[2 * i + 1] = keys1[2 * mp[2 * i] + 1];
-    p1[2 * i] = keys2[2 * mp[2 * i + 1]]; p1[2 * i + 1] = keys2[2 * mp[2 * i + 1] + 1];
+  tv.K = epi::from(cfg->K);
+  tv.sigma2 = sigma * sigma;
+  tv.inlier.assign((size_t)nm, 0);
+  std::vector<float> p0(2 * (size_t)nm), p1(2 * (size_t)nm);
+  for (int m = 0; m < nm; ++m) {
+    memcpy(&p0[2 * (size_t)m], keys1 + 2 * tv.pairs[m][0], 2 * sizeof(float));
+    memcpy(&p1[2 * (size_t)m], keys2 + 2 * tv.pairs[m][1], 2 * sizeof(float));
   }
+  // minimal sets: the caller's, the reference's rand() stream, or (nullptr) the device-side counter hash
+  std::vector<int> host_sets;
+  if (!sets && cfg->sampler == URF_SAMPLER_GLIBC) {
+    host_sets.resize((size_t)its * 8);
+    epi::minimal_sets(URF_SAMPLER_GLIBC, cfg->seed, nm, its, host_sets.data());
+    sets = host_sets.data();
+  }
+  if (sets)
+    for (int k = 0; k < its * 8; ++k) URF_CHECK(sets[k] >= 0 && sets[k] < nm, "minimal set index %d outside the %d matches", sets[k], nm);
+
   // ---- GPU: both RANSAC searches
   URF_HIP(hipSetDevice(urf_pm_device_(h)));
-  float *d = nullptr;
-  const size_t nf = 2 * (size_t)n1 + 2 * (size_t)n2 + 8 * (size_t)nm + 18 + (size_t)its * (9 + 1 + 18 + 1) + 8;
-  URF_HIP(hipMalloc((void **)&d, nf * sizeof(float)));
-  float *dk1 = d, *dk2 = dk1 + 2 * n1, *dp0 = dk2 + 2 * n2, *dp1 = dp0 + 2 * nm, *dq0 = dp1 + 2 * nm, *dq1 = dq0 + 2 * nm;
+  DeviceScratch scratch;
+  const size_t nf = 2 * (size_t)n1 + 2 * (size_t)n2 + 8 * (size_t)nm + 18 + (size_t)its * (9 + 1 + 18 + 1 + 8) + 8;
+  URF_HIP(hipMalloc((void **)&scratch.p, nf * sizeof(float)));
+  float *dk1 = scratch.p, *dk2 = dk1 + 2 * n1, *dp0 = dk2 + 2 * n2, *dp1 = dp0 + 2 * nm, *dq0 = dp1 + 2 * nm, *dq1 = dq0 + 2 * nm;
   float *dT = dq1 + 2 * nm, *dF = dT + 18, *dsF = dF + (size_t)its * 9, *dH = dsF + its, *dsH = dH + (size_t)its * 18;
-  int *dnm = (int *)(dsH + its);
-  int rc = 0;
+  int *dnm = (int *)(dsH + its), *dsets = dnm + 8;
   std::vector<float> F((size_t)its * 9), H((size_t)its * 18), sF(its), sH(its);
-  do {
-    if (hipMemcpyAsync(dk1, keys1, 8 * (size_t)n1, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(dk2, keys2, 8 * (size_t)n2, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(dp0, p0.data(), 8 * (size_t)nm, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(dp1, p1.data(), 8 * (size_t)nm, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(dnm, &nm, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
-    if (launch_epipolar_search(dk1, n1, dk2, n2, dp0, dp1, dnm, nm, dq0, dq1, dT, dF, dsF, dH, dsH, cfg->seed, its, sigma, st)) { rc = -1; break; }
-    if (hipMemcpyAsync(F.data(), dF, F.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(H.data(), dH, H.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(sF.data(), dsF, its * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(sH.data(), dsH, its * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
-    if (hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
-  } while (0);
-  (void)hipFree(d);
-  URF_CHECK(rc == 0, "urf_epipolar_reconstruct: HIP error %s", hipGetErrorString(hipGetLastError()));
+  URF_HIP(hipMemcpyAsync(dk1, keys1, 8 * (size_t)n1, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(dk2, keys2, 8 * (size_t)n2, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(dp0, p0.data(), 8 * (size_t)nm, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(dp1, p1.data(), 8 * (size_t)nm, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(dnm, &nm, sizeof(int), hipMemcpyHostToDevice, st));
+  if (sets) URF_HIP(hipMemcpyAsync(dsets, sets, (size_t)its * 8 * sizeof(int), hipMemcpyHostToDevice, st));
+  if (launch_epipolar_search(dk1, n1, dk2, n2, dp0, dp1, dnm, nm, dq0, dq1, dT, dF, dsF, dH, dsH, cfg->seed, its, sigma,
+                             sets ? dsets : nullptr, st))
+    return -1;
+  URF_HIP(hipMemcpyAsync(F.data(), dF, F.size() * 4, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(H.data(), dH, H.size() * 4, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(sF.data(), dsF, (size_t)its * 4, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(sH.data(), dsH, (size_t)its * 4, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipStreamSynchronize(st));
 
-  // ---- host tail: reconstruct() :86-97
-  float SF = 0.0f, SH = 0.0f;
-  int bF = -1, bH = -1;
-  for (int it = 0; it < its; ++it) {
-    if (sF[it] > SF) { SF = sF[it]; bF = it; }
-    if (sH[it] > SH) { SH = sH[it]; bH = it; }
-  }
+  // ---- model selection :86-97 (first best hypothesis of each search, strict '>')
+  const int bF = (int)(std::max_element(sF.begin(), sF.end()) - sF.begin());
+  const int bH = (int)(std::max_element(sH.begin(), sH.end()) - sH.begin());
+  const float SF = sF[bF] > 0.0f ? sF[bF] : 0.0f, SH = sH[bH] > 0.0f ? sH[bH] : 0.0f;
   scores[0] = SH; scores[1] = SF;
   if (SH + SF == 0.0f) return 0;
-  const float *K = cfg->K;
-  const float inv = (float)(1.0 / (double)(sigma * sigma));
-  const float th2 = 4.0f * (sigma * sigma);
-  const float minParallax = 1.0f;
-  const int minTri = 50;
-  std::vector<uint8_t> inl(nm), gd(n1 > 0 ? n1 : 1);
-  std::vector<float> P(3 * (size_t)(n1 > 0 ? n1 : 1));
   const float RH = SH / (SH + SF);
-  int ok = 0;
-  if (RH > 0.50f && bH >= 0) {  // _reconstruct_H :564-733
+  std::array<epi::Pose, 8> cands;
+  const epi::Pose *pose = nullptr;
+  epi::Tally result;
+  bool ok;
+  if (RH > 0.50f && SH > 0.0f) {
     *model = 0;
-    const float *H21 = H.data() + (size_t)bH * 18, *H12 = H21 + 9;
-    int N = 0;
-    for (int i = 0; i < nm; ++i) { inl[i] = epi::in_H(H21, H12, p0[2 * i], p0[2 * i + 1], p1[2 * i], p1[2 * i + 1], inv); N += inl[i]; }
-    float invK[9], M[9], A[9];
-    epi::inv3(K, invK); epi::mul3(invK, H21, M); epi::mul3(M, K, A);
-    double U[9], w[3], V[9], Vt[9];
-    epi::svd3(A, U, w, V);
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Vt[i * 3 + j] = V[j * 3 + i];
-    const float s = (float)(epi::det3(U) * epi::det3(Vt));
-    const float d1 = (float)w[0], d2 = (float)w[1], d3 = (float)w[2];
-    if (d1 / d2 < 1.00001f || d2 / d3 < 1.00001f) return 0;
-    float Rs[8][9], ts[8][3];
-    const float aux1 = sqrtf((d1 * d1 - d2 * d2) / (d1 * d1 - d3 * d3));
-    const float aux3 = sqrtf((d2 * d2 - d3 * d3) / (d1 * d1 - d3 * d3));
-    const float x1[4] = {aux1, aux1, -aux1, -aux1}, x3[4] = {aux3, -aux3, aux3, -aux3};
-    const float aux_st = sqrtf((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 + d3) * d2);
-    const float ctheta = (d2 * d2 + d1 * d3) / ((d1 + d3) * d2);
-    const float stheta[4] = {aux_st, -aux_st, -aux_st, aux_st};
-    const float aux_sp = sqrtf((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 - d3) * d2);
-    const float cphi = (d1 * d3 - d2 * d2) / ((d1 - d3) * d2);
-    const float sphi[4] = {aux_sp, -aux_sp, -aux_sp, aux_sp};
-    float Uf[9], Vtf[9];
-    for (int k = 0; k < 9; ++k) { Uf[k] = (float)U[k]; Vtf[k] = (float)Vt[k]; }
-    for (int h8 = 0; h8 < 8; ++h8) {
-      const int i = h8 & 3;
-      const bool second = h8 >= 4;
-      float Rp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tp[3];
-      if (!second) { Rp[0] = ctheta; Rp[2] = -stheta[i]; Rp[4] = 1.0f; Rp[6] = stheta[i]; Rp[8] = ctheta;
-                     tp[0] = x1[i] * (d1 - d3); tp[1] = 0.0f; tp[2] = -x3[i] * (d1 - d3); }
-      else { Rp[0] = cphi; Rp[2] = sphi[i]; Rp[4] = -1.0f; Rp[6] = sphi[i]; Rp[8] = -cphi;
-             tp[0] = x1[i] * (d1 + d3); tp[1] = 0.0f; tp[2] = x3[i] * (d1 + d3); }
-      float M1[9], M2[9];
-      epi::mul3(Uf, Rp, M1); epi::mul3(M1, Vtf, M2);
-      for (int k = 0; k < 9; ++k) Rs[h8][k] = s * M2[k];
-      float tt[3];
-      for (int r = 0; r < 3; ++r) tt[r] = (Uf[r * 3] * tp[0] + Uf[r * 3 + 1] * tp[1]) + Uf[r * 3 + 2] * tp[2];
-      const float nrm = sqrtf((tt[0] * tt[0] + tt[1] * tt[1]) + tt[2] * tt[2]);
-      for (int r = 0; r < 3; ++r) ts[h8][r] = tt[r] / nrm;
-    }
-    int bestGood = 0, second = 0, bestIdx = -1;
-    float bestPar = -1.0f;
-    std::vector<uint8_t> bg(gd.size());
-    std::vector<float> bP(P.size());
-    for (int h8 = 0; h8 < 8; ++h8) {
-      float par;
-      std::fill(P.begin(), P.end(), 0.0f);
-      const int nG = epi::check_R_T(Rs[h8], ts[h8], keys1, n1, keys2, mp.data(), nm, inl.data(), K, P.data(), th2, gd.data(), &par);
-      if (nG > bestGood) { second = bestGood; bestGood = nG; bestIdx = h8; bestPar = par; bg = gd; bP = P; }
-      else if (nG > second) second = nG;
-    }
-    if (second < 0.75 * bestGood && bestPar >= minParallax && bestGood > minTri && bestGood > 0.9 * N) {
-      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T21[r * 4 + c] = Rs[bestIdx][r * 3 + c]; T21[r * 4 + 3] = ts[bestIdx][r]; }
-      memcpy(tri, bg.data(), n1); memcpy(P3D, bP.data(), 12 * (size_t)n1);
-      ok = 1;
-    }
-  } else if (bF >= 0) {  // _reconstruct_F :451-562
+    ok = epi::motion_from_H(tv, epi::from(&H[(size_t)bH * 18]), epi::from(&H[(size_t)bH * 18 + 9]), p0.data(), p1.data(), &pose,
+                            cands, result);
+  } else if (SF > 0.0f) {
     *model = 1;
-    const float *F21 = F.data() + (size_t)bF * 9;
-    int N = 0;
-    for (int i = 0; i < nm; ++i) { inl[i] = epi::in_F(F21, p0[2 * i], p0[2 * i + 1], p1[2 * i], p1[2 * i + 1], inv); N += inl[i]; }
-    float Kt[9], M[9], E[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Kt[i * 3 + j] = K[j * 3 + i];
-    epi::mul3(Kt, F21, M); epi::mul3(M, K, E);
-    double U[9], w[3], V[9];
-    epi::svd3(E, U, w, V);  // _decompose_E :900-926
-    float Uf[9], Vtf[9], t[3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Uf[i * 3 + j] = (float)U[i * 3 + j]; Vtf[i * 3 + j] = (float)V[j * 3 + i]; }
-    { const float nrm = sqrtf((Uf[2] * Uf[2] + Uf[5] * Uf[5]) + Uf[8] * Uf[8]); t[0] = Uf[2] / nrm; t[1] = Uf[5] / nrm; t[2] = Uf[8] / nrm; }
-    const float Wm[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
-    float R1[9], R2[9], M1[9];
-    epi::mul3(Uf, Wm, M1); epi::mul3(M1, Vtf, R1);
-    epi::mul3(Uf, Wt, M1); epi::mul3(M1, Vtf, R2);
-    { double dd[9]; for (int k = 0; k < 9; ++k) dd[k] = R1[k]; if (epi::det3(dd) < 0) for (int k = 0; k < 9; ++k) R1[k] = -R1[k]; }
-    { double dd[9]; for (int k = 0; k < 9; ++k) dd[k] = R2[k]; if (epi::det3(dd) < 0) for (int k = 0; k < 9; ++k) R2[k] = -R2[k]; }
-    const float t2[3] = {-t[0], -t[1], -t[2]};
-    const float *Rc[4] = {R1, R2, R1, R2};
-    const float *tc[4] = {t, t, t2, t2};
-    int nG[4];
-    float par[4];
-    std::vector<uint8_t> gds(4 * gd.size());
-    std::vector<float> Ps(4 * P.size(), 0.0f);
-    for (int c = 0; c < 4; ++c)
-      nG[c] = epi::check_R_T(Rc[c], tc[c], keys1, n1, keys2, mp.data(), nm, inl.data(), K, Ps.data() + P.size() * c, th2,
-                             gds.data() + gd.size() * c, &par[c]);
-    int maxGood = nG[0];
-    for (int c = 1; c < 4; ++c) maxGood = std::max(maxGood, nG[c]);
-    const int nMinGood = std::max((int)(0.9 * N), minTri);
-    int nsimilar = 0;
-    for (int c = 0; c < 4; ++c) if (nG[c] > 0.7 * maxGood) nsimilar++;
-    if (!(maxGood < nMinGood || nsimilar > 1)) {
-      for (int c = 0; c < 4; ++c)
-        if (maxGood == nG[c]) {
-          if (par[c] > minParallax) {
-            for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) T21[r * 4 + cc] = Rc[c][r * 3 + cc]; T21[r * 4 + 3] = tc[c][r]; }
-            memcpy(tri, gds.data() + gd.size() * c, n1); memcpy(P3D, Ps.data() + P.size() * c, 12 * (size_t)n1);
-            ok = 1;
-          }
-          break;
-        }
-    }
+    ok = epi::motion_from_F(tv, epi::from(&F[(size_t)bF * 9]), p0.data(), p1.data(), &pose, cands, result);
+  } else {
+    return 0;
   }
-  return ok;
+  if (!ok) return 0;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T21[r * 4 + c] = pose->R(r, c);
+    T21[r * 4 + 3] = pose->t[r];
+  }
+  memcpy(tri, result.triangulated.data(), (size_t)n1);
+  memcpy(P3D, result.points.data(), 12 * (size_t)n1);
+  return 1;
+}
+
+extern "C" int urf_epipolar_reconstruct(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
+                                        const float *keys2, int n2, const int *matches12, float *T21, float *P3D,
+                                        uint8_t *tri, int *model, float *scores) {
+  return reconstruct_impl(h, cfg, keys1, n1, keys2, n2, matches12, nullptr, T21, P3D, tri, model, scores);
+}
+
+extern "C" int urf_epipolar_reconstruct_sets(urf_pm *h, const urf_epi_config *cfg, const float *keys1, int n1,
+                                             const float *keys2, int n2, const int *matches12, const int *sets,
+                                             float *T21, float *P3D, uint8_t *tri, int *model, float *scores) {
+  URF_CHECK(sets, "urf_epipolar_reconstruct_sets: null sets");
+  return reconstruct_impl(h, cfg, keys1, n1, keys2, n2, matches12, sets, T21, P3D, tri, model, scores);
 }

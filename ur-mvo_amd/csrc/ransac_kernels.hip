@@ -278,8 +278,10 @@ __global__ void __launch_bounds__(128) ransac_normalize_kernel(const int *nmatch
   }
 }
 
+// sets: NULL (draw with the counter hash) or [P][iters][8] explicit minimal sets -- the reference's _vSets
+// (src/epipolar_geometry.cc:52-71), indices into the match list as the hypothesis kernels see it
 __global__ void __launch_bounds__(64) ransac_hyp_kernel(const int *nmatch, const float *pn0, const float *pn1,
-                                                        const float *T, uint32_t seed, int iters,
+                                                        const float *T, uint32_t seed, int iters, const int *sets,
                                                         float *F /*[P][iters][9]*/) {
   __shared__ double lA[72 * 64];
   __shared__ int lperm[9 * 64];
@@ -287,7 +289,11 @@ __global__ void __launch_bounds__(64) ransac_hyp_kernel(const int *nmatch, const
   const int n = nmatch[p];
   if (it >= iters || n < 8) return;
   int set[8];
-  draw_set(seed, it, n, set);
+  if (sets) {
+    for (int j = 0; j < 8; ++j) set[j] = sets[((size_t)p * iters + it) * 8 + j];
+  } else {
+    draw_set(seed, it, n, set);
+  }
   float a[16], b[16];
   const float *q0 = pn0 + (size_t)p * RNP * 2, *q1 = pn1 + (size_t)p * RNP * 2;
   for (int j = 0; j < 8; ++j) {
@@ -330,7 +336,8 @@ __device__ __forceinline__ bool check_pair(const float *F, float u1, float v1, f
 }
 
 __global__ void __launch_bounds__(256) ransac_score_kernel(const int *nmatch, const float *pts0, const float *pts1,
-                                                           const float *F, float sigma, int iters, float *score) {
+                                                           const float *F, float sigma, int iters, float *score,
+                                                           int *ninl /*[P][iters] inlier counts, may be NULL*/) {
   const int p = blockIdx.y, it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = nmatch[p];
   if (it >= iters || n < 8) return;
@@ -341,23 +348,53 @@ __global__ void __launch_bounds__(256) ransac_score_kernel(const int *nmatch, co
   const float invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));
   const float *q0 = pts0 + (size_t)p * RNP * 2, *q1 = pts1 + (size_t)p * RNP * 2;
   float sc = 0.0f;
-  for (int i = lane; i < n; i += 64) check_pair(Fl, q0[2 * i], q0[2 * i + 1], q1[2 * i], q1[2 * i + 1], invSigmaSquare, sc);
+  int cnt = 0;
+  for (int i = lane; i < n; i += 64)
+    cnt += check_pair(Fl, q0[2 * i], q0[2 * i + 1], q1[2 * i], q1[2 * i + 1], invSigmaSquare, sc) ? 1 : 0;
   sc = bfly64_sum(sc);
-  if (lane == 0) score[(size_t)p * iters + it] = sc;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+  if (lane == 0) {
+    score[(size_t)p * iters + it] = sc;
+    if (ninl) ninl[(size_t)p * iters + it] = cnt;
+  }
 }
 
 // best hypothesis (strict '>' against 0, first wins: :197-201), inlier mask,
 // ordered compaction of the match list (src/point_matching.cc:52-58).
+// Hypotheses the sequential RANSAC loop of cv::findFundamentalMat(..., confidence) would still evaluate
+// (src/point_matching.cc:50; OpenCV's RANSACUpdateNumIters with 8 model points): walking the hypotheses in
+// order, every new best shrinks the bound to the smallest k with (1 - w^8)^k <= 1 - confidence, w = its inlier
+// ratio; the product is accumulated by sequential f64 multiplications so that CPU and GPU agree bit for bit.
+__device__ int ransac_confident_prefix(const float *score, const int *ninl, int n, int iters, double confidence) {
+  int niters = iters;
+  float best = 0.0f;
+  for (int it = 0; it < iters && it < niters; ++it) {
+    if (score[it] > best) {
+      best = score[it];
+      const double wr = (double)ninl[it] / (double)n;
+      double w8 = wr * wr; w8 = w8 * w8; w8 = w8 * w8;
+      const double q = 1.0 - w8, tgt = 1.0 - confidence;
+      int k = 1;
+      double acc = q;
+      while (acc > tgt && k < iters) { acc = acc * q; ++k; }
+      if (k < niters) niters = k;
+    }
+  }
+  return niters;
+}
+
 __global__ void __launch_bounds__(1024) ransac_select_kernel(const int *nmatch, const float *pts0, const float *pts1,
-                                                             const float *F, const float *score, float sigma,
-                                                             int iters, int enable, const DMatchR *matches,
+                                                             const float *F, const float *score, const int *ninl,
+                                                             float sigma, double confidence,
+                                                             int iters_max, int enable, const DMatchR *matches,
                                                              DMatchR *out, int *nout, uint8_t *inliers, float *Fbest,
                                                              float *best_score) {
   __shared__ float s_best[16];
   __shared__ int s_bi[16];
   __shared__ int wsum[16];
   __shared__ float s_F[9];
-  __shared__ int s_it;
+  __shared__ int s_it, s_iters;
   const int p = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
   const int n = nmatch[p];
   const DMatchR *mi = matches + (size_t)p * RNP;
@@ -368,10 +405,16 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const int *nmatch, 
     if (Fbest && i < 9) Fbest[(size_t)p * 9 + i] = 0.0f;
     return;
   }
+  if (i == 0)
+    s_iters = (confidence > 0.0 && ninl) ? ransac_confident_prefix(score + (size_t)p * iters_max, ninl + (size_t)p * iters_max, n,
+                                                                   iters_max, confidence)
+                                         : iters_max;
+  __syncthreads();
+  const int iters = s_iters;      // hypotheses that count; the arrays keep their stride iters_max
   float best = 0.0f;
   int bi = 0x7fffffff;
   for (int it = i; it < iters; it += 1024) {
-    const float s = score[(size_t)p * iters + it];
+    const float s = score[(size_t)p * iters_max + it];
     if (s > best) { best = s; bi = it; }
   }
 #pragma unroll
@@ -393,7 +436,7 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const int *nmatch, 
   __syncthreads();
   const int bit = s_it;
   if (i < 9) {
-    const float v = bit >= 0 ? F[((size_t)p * iters + bit) * 9 + i] : 0.0f;
+    const float v = bit >= 0 ? F[((size_t)p * iters_max + bit) * 9 + i] : 0.0f;
     s_F[i] = v;
     if (Fbest) Fbest[(size_t)p * 9 + i] = v;
   }
@@ -506,14 +549,19 @@ __device__ void jacobi9_lds(double *la, double *lv) {
 }
 
 __global__ void __launch_bounds__(32) epi_hyp_h_kernel(const float *pn0, const float *pn1, int nm, const float *T,
-                                                       uint32_t seed, int iters, float *H /*[iters][18]: H21 | H12*/) {
+                                                       uint32_t seed, int iters, const int *sets,
+                                                       float *H /*[iters][18]: H21 | H12*/) {
   __shared__ double la[81 * 32];
   __shared__ double lv[81 * 32];
   const int it = blockIdx.x * 32 + threadIdx.x;
   if (it >= iters || nm < 8) return;
   double *a = la + threadIdx.x, *v = lv + threadIdx.x;
   int set[8];
-  draw_set(seed, it, nm, set);
+  if (sets) {
+    for (int j = 0; j < 8; ++j) set[j] = sets[(size_t)it * 8 + j];
+  } else {
+    draw_set(seed, it, nm, set);
+  }
   // A^T A of the 16x9 DLT system, accumulated row pair by row pair in source order
   for (int r = 0; r < 9; ++r)
     for (int c = 0; c < 9; ++c) a[(r * 9 + c) * 32] = 0.0;
@@ -585,33 +633,37 @@ __global__ void __launch_bounds__(256) epi_score_h_kernel(const float *pts0, con
 // both model searches for one image pair; everything on `st`
 int launch_epipolar_search(const float *keys1, int n1, const float *keys2, int n2, const float *pts0, const float *pts1,
                            const int *d_nm, int nm, float *pn0, float *pn1, float *T, float *F, float *scoreF,
-                           float *H, float *scoreH, uint32_t seed, int iters, float sigma, hipStream_t st) {
+                           float *H, float *scoreH, uint32_t seed, int iters, float sigma, const int *d_sets,
+                           hipStream_t st) {
   hipLaunchKernelGGL(epi_normalize_kernel, dim3(1), dim3(128), 0, st, keys1, n1, keys2, n2, pts0, pts1, nm, pn0, pn1, T);
-  hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, 1), dim3(64), 0, st, d_nm, pn0, pn1, T, seed, iters, F);
+  hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, 1), dim3(64), 0, st, d_nm, pn0, pn1, T, seed, iters, d_sets, F);
   hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, 1), dim3(256), 0, st, d_nm, pts0, pts1, F, sigma, iters,
-                     scoreF);
-  hipLaunchKernelGGL(epi_hyp_h_kernel, dim3((iters + 31) / 32), dim3(32), 0, st, pn0, pn1, nm, T, seed, iters, H);
+                     scoreF, (int *)nullptr);
+  hipLaunchKernelGGL(epi_hyp_h_kernel, dim3((iters + 31) / 32), dim3(32), 0, st, pn0, pn1, nm, T, seed, iters, d_sets, H);
   hipLaunchKernelGGL(epi_score_h_kernel, dim3((iters + 3) / 4), dim3(256), 0, st, pts0, pts1, nm, H, sigma, iters,
                      scoreH);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
+// d_sets: NULL, or explicit minimal sets [P][iters][8] that index the matches in the CALLER's order (then the
+// canonical sort is skipped: sampler, sums and scores walk the list as given, like the reference)
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
-                  float *pn1, float *T, float *F, float *score, uint32_t seed, int iters, float sigma, int enable,
-                  const void *matches, void *out, int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P,
-                  hipStream_t st) {
+                  float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
+                  double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
+                  uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st) {
   if (enable) {
     // ps0 / ps1: the correspondences in canonical order; the final per-point inlier test runs on the caller's order
-    hipLaunchKernelGGL(ransac_sort_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, ps0, ps1);
-    hipLaunchKernelGGL(ransac_normalize_kernel, dim3(P), dim3(128), 0, st, nmatch, ps0, ps1, pn0, pn1, T);
+    const float *w0 = d_sets ? pts0 : ps0, *w1 = d_sets ? pts1 : ps1;
+    if (!d_sets) hipLaunchKernelGGL(ransac_sort_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, ps0, ps1);
+    hipLaunchKernelGGL(ransac_normalize_kernel, dim3(P), dim3(128), 0, st, nmatch, w0, w1, pn0, pn1, T);
     hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, P), dim3(64), 0, st, nmatch, pn0, pn1, T, seed, iters,
-                       F);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, P), dim3(256), 0, st, nmatch, ps0, ps1, F, sigma,
-                       iters, score);
+                       d_sets, F);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((iters + 3) / 4, P), dim3(256), 0, st, nmatch, w0, w1, F, sigma,
+                       iters, score, ninl);
   }
-  hipLaunchKernelGGL(ransac_select_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, F, score, sigma, iters,
-                     enable, (const DMatchR *)matches, (DMatchR *)out, nout, inliers, Fbest, best_score);
+  hipLaunchKernelGGL(ransac_select_kernel, dim3(P), dim3(1024), 0, st, nmatch, pts0, pts1, F, score, ninl, sigma,
+                     confidence, iters, enable, (const DMatchR *)matches, (DMatchR *)out, nout, inliers, Fbest, best_score);
   URF_HIP(hipGetLastError());
   return 0;
 }

@@ -22,13 +22,19 @@ int launch_score(const float *mdesc, const int *counts, float alpha, float *C, f
                  hipStream_t st);
 int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u, float *v, int iters, int P,
                     bool fast, hipStream_t st);
+size_t sinkhorn_resident_xin_granules(int maxP);
+size_t sinkhorn_resident_xbc_granules(int maxP);
+int sinkhorn_resident_enabled();
+int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
+                             void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st);
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int P,
                   hipStream_t st);
-int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0, float *pn1, float *T, float *F,
-                  float *score, uint32_t seed, int iters, float sigma, int enable, const void *matches, void *out,
-                  int *nout, uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st);
+int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
+                  float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
+                  double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
+                  uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st);
 
 constexpr int NP = kCap, LDC = 1028, SG_LAYERS = 18;
 enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC, PT_COUNT };
@@ -41,6 +47,8 @@ struct urf_pm {
   urf_sg_config cfg;
   int device = 0, maxP = 1, iters = 100, r_iters = 200;
   float r_sigma = 1.0f;
+  double r_conf = 0.99;              // <= 0: every hypothesis counts
+  int *ninl = nullptr, *d_sets = nullptr;
   hipStream_t st = nullptr;
   bool own_stream = true;
   hipEvent_t ev_done = nullptr;
@@ -65,6 +73,11 @@ struct urf_pm {
   float *kin = nullptr, *kxy = nullptr, *x = nullptr, *tA = nullptr, *tB = nullptr, *qkv = nullptr, *o = nullptr,
         *msg = nullptr, *hid = nullptr, *mdesc = nullptr;
   float *C = nullptr, *Ct = nullptr, *u = nullptr, *v = nullptr, *Z = nullptr;
+  // LDS-resident Sinkhorn (fast mode): exchange granules, launch salt, device error word and its pinned mirror
+  unsigned long long *rs_xin = nullptr, *rs_xbc = nullptr;
+  unsigned rs_salt = 0;
+  int *rs_err = nullptr, *h_rs_err = nullptr;
+  bool rs_on = false;
   int *mi0 = nullptr, *mi1 = nullptr, *idx0 = nullptr, *idx1 = nullptr, *nmatch = nullptr, *nfinal = nullptr;
   float *mv0 = nullptr, *mv1 = nullptr;
   double *ms0 = nullptr, *ms1 = nullptr;
@@ -104,7 +117,14 @@ extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
   h->maxP = cfg->max_pairs > 0 ? cfg->max_pairs : 1;
   h->iters = cfg->sinkhorn_iterations > 0 ? cfg->sinkhorn_iterations : 100;
   h->r_iters = cfg->ransac_iterations > 0 ? cfg->ransac_iterations : 200;
-  h->r_sigma = cfg->ransac_sigma > 0 ? cfg->ransac_sigma : 1.0f;
+  // inlier gate: sigma as given, else from the pixel threshold of the reference call (3 px -> sigma 1.5307,
+  // 3.841 sigma^2 = 9 px^2); confidence of the reference call unless switched off
+  {
+    const float px = cfg->ransac_threshold_px > 0 ? cfg->ransac_threshold_px : 3.0f;
+    h->r_sigma = cfg->ransac_sigma > 0 ? cfg->ransac_sigma : (float)((double)px / sqrt(3.841));
+    h->r_conf = cfg->ransac_confidence < 0 ? 0.0 : (cfg->ransac_confidence > 0 ? (double)cfg->ransac_confidence : 0.99);
+    URF_CHECK(h->r_conf < 1.0, "ransac_confidence must be below 1");
+  }
   h->precision = cfg->precision;
   URF_CHECK(h->precision == 0 || h->precision == 1, "precision must be 0 (exact fp32) or 1 (fast split-f16)");
   *out = h;
@@ -260,7 +280,12 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     if (dalloc(&h->vth, NI * NP * 256) || dalloc(&h->vtl, NI * NP * 256)) return -1;
     if (dalloc(&h->oh, NI * NP * 256) || dalloc(&h->ol, NI * NP * 256)) return -1;
     if (dalloc(&h->hh, NI * NP * 512) || dalloc(&h->hl, NI * NP * 512)) return -1;
+    h->rs_on = sinkhorn_resident_enabled() != 0;
+    if (dalloc(&h->rs_xin, sinkhorn_resident_xin_granules((int)P)) || dalloc(&h->rs_xbc, sinkhorn_resident_xbc_granules((int)P))) return -1;
   }
+  if (dalloc(&h->rs_err, 4)) return -1;
+  URF_HIP(hipHostMalloc((void **)&h->h_rs_err, 4 * sizeof(int), hipHostMallocDefault));
+  h->h_rs_err[0] = 0;
   if (dalloc(&h->counts, NI)) return -1;
   if (dalloc(&h->kin, NI * NP * 4)) return -1;
   if (dalloc(&h->kxy, NI * NP * 2)) return -1;
@@ -299,6 +324,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->T, P * 18)) return -1;
   if (dalloc(&h->F, P * (size_t)h->r_iters * 9)) return -1;
   if (dalloc(&h->score, P * (size_t)h->r_iters)) return -1;
+  if (dalloc(&h->ninl, P * (size_t)h->r_iters)) return -1;
+  if (dalloc(&h->d_sets, (size_t)h->r_iters * 8)) return -1;
   if (dalloc(&h->Fbest, P * 9)) return -1;
   if (dalloc(&h->best_score, P)) return -1;
   if (dalloc(&h->inliers, P * NP)) return -1;
@@ -330,10 +357,11 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
-                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs};
+                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets};
     for (void *p : bufs) (void)hipFree(p);
     (void)hipHostFree(h->h_matches);
     (void)hipHostFree(h->h_n);
+    (void)hipHostFree(h->h_rs_err);
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 18; ++i) { (void)hipEventDestroy(h->ev_attn[i][0]); (void)hipEventDestroy(h->ev_attn[i][1]); }
@@ -457,18 +485,35 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
   (void)hipEventRecord(h->ev_sink, st);
-  if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, h->precision == 1, st)) return -1;
+  if (h->precision == 1 && h->rs_on) {
+    // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
+    if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, &h->rs_salt,
+                                 h->rs_err, h->device, st))
+      return -1;
+    URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, h->precision == 1, st)) return -1;
   mark(PT_DECODE);
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
                     h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,
                     want_Z ? h->Z : nullptr, P, st))
     return -1;
   mark(PT_RANSAC);
-  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
-                    h->r_sigma, ransac ? 1 : 0, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest,
-                    h->best_score, P, st))
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
+                    h->cfg.ransac_seed, h->r_iters, h->r_sigma, h->r_conf, nullptr, ransac ? 1 : 0, h->matches, h->fmatches,
+                    h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
     return -1;
   mark(PT_COUNT);
+  return 0;
+}
+
+// after the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?
+static int pm_check_resident(urf_pm *h) {
+  if (h->h_rs_err && h->h_rs_err[0] != 0) {
+    h->h_rs_err[0] = 0;
+    (void)hipMemsetAsync(h->rs_err, 0, sizeof(int), h->st);
+    URF_CHECK(false, "resident Sinkhorn timed out: its %d workgroups per pair never became co-resident (another process "
+                     "on this GPU?); set URF_SINKHORN_RESIDENT=0 to use the streaming kernels", 32);
+  }
   return 0;
 }
 
@@ -548,6 +593,7 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
                              hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
   pm_collect_times(h);
+  if (pm_check_resident(h)) return -3;
   return 0;
 }
 
@@ -567,6 +613,7 @@ extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, 
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
   pm_collect_times(h);
+  if (pm_check_resident(h)) return -3;
   const int n = h->h_n[0];
   URF_CHECK(n <= cap, "match buffer too small: %d > cap %d", n, cap);
   memcpy(out, h->h_matches, (size_t)n * sizeof(urf_dmatch));
@@ -609,6 +656,7 @@ extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nou
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
+  if (pm_check_resident(h)) return -3;
   URF_CHECK(P >= 1 && P <= h->maxP && out && nout, "urf_pm_fetch: bad argument");
   for (int p = 0; p < P; ++p) {
     const int n = h->h_n[p];
@@ -626,8 +674,10 @@ extern "C" int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, c
   return urf_pm_fetch(h, P, out, cap, nout);
 }
 
-extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n, uint8_t *inliers, float *F21,
-                                 float *score) {
+// sets == nullptr: the handle's configured search (counter-hash sampler, canonical order, confidence stop);
+// else: the explicit minimal sets, caller's order, every hypothesis counts
+static int pm_find_F(urf_pm *h, const float *pts0, const float *pts1, int n, const int *sets, int iterations,
+                     uint8_t *inliers, float *F21, float *score) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(pts0 && pts1 && inliers && F21 && score && n >= 0 && n <= NP, "urf_ransac_find_F: bad argument");
   memset(inliers, 0, n);
@@ -635,17 +685,43 @@ extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1
   *score = 0.0f;
   if (n < 8) return 0;
   URF_HIP(hipSetDevice(h->device));
+  if (sets) {
+    URF_CHECK(iterations >= 1 && iterations <= h->r_iters, "explicit sets: %d iterations outside [1, %d] (ransac_iterations of the handle)",
+              iterations, h->r_iters);
+    for (int k = 0; k < iterations * 8; ++k) URF_CHECK(sets[k] >= 0 && sets[k] < n, "explicit sets: index %d out of range", sets[k]);
+    URF_HIP(hipMemcpyAsync(h->d_sets, sets, (size_t)iterations * 8 * sizeof(int), hipMemcpyHostToDevice, h->st));
+  }
   URF_HIP(hipMemcpyAsync(h->nmatch, &n, sizeof(int), hipMemcpyHostToDevice, h->st));
   URF_HIP(hipMemcpyAsync(h->pts0, pts0, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
   URF_HIP(hipMemcpyAsync(h->pts1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
-  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->cfg.ransac_seed, h->r_iters,
-                    h->r_sigma, 1, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, 1, h->st))
+  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
+                    h->cfg.ransac_seed, sets ? iterations : h->r_iters, h->r_sigma, sets ? 0.0 : h->r_conf,
+                    sets ? h->d_sets : nullptr, 1, h->matches, h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, 1,
+                    h->st))
     return -1;
   URF_HIP(hipMemcpyAsync(inliers, h->inliers, n, hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(F21, h->Fbest, 9 * sizeof(float), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(score, h->best_score, sizeof(float), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipStreamSynchronize(h->st));
+  return 0;
+}
+
+extern "C" int urf_ransac_find_F(urf_pm *h, const float *pts0, const float *pts1, int n, uint8_t *inliers, float *F21,
+                                 float *score) {
+  return pm_find_F(h, pts0, pts1, n, nullptr, 0, inliers, F21, score);
+}
+
+extern "C" int urf_ransac_find_F_sets(urf_pm *h, const float *pts0, const float *pts1, int n, const int *sets,
+                                      int iterations, uint8_t *inliers, float *F21, float *score) {
+  URF_CHECK(sets, "urf_ransac_find_F_sets: null sets");
+  return pm_find_F(h, pts0, pts1, n, sets, iterations, inliers, F21, score);
+}
+
+extern "C" int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts) {
+  URF_CHECK(h && h->built && d_matches && d_counts, "urf_pm_device_results: bad argument");
+  *d_matches = h->fmatches;
+  *d_counts = h->nfinal;
   return 0;
 }
 

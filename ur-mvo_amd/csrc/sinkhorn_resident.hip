@@ -1,0 +1,393 @@
+// sinkhorn_resident.hip -- the 100 Sinkhorn iterations of SuperGlue's optimal-transport layer
+// (recurrence: src/super_glue.cpp:432-498 of the reference) as ONE persistent launch whose
+// couplings matrix never leaves the chip (fast precision mode; DESIGN.md "Sinkhorn").
+//
+// The streaming form (sg_kernels.hip, sinkhorn_half_kernel) reads C or C^T from the Infinity
+// Cache in every one of the 200 half-iterations: 6.4 GB of fabric traffic per 8-pair step.  Here a
+// pair is spread over 32 workgroups = 32 CUs (8 pairs = the whole chip); workgroup w keeps rows
+// [32w, 32w+32) of the plan in LDS (32 x 1024 f32 = 128 KiB).  The iteration itself is the scaling form of the same recurrence,
+//     P_ij = exp(C_ij + u0_i + v0_j),   u = u0 + log a,   v = v0 + log b,
+//     a_i = mu_i / sum_j P_ij b_j        (row pass: local to the workgroup that owns row i)
+//     b_j = nu_j / sum_i a_i P_ij        (column pass: 32 partial sums per column, one exchange)
+// which is algebraically the reference's  u = log_mu - LSE_j(C + v),  v = log_nu - LSE_i(C + u)
+// with the exponentials taken once per re-absorption instead of once per element per pass.  (u0, v0)
+// are re-absorbed from C (a_i b_j folded into P, recomputed from the couplings in HBM/L2) after
+// iterations 1, 2, 4, 8, ...: the scalings stay near 1, so no entry of P under- or overflows on the way.
+// The dustbin row and column (constant alpha, :466-474) are carried analytically, never stored.
+//
+// Exchange per iteration (one all-reduce of 1025 column sums over the 32 workgroups of a pair), two
+// hops of 8-byte {tag, value} granules written with agent-scope (sc1, write-through) stores and
+// polled with agent-scope loads -- the data is the flag, no fence (cdna_hip_programming.md G16/R2):
+//   hop 1: workgroup w -> reducer r = column / 32;   hop 2: reducer -> every workgroup.
+// Every spin is bounded (0.25 s of s_memrealtime): a launch that cannot become co-resident gives up,
+// raises *err and the host reports an error instead of hanging the GPU.
+#include "urf_common.h"
+#include "urf_math.h"
+
+#include <float.h>
+#include <stdlib.h>
+
+#include <mutex>
+
+namespace urf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;   // explicitly global: the polling loads must be global_load ... sc1, never flat
+
+constexpr int RS_NP = kCap;          // 1024 keypoints per image at most
+constexpr int RS_LDC = 1028;         // leading dimension of C in HBM (sg_kernels.hip)
+constexpr int RS_WG = 32;            // workgroups (CUs) per pair
+constexpr int RS_ROWS = 32;          // plan rows per workgroup
+constexpr int RS_T = 1024;           // threads per workgroup: thread t owns column t
+constexpr int RS_XIN = RS_WG * RS_WG * 32 + RS_WG;   // hop-1 granules per pair: [reducer][source][32 columns] + column 1024 [source]
+constexpr int RS_XBC = 1056;                 // hop-2 granules per pair (1025 used)
+constexpr u64 RS_TIMEOUT_TICKS = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
+
+struct RsArgs {
+  const int *counts;
+  const float *C;
+  float *u, *v;
+  float alpha;
+  int iters, pair0, npairs;
+  u64 *xin, *xbc;
+  unsigned salt;
+  int *err;
+};
+
+__device__ __forceinline__ void rs_store(u64 *p, unsigned tag, float v) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every lane of the wave with `active` set re-reads its own granule until all their tags equal `tag`.
+// Returns false when the launch gave up (time-out here or in another workgroup).
+__device__ __forceinline__ bool rs_wait(const u64 *p, bool active, unsigned tag, float &val, int *err) {
+  u64 t0 = 0;
+  for (unsigned spins = 1;; ++spins) {
+    bool ok = true;
+    if (active) {
+      const u64 x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      val = __uint_as_float((unsigned)x);
+      ok = (unsigned)(x >> 32) == tag;
+    }
+    if (__all(ok)) return true;
+    if ((spins & 255u) == 0) {
+      const u64 now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      const bool late = now - t0 > RS_TIMEOUT_TICKS;
+      if (late) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (late || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// ONE wave re-reads its granules g = lane + 64 k (k < N, g < count) every pass until all their tags equal `tag`
+// (the polling stays with one wave per CU: sixteen waves polling at once cost 3-5 us per hop).  The values of a
+// pass are consumed on the fly -- summed per lane in k order (SUM) or written to dst[g] in LDS -- and are
+// only meaningful for the pass that returns true.
+template <int N, bool SUM>
+__device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned tag, float &sum, float *dst, int lane, int *err) {
+  u64 t0 = 0;
+  const gu64 *q = (const gu64 *)base + lane;
+  for (unsigned spins = 1;; ++spins) {
+    bool ok = true;
+    float acc = 0.0f;
+    asm volatile("" : "+v"(q));   // one live address per lane: keep the compiler from parking N 64-bit addresses in registers
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int g = lane + 64 * k;
+      if (g < count) {
+        const u64 x = __hip_atomic_load(q + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v = __uint_as_float((unsigned)x);
+        if (SUM) acc = acc + v; else dst[g] = v;
+        ok = ok && ((unsigned)(x >> 32) == tag);
+      }
+    }
+    sum = acc;
+    if (__all(ok)) return true;
+    if ((spins & 63u) == 0) {
+      const u64 now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      const bool late = now - t0 > RS_TIMEOUT_TICKS;
+      if (late) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (late || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this half of the wave
+#pragma unroll
+  for (int s = 16; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Pt = lds;                      // [32][1024] plan rows of this workgroup
+  float *bvec = Pt + RS_ROWS * RS_NP;   // [1024] b_j (0 for j >= n1)
+  float *v0vec = bvec + RS_NP;          // [1024] v0_j
+  float *avec = v0vec + RS_NP;          // [32] a_i of the own rows (0 for i >= n0)
+  float *u0vec = avec + RS_ROWS;        // [32]
+  float *pcvec = u0vec + RS_ROWS;       // [32] dustbin-column entries exp(alpha + u0_i + v0_dust)
+  float *wsum = pcvec + RS_ROWS;        // [16] per-wave partials of the dustbin-row sum
+  float *misc = wsum + 16;              // [0] = b of the dustbin column, [1] = "the launch gave up"
+  float *csumv = misc + 16;             // [1025 (+3)] reduced column sums of this iteration
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pl = (int)blockIdx.x % a.npairs, w = (int)blockIdx.x / a.npairs;   // pairs congruent mod 8 share an XCD at 8 pairs
+  const int p = a.pair0 + pl;
+  const int n0 = a.counts[2 * p], n1 = a.counts[2 * p + 1];
+  const float *Cp = a.C + (size_t)p * (RS_NP + 1) * RS_LDC;
+  u64 *xin = a.xin + (size_t)p * RS_XIN, *xbc = a.xbc + (size_t)p * RS_XBC;
+  const float tot = (float)(n0 + n1);
+  const float mu = 1.0f / tot, mu_d = (float)n1 / tot, nu = 1.0f / tot, nu_d = (float)n0 / tot;
+  const float alpha = a.alpha;
+  const int i0 = w * RS_ROWS;                 // first plan row of this workgroup
+  const int t = tid;                          // this thread's column
+  const bool col_ok = t < n1;
+  const int r0 = 2 * wv, r1 = 2 * wv + 1;     // the two rows this wave sums in the row pass
+  // owner of the dustbin column's slot: thread n1 (its own column is invalid) or, at n1 == 1024, thread 0's second slot
+  const bool own_dust = (n1 < RS_NP) ? (t == n1) : (t == 0);
+
+  float b_t = col_ok ? 1.0f : 0.0f, v0_t = 0.0f, pd_t = 0.0f;
+  float u0d = -alpha, v0d = 0.0f, Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
+
+  // ---- u0_i = -max_j C_ij over the valid columns and the dustbin entry alpha (local to the row's owner)
+  {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int ri = r0 + rr, i = i0 + ri;
+      float m = alpha;
+      if (i < n0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 256 * q + 4 * lane;
+          const f32x4 x = *(const f32x4 *)(Cp + (size_t)i * RS_LDC + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < n1) m = fmaxf(m, x[e]);
+        }
+      }
+      m = bfly64_max(m);
+      if (lane == 0) u0vec[ri] = -m;
+    }
+    v0vec[t] = 0.0f;
+  }
+
+  // (re)build the plan tile from the couplings: P_ij = exp(C_ij + u0_i + v0_j); b = 1
+  auto absorb = [&]() {
+    __syncthreads();                      // u0vec / v0vec written, nobody still reads Pt / bvec
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int ri = r0 + rr, i = i0 + ri;
+      const float u0i = u0vec[ri];
+#pragma unroll 2
+      for (int q = 0; q < 4; ++q) {
+        const int c = 256 * q + 4 * lane;
+        f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < n0) {
+          const f32x4 x = *(const f32x4 *)(Cp + (size_t)i * RS_LDC + c);
+          const f32x4 vv = *(const f32x4 *)(v0vec + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < n1) pv[e] = __expf((x[e] + u0i) + vv[e]);
+        }
+        *(f32x4 *)(Pt + ri * RS_NP + c) = pv;
+      }
+      if (lane == 0) pcvec[ri] = (i < n0) ? __expf((alpha + u0i) + v0d) : 0.0f;
+    }
+    bvec[t] = col_ok ? 1.0f : 0.0f;
+    if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
+    __syncthreads();
+    pd_t = col_ok ? __expf((alpha + u0d) + v0_t) : 0.0f;
+    Pdd = __expf((alpha + u0d) + v0d);
+    b_t = col_ok ? 1.0f : 0.0f;
+    bdust = 1.0f;
+  };
+  absorb();
+
+  int next_absorb = 1;
+  for (int k = 1; k <= a.iters; ++k) {
+    const unsigned tag = (a.salt << 12) | (unsigned)k;
+    // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust)
+    __syncthreads();                      // bvec, misc[0] of the previous iteration (or of absorb) are in place
+    bdust = misc[0];
+    {
+      f32x4 b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4 *)(bvec + 256 * q + 4 * lane);
+      float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 p0 = *(const f32x4 *)(Pt + r0 * RS_NP + 256 * q + 4 * lane);
+        const f32x4 p1 = *(const f32x4 *)(Pt + r1 * RS_NP + 256 * q + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = fma_rn(p0[e], b4[q][e], acc0);
+          acc1 = fma_rn(p1[e], b4[q][e], acc1);
+        }
+      }
+      acc0 = bfly64_sum(acc0);
+      acc1 = bfly64_sum(acc1);
+      const float part = bfly64_sum(pd_t * b_t);          // dustbin row: sum_j pd_j b_j
+      if (lane == 0) {
+        const float ra = fma_rn(pcvec[r0], bdust, acc0), rb = fma_rn(pcvec[r1], bdust, acc1);
+        avec[r0] = (i0 + r0 < n0) ? mu / ra : 0.0f;
+        avec[r1] = (i0 + r1 < n0) ? mu / rb : 0.0f;
+        wsum[wv] = part;
+      }
+    }
+    __syncthreads();
+    {
+      float rd = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *(const f32x4 *)(wsum + 4 * q);
+        rd = (((rd + x[0]) + x[1]) + x[2]) + x[3];
+      }
+      rd = fma_rn(Pdd, bdust, rd);
+      ad = mu_d / rd;
+    }
+    // ---------------- column pass: partial sums over the own 32 rows (a_i broadcast from LDS, P_it read down the column: conflict-free)
+    float creg = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 x = *(const f32x4 *)(avec + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) creg = fma_rn(x[e], Pt[(4 * q + e) * RS_NP + t], creg);
+    }
+    if (!col_ok) creg = 0.0f;
+    float cdust = 0.0f;
+    if (wv == ((n1 & (RS_NP - 1)) >> 6)) {    // the wave of the dustbin slot's owner (uniform branch)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 x = *(const f32x4 *)(avec + 4 * q), y = *(const f32x4 *)(pcvec + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cdust = fma_rn(x[e], y[e], cdust);
+      }
+    }
+    // ---------------- all-reduce of the 1025 column sums over the 32 workgroups of the pair
+    {   // hop 1, publish: column t -> reducer t / 32; 32 consecutive lanes write 256 contiguous bytes
+      const float v1 = (n1 < RS_NP && t == n1) ? cdust : creg;
+      rs_store(xin + ((size_t)((t >> 5) * RS_WG + w) * 32 + (t & 31)), tag, v1);
+      if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f);
+    }
+    if (wv == 0) {   // wave 0 alone talks to the other CUs; waves 1..15 park at the barrier below
+      bool alive = true;
+      {   // hop 1, reduce: this workgroup sums columns [32w, 32w+32) over the 32 sources.  Granule g = 32 src + column:
+          // lane L sums column L & 31 over the sources (L >> 5) + 2k in k order, then the two half-waves are added
+        float x = 0.0f;
+        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err);
+        x = x + __shfl_xor(x, 32, 64);
+        if (alive && lane < 32) rs_store(xbc + 32 * w + lane, tag, x);
+        if (alive && w == 31) {           // column 1024 (the dustbin column when n1 == 1024)
+          float y = 0.0f;
+          alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RS_WG, tag, y, nullptr, lane, a.err);
+          const float ys = half_sum32(lane < 32 ? y : 0.0f);
+          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys);
+        }
+      }
+      if (alive) {   // hop 2: the 1025 reduced sums of every reducer -> LDS
+        float unused = 0.0f;
+        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err);
+      }
+      if (!alive && lane == 0) misc[1] = 1.0f;
+    }
+    __syncthreads();
+    if (misc[1] != 0.0f) return;
+    const float csum = csumv[t], csum2 = csumv[1024];
+    // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
+    b_t = col_ok ? nu / fma_rn(ad, pd_t, csum) : 0.0f;
+    bvec[t] = b_t;
+    if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, (n1 < RS_NP) ? csum : csum2);
+    // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
+    if (k == next_absorb && k < a.iters) {
+      next_absorb *= 2;
+      __syncthreads();                    // misc[0] written
+      bdust = misc[0];
+      if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + __logf(avec[tid]);
+      u0d = u0d + __logf(ad);
+      if (col_ok) v0_t = v0_t + __logf(b_t);
+      v0vec[t] = v0_t;
+      v0d = v0d + __logf(bdust);
+      absorb();
+    }
+  }
+  // ---------------- u = u0 + log a, v = v0 + log b
+  __syncthreads();
+  bdust = misc[0];
+  if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = u0vec[tid] + __logf(avec[tid]);
+  if (w == 0) {
+    if (col_ok) a.v[(size_t)p * RS_LDC + t] = v0_t + __logf(b_t);
+    if (tid == 0) {
+      a.u[(size_t)p * RS_LDC + n0] = u0d + __logf(ad);
+      a.v[(size_t)p * RS_LDC + n1] = v0d + __logf(bdust);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host side.  Two resident launches must never be in flight together (each needs every workgroup of
+// its grid on a CU of its own before any of them can finish): launches of one process are chained on a
+// per-device event.  Launches from another process are not seen here; the bounded spins turn that
+// case into an error instead of a hang.
+struct RsDevice {
+  std::mutex mu;
+  hipEvent_t last = nullptr;
+  int cus = -1;
+};
+static RsDevice g_rs_dev[16];
+
+size_t sinkhorn_resident_xin_granules(int maxP) { return (size_t)maxP * RS_XIN; }
+size_t sinkhorn_resident_xbc_granules(int maxP) { return (size_t)maxP * RS_XBC; }
+
+// 1 = use the resident kernel (fast mode default), 0 = the streaming launches; URF_SINKHORN_RESIDENT overrides
+int sinkhorn_resident_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("URF_SINKHORN_RESIDENT");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v;
+}
+
+int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
+                             void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st) {
+  URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
+  URF_CHECK(iters >= 1 && iters < 4096, "sinkhorn_resident: iterations %d outside [1, 4095]", iters);
+  RsDevice &d = g_rs_dev[device];
+  std::lock_guard<std::mutex> lock(d.mu);
+  const size_t lds = sizeof(float) * (RS_ROWS * RS_NP + 2 * RS_NP + 3 * RS_ROWS + 32 + 1028);
+  if (d.cus < 0) {
+    hipDeviceProp_t prop;
+    URF_HIP(hipGetDeviceProperties(&prop, device));
+    d.cus = prop.multiProcessorCount;
+    URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
+    URF_HIP(hipEventRecord(d.last, st));
+  }
+  int group = d.cus / RS_WG;                  // pairs per launch: one workgroup per CU
+  {
+    static int knob = -1;                     // URF_SINKHORN_GROUP (A/B runs): fewer pairs per launch leave CUs to the other streams
+    if (knob < 0) { const char *e = getenv("URF_SINKHORN_GROUP"); knob = e ? atoi(e) : 0; }
+    if (knob >= 1 && knob < group) group = knob;
+  }
+  URF_CHECK(group >= 1, "sinkhorn_resident: the device has %d CUs, a pair needs %d", d.cus, RS_WG);
+  for (int p0 = 0; p0 < P; p0 += group) {
+    RsArgs a;
+    a.counts = counts; a.C = C; a.u = u; a.v = v; a.alpha = alpha; a.iters = iters;
+    a.pair0 = p0; a.npairs = (P - p0 < group) ? (P - p0) : group;
+    a.xin = (u64 *)xin; a.xbc = (u64 *)xbc;
+    *salt = (*salt % 0xFFFFFu) + 1;           // tags are (salt << 12 | iteration), never 0
+    a.salt = *salt; a.err = err;
+    URF_HIP(hipStreamWaitEvent(st, d.last, 0));
+    hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
+    URF_HIP(hipGetLastError());
+    URF_HIP(hipEventRecord(d.last, st));
+  }
+  return 0;
+}
+
+}  // namespace urf

@@ -7,8 +7,60 @@ ranks, SuperPoint locally, ONE all-gather (RCCL over xGMI when the backend is
 matches the pairs whose second frame it owns.  No other collective is on the
 data path; the host tracker that consumes the match lists stays serial.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
+from ._lib import check
+
+
+class Comm:
+    """the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI.  One instance per rank.
+
+        id_bytes = Comm.unique_id() on rank 0, shipped to the other ranks by any host channel;
+        Comm(world, rank, device, id_bytes).  world == 1 with id_bytes=None never loads RCCL."""
+
+    def __init__(self, world, rank, device, id_bytes=None):
+        self.world, self.rank, self.device = int(world), int(rank), int(device)
+        self._h = C.c_void_p()
+        buf = None if id_bytes is None else C.create_string_buffer(bytes(id_bytes), 128)
+        check(_lib.lib().urf_comm_init(self.world, self.rank, self.device, buf, C.byref(self._h)), "urf_comm_init")
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().urf_comm_unique_id(buf), "urf_comm_unique_id")
+        return buf.raw
+
+    def allgather_slots(self, d_local, nslots, d_all, stream=None):
+        """d_all[world * nslots] <- every rank's d_local[nslots] (device pointers), enqueued on `stream` (hipStream_t)"""
+        check(_lib.lib().urf_comm_allgather_slots(self._h, C.c_void_p(d_local), int(nslots), C.c_void_p(d_all),
+                                                  C.c_void_p(stream)), "urf_comm_allgather_slots")
+
+    def gather(self, d_send, nbytes, d_recv, root=0, stream=None):
+        check(_lib.lib().urf_comm_gather(self._h, C.c_void_p(d_send), C.c_size_t(nbytes), C.c_void_p(d_recv), int(root),
+                                         C.c_void_p(stream)), "urf_comm_gather")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().urf_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def plan_pairs(world, rank, per_rank):
+    """urf_comm_plan_pairs: (first, second) indices into the gathered slots of the pairs `rank` matches in a step;
+    first == -1 is the carried last frame of the previous step"""
+    a = np.zeros(per_rank, np.int32)
+    b = np.zeros(per_rank, np.int32)
+    check(_lib.lib().urf_comm_plan_pairs(int(world), int(rank), int(per_rank), a.ctypes.data_as(C.c_void_p),
+                                         b.ctypes.data_as(C.c_void_p)), "urf_comm_plan_pairs")
+    return a, b
 
 
 def shard_range(n_frames, rank, world):

@@ -149,10 +149,13 @@ PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac
 
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
-                 ransac_sigma=1.0, ransac_seed=0, precision=0):
+                 ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0):
+        """outlier stage: all-zero = the reference call's parameters (3 px, confidence 0.99, src/point_matching.cc:50);
+        ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count"""
         self.cfg = cfg
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
-                           max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision)
+                           max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision,
+                           ransac_threshold_px, ransac_confidence)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 
@@ -240,6 +243,12 @@ class PointMatching(_PM):
     def sync(self):
         check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
 
+    def device_results(self):
+        """device pointers (matches [max_pairs][1024] x 12 B, counts [max_pairs] int) of the last batch"""
+        m, n = C.c_void_p(), C.c_void_p()
+        check(_lib.lib().urf_pm_device_results(self._h, C.byref(m), C.byref(n)), "urf_pm_device_results")
+        return m.value, n.value
+
     def wait_for_sp(self, superpoint):
         check(_lib.lib().urf_pm_wait_for_sp(self._h, superpoint._h), "urf_pm_wait_for_sp")
 
@@ -261,18 +270,32 @@ class PointMatching(_PM):
         check(_lib.lib().urf_ransac_find_F(self._h, _p(p0), _p(p1), n, _p(inl), _p(F), C.byref(s)), "find_F")
         return float(s.value), inl[:n], F.reshape(3, 3)
 
+    def find_F_sets(self, pts0, pts1, sets):
+        """_find_F over explicit minimal sets [iterations, 8] (the reference's _vSets), caller's order"""
+        p0 = np.ascontiguousarray(pts0, np.float32)
+        p1 = np.ascontiguousarray(pts1, np.float32)
+        st = np.ascontiguousarray(sets, np.int32)
+        n = p0.shape[0]
+        inl = np.zeros(max(n, 1), np.uint8)
+        F = np.zeros(9, np.float32)
+        s = C.c_float(0)
+        check(_lib.lib().urf_ransac_find_F_sets(self._h, _p(p0), _p(p1), n, _p(st), st.shape[0], _p(inl), _p(F), C.byref(s)),
+              "find_F_sets")
+        return float(s.value), inl[:n], F.reshape(3, 3)
+
 
 class EpipolarGeometry:
     """EpipolarGeometry (include/epipolar_geometry.h:20-40 of UR-MVO): two-view
     initialisation.  Runs on the matcher's device/stream (pass a built
     PointMatching or SuperGlue object)."""
 
-    def __init__(self, matcher, K, sigma=1.0, iterations=200, seed=0):
+    def __init__(self, matcher, K, sigma=1.0, iterations=200, seed=0, sampler=0):
+        """sampler 0: the build's counter hash; 1: the reference's rand() stream after srand(seed)"""
         self._m = matcher
-        self._cfg = _lib.EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed)
+        self._cfg = _lib.EpiConfig((C.c_float * 9)(*np.asarray(K, np.float32).reshape(-1)), sigma, iterations, seed, sampler)
 
-    def reconstruct(self, vKeys1, vKeys2, vMatches12):
-        """-> (ok, T21[4,4], vP3D[n1,3], vbTriangulated[n1], model, (SH, SF))"""
+    def reconstruct(self, vKeys1, vKeys2, vMatches12, sets=None):
+        """-> (ok, T21[4,4], vP3D[n1,3], vbTriangulated[n1], model, (SH, SF)); sets: explicit minimal sets [iterations, 8]"""
         k1 = np.ascontiguousarray(vKeys1, np.float32)
         k2 = np.ascontiguousarray(vKeys2, np.float32)
         m = np.ascontiguousarray(vMatches12, np.int32)
@@ -282,8 +305,15 @@ class EpipolarGeometry:
         tri = np.zeros(max(n1, 1), np.uint8)
         model = C.c_int(-1)
         sc = np.zeros(2, np.float32)
-        rc = check(_lib.lib().urf_epipolar_reconstruct(self._m._h, C.byref(self._cfg), _p(k1), n1, _p(k2), n2, _p(m),
-                                                       _p(T), _p(P), _p(tri), C.byref(model), _p(sc)), "reconstruct")
+        if sets is not None:
+            st = np.ascontiguousarray(sets, np.int32)
+            assert st.shape == (self._cfg.iterations, 8)
+            rc = check(_lib.lib().urf_epipolar_reconstruct_sets(self._m._h, C.byref(self._cfg), _p(k1), n1, _p(k2), n2, _p(m),
+                                                                _p(st), _p(T), _p(P), _p(tri), C.byref(model), _p(sc)),
+                       "reconstruct_sets")
+        else:
+            rc = check(_lib.lib().urf_epipolar_reconstruct(self._m._h, C.byref(self._cfg), _p(k1), n1, _p(k2), n2, _p(m),
+                                                           _p(T), _p(P), _p(tri), C.byref(model), _p(sc)), "reconstruct")
         return bool(rc), T.reshape(4, 4), P[:n1], tri[:n1], model.value, (float(sc[0]), float(sc[1]))
 
 
@@ -365,12 +395,13 @@ class FrameStream:
 
     def __init__(self, sp_cfg, sg_cfg, batch=8, max_height=0, max_width=0, device=0, precision=0, matchers=2,
                  history_batches=0, outlier_rejection=True, sinkhorn_iterations=100, ransac_iterations=200,
-                 ransac_sigma=1.0, ransac_seed=0):
+                 ransac_sigma=0.0, ransac_seed=0, ransac_threshold_px=0.0, ransac_confidence=0.0):
         c = _lib.FEConfig()
         c.sp = SPConfig(sp_cfg.max_keypoints, sp_cfg.keypoint_threshold, sp_cfg.remove_borders, max_height, max_width,
                         batch, device, precision)
         c.sg = SGConfig(sg_cfg.image_width, sg_cfg.image_height, sg_cfg.matching_threshold, sinkhorn_iterations, batch,
-                        device, ransac_iterations, ransac_sigma, ransac_seed, precision)
+                        device, ransac_iterations, ransac_sigma, ransac_seed, precision, ransac_threshold_px,
+                        ransac_confidence)
         c.batch, c.matchers, c.history_batches, c.outlier_rejection = batch, matchers, history_batches, int(outlier_rejection)
         self.batch = batch
         self._h = C.c_void_p()
@@ -494,3 +525,10 @@ def probe_divsqrt(a, b, device=0):
 
 def set_profiling(on):
     _lib.lib().urf_set_profiling(int(bool(on)))
+
+
+def minimal_sets(sampler, seed, n, iterations):
+    """urf_minimal_sets: sampler 0 = counter hash, 1 = the reference's glibc rand() stream after srand(seed)"""
+    sets = np.zeros((iterations, 8), np.int32)
+    check(_lib.lib().urf_minimal_sets(int(sampler), C.c_uint32(seed), int(n), int(iterations), _p(sets)), "urf_minimal_sets")
+    return sets
