@@ -355,6 +355,8 @@ int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, i
                      int reps, float *ms_out, int device);
 /* research probe: ncases independent v_mfma_f32_16x16x32_f16 (A 16x32 f16, B 32x16 f16, C/D 16x16 f32, row-major) */
 int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
+/* diagnostic: s_memtime stamps of the LDS-resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
+int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
 
 #ifdef __cplusplus

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 namespace urf {
 
@@ -41,7 +42,7 @@ constexpr int RS_WG = 32;            // workgroups (CUs) per pair
 constexpr int RS_ROWS = 32;          // plan rows per workgroup
 constexpr int RS_T = 1024;           // threads per workgroup: thread t owns column t
 constexpr int RS_XIN = RS_WG * RS_WG * 32 + RS_WG;   // hop-1 granules per pair: [reducer][source][32 columns] + column 1024 [source]
-constexpr int RS_XBC = 1056;                 // hop-2 granules per pair (1025 used)
+constexpr int RS_XBC = 1056 + 32;            // hop-2 granules per pair (1025 used) + the 32 placement granules
 constexpr u64 RS_TIMEOUT_TICKS = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
 
 struct RsArgs {
@@ -53,10 +54,17 @@ struct RsArgs {
   u64 *xin, *xbc;
   unsigned salt;
   int *err;
+  int allow_near;      // 0: always the agent-scope granule stores (A/B runs, URF_SINKHORN_NEAR=0)
+  long long *stamps;   // diagnostic runs only (urf_probe_sinkhorn_stamps): s_memtime at 8 points of every iteration
 };
 
-__device__ __forceinline__ void rs_store(u64 *p, unsigned tag, float v) {
-  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Granule store.  `near` = every workgroup of the pair runs on ONE XCD (verified at run time, below): the store
+// only has to reach that XCD's L2 (sc0: the line stays there) where the readers' L1-bypassing loads find it
+// ~0.1 us later; otherwise the agent-scope form (sc1: written through to the memory side, ~1 us per hop).
+__device__ __forceinline__ void rs_store(u64 *p, unsigned tag, float v, bool near) {
+  const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+  if (near) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Every lane of the wave with `active` set re-reads its own granule until all their tags equal `tag`.
@@ -87,24 +95,32 @@ __device__ __forceinline__ bool rs_wait(const u64 *p, bool active, unsigned tag,
 // pass are consumed on the fly -- summed per lane in k order (SUM) or written to dst[g] in LDS -- and are
 // only meaningful for the pass that returns true.
 template <int N, bool SUM>
-__device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned tag, float &sum, float *dst, int lane, int *err) {
+__device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned tag, float &sum, float *dst, int lane, int *err,
+                                         unsigned *passes = nullptr) {
   u64 t0 = 0;
   const gu64 *q = (const gu64 *)base + lane;
   for (unsigned spins = 1;; ++spins) {
     bool ok = true;
     float acc = 0.0f;
     asm volatile("" : "+v"(q));   // one live address per lane: keep the compiler from parking N 64-bit addresses in registers
+    // all N loads are issued before the first result is looked at: a pass costs ONE memory round trip, not N
+    u64 x[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      x[k] = 0;
+      if (lane + 64 * k < count) x[k] = __hip_atomic_load(q + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int g = lane + 64 * k;
       if (g < count) {
-        const u64 x = __hip_atomic_load(q + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v = __uint_as_float((unsigned)x);
+        const float v = __uint_as_float((unsigned)x[k]);
         if (SUM) acc = acc + v; else dst[g] = v;
-        ok = ok && ((unsigned)(x >> 32) == tag);
+        ok = ok && ((unsigned)(x[k] >> 32) == tag);
       }
     }
     sum = acc;
+    if (passes) *passes = spins;
     if (__all(ok)) return true;
     if ((spins & 63u) == 0) {
       const u64 now = __builtin_amdgcn_s_memrealtime();
@@ -115,6 +131,22 @@ __device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned ta
     }
     __builtin_amdgcn_s_sleep(1);
   }
+}
+
+// wave-wide sum on the DPP network (VALU speed; six dependent v_add_f32 instead of six LDS-crossbar ds_bpermute
+// round trips): quad swaps, half-row and row mirrors, then row_bcast15 / row_bcast31; the total lands in row 3 and
+// is broadcast from lane 63.  The summation order differs from bfly64_sum: fast precision mode only.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
+  };
+  v = v + dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});    // quad_perm [1,0,3,2]
+  v = v + dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
+  v = v + dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});   // row_half_mirror
+  v = v + dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});   // row_mirror: every lane = its row's sum
+  v = v + dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast15 into rows 1, 3
+  v = v + dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this half of the wave
@@ -132,7 +164,7 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   float *u0vec = avec + RS_ROWS;        // [32]
   float *pcvec = u0vec + RS_ROWS;       // [32] dustbin-column entries exp(alpha + u0_i + v0_dust)
   float *wsum = pcvec + RS_ROWS;        // [16] per-wave partials of the dustbin-row sum
-  float *misc = wsum + 16;              // [0] = b of the dustbin column, [1] = "the launch gave up"
+  float *misc = wsum + 16;              // [0] = b of the dustbin column, [1] = "the launch gave up", [2] = one XCD
   float *csumv = misc + 16;             // [1025 (+3)] reduced column sums of this iteration
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -208,12 +240,36 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   };
   absorb();
 
+  // ---- placement: are the 32 workgroups of this pair on one XCD (they are when 8 pairs share a launch: workgroups
+  // b and b + 8 are dealt to the same XCD)?  Every workgroup publishes its XCC id with the always-valid agent-scope
+  // form and reads all 32; all of them see the same 32 values, so they agree on the protocol.  Speed only.
+  bool near = false;
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned tag0 = (a.salt << 12) | 0xFFFu;
+    if (tid == 0) rs_store(xbc + 1056 + w, tag0, (float)(xcc & 15u), false);
+    if (wv == 0) {
+      float ids = 0.0f;
+      const bool alive = rs_sweep<1, true>(xbc + 1056, RS_WG, tag0, ids, nullptr, lane, a.err);
+      const float first = __shfl(ids, 0, 64);
+      const bool same = __all(lane >= RS_WG || ids == first);
+      if (lane == 0) { misc[2] = same ? 1.0f : 0.0f; if (!alive) misc[1] = 1.0f; }
+    }
+    __syncthreads();
+    if (misc[1] != 0.0f) return;
+    near = misc[2] != 0.0f && a.allow_near != 0;
+  }
+
   int next_absorb = 1;
+  const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+#define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   for (int k = 1; k <= a.iters; ++k) {
     const unsigned tag = (a.salt << 12) | (unsigned)k;
     // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust)
     __syncthreads();                      // bvec, misc[0] of the previous iteration (or of absorb) are in place
     bdust = misc[0];
+    RS_STAMP(0);
     {
       f32x4 b4[4];
 #pragma unroll
@@ -229,9 +285,9 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
           acc1 = fma_rn(p1[e], b4[q][e], acc1);
         }
       }
-      acc0 = bfly64_sum(acc0);
-      acc1 = bfly64_sum(acc1);
-      const float part = bfly64_sum(pd_t * b_t);          // dustbin row: sum_j pd_j b_j
+      acc0 = wave_sum_dpp(acc0);
+      acc1 = wave_sum_dpp(acc1);
+      const float part = wave_sum_dpp(pd_t * b_t);        // dustbin row: sum_j pd_j b_j
       if (lane == 0) {
         const float ra = fma_rn(pcvec[r0], bdust, acc0), rb = fma_rn(pcvec[r1], bdust, acc1);
         avec[r0] = (i0 + r0 < n0) ? mu / ra : 0.0f;
@@ -239,7 +295,9 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
         wsum[wv] = part;
       }
     }
+    RS_STAMP(1);
     __syncthreads();
+    RS_STAMP(2);
     {
       float rd = 0.0f;
 #pragma unroll
@@ -271,37 +329,44 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
     // ---------------- all-reduce of the 1025 column sums over the 32 workgroups of the pair
     {   // hop 1, publish: column t -> reducer t / 32; 32 consecutive lanes write 256 contiguous bytes
       const float v1 = (n1 < RS_NP && t == n1) ? cdust : creg;
-      rs_store(xin + ((size_t)((t >> 5) * RS_WG + w) * 32 + (t & 31)), tag, v1);
-      if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f);
+      rs_store(xin + ((size_t)((t >> 5) * RS_WG + w) * 32 + (t & 31)), tag, v1, near);
+      if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, near);
     }
+    RS_STAMP(3);
+    unsigned np1 = 0, np2 = 0;
     if (wv == 0) {   // wave 0 alone talks to the other CUs; waves 1..15 park at the barrier below
       bool alive = true;
       {   // hop 1, reduce: this workgroup sums columns [32w, 32w+32) over the 32 sources.  Granule g = 32 src + column:
           // lane L sums column L & 31 over the sources (L >> 5) + 2k in k order, then the two half-waves are added
         float x = 0.0f;
-        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err);
+        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err, &np1);
         x = x + __shfl_xor(x, 32, 64);
-        if (alive && lane < 32) rs_store(xbc + 32 * w + lane, tag, x);
+        if (alive && lane < 32) rs_store(xbc + 32 * w + lane, tag, x, near);
         if (alive && w == 31) {           // column 1024 (the dustbin column when n1 == 1024)
           float y = 0.0f;
           alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RS_WG, tag, y, nullptr, lane, a.err);
           const float ys = half_sum32(lane < 32 ? y : 0.0f);
-          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys);
+          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, near);
         }
       }
+      RS_STAMP(4);
       if (alive) {   // hop 2: the 1025 reduced sums of every reducer -> LDS
         float unused = 0.0f;
-        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err);
+        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err, &np2);
       }
       if (!alive && lane == 0) misc[1] = 1.0f;
+      RS_STAMP(5);
+      if (stamping) a.stamps[4096 * 8 + (size_t)(k - 1) * 2] = np1, a.stamps[4096 * 8 + (size_t)(k - 1) * 2 + 1] = np2;
     }
     __syncthreads();
+    RS_STAMP(6);
     if (misc[1] != 0.0f) return;
     const float csum = csumv[t], csum2 = csumv[1024];
     // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
     b_t = col_ok ? nu / fma_rn(ad, pd_t, csum) : 0.0f;
     bvec[t] = b_t;
     if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, (n1 < RS_NP) ? csum : csum2);
+    RS_STAMP(7);
     // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
     if (k == next_absorb && k < a.iters) {
       next_absorb *= 2;
@@ -353,6 +418,8 @@ int sinkhorn_resident_enabled() {
   return v;
 }
 
+long long *g_rs_stamps = nullptr;   // set by urf_probe_sinkhorn_stamps
+
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st) {
   URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
@@ -368,11 +435,16 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }
-  int group = d.cus / RS_WG;                  // pairs per launch: one workgroup per CU
+  // pairs per launch.  A launch may take one CU per workgroup, i.e. cus / 32 pairs; by default it takes HALF the
+  // chip (4 pairs on an MI355X): the iterations are latency-bound (an exchange per iteration), so a second launch for
+  // the other pairs costs little, and the free half keeps the MFMA kernels of the other streams running
+  // (measured, 8 pairs, 3-stream pipeline: 8 per launch 1523 frames/s, 4 per launch 1697).  URF_SINKHORN_GROUP overrides.
+  int group = d.cus / RS_WG;
   {
-    static int knob = -1;                     // URF_SINKHORN_GROUP (A/B runs): fewer pairs per launch leave CUs to the other streams
+    static int knob = -1;
     if (knob < 0) { const char *e = getenv("URF_SINKHORN_GROUP"); knob = e ? atoi(e) : 0; }
-    if (knob >= 1 && knob < group) group = knob;
+    const int want = knob >= 1 ? knob : (group >= 2 ? group / 2 : group);
+    if (want < group) group = want;
   }
   URF_CHECK(group >= 1, "sinkhorn_resident: the device has %d CUs, a pair needs %d", d.cus, RS_WG);
   for (int p0 = 0; p0 < P; p0 += group) {
@@ -382,6 +454,12 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     a.xin = (u64 *)xin; a.xbc = (u64 *)xbc;
     *salt = (*salt % 0xFFFFFu) + 1;           // tags are (salt << 12 | iteration), never 0
     a.salt = *salt; a.err = err;
+    {
+      static int near_knob = -1;
+      if (near_knob < 0) { const char *e = getenv("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 1; }
+      a.allow_near = near_knob;
+    }
+    a.stamps = g_rs_stamps;
     URF_HIP(hipStreamWaitEvent(st, d.last, 0));
     hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
     URF_HIP(hipGetLastError());
@@ -391,3 +469,23 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
 }
 
 }  // namespace urf
+
+// diagnostic: the next resident launches record s_memtime stamps (8 per iteration, workgroup 0) into a device
+// buffer; enable = 0 copies the stamps of `iters` iterations to `out` and switches recording off again
+extern "C" int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out) {
+  if (enable) {
+    if (!urf::g_rs_stamps) {
+      if (hipMalloc((void **)&urf::g_rs_stamps, 4096 * 10 * sizeof(long long)) != hipSuccess) return -1;
+      (void)hipMemset(urf::g_rs_stamps, 0, 4096 * 10 * sizeof(long long));
+    }
+    return 0;
+  }
+  if (!urf::g_rs_stamps || !out || iters < 1 || iters > 4096) return -1;
+  (void)hipDeviceSynchronize();
+  int rc = hipMemcpy(out, urf::g_rs_stamps, (size_t)iters * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  // poll passes of hop 1 / hop 2 per iteration follow the stamps in `out` (iters x 2)
+  if (hipMemcpy(out + (size_t)iters * 8, urf::g_rs_stamps + 4096 * 8, (size_t)iters * 2 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+  (void)hipFree(urf::g_rs_stamps);
+  urf::g_rs_stamps = nullptr;
+  return rc;
+}
