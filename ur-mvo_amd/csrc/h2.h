@@ -44,6 +44,10 @@ struct H2ConvArgs {
 int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int batch, hipStream_t st);
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st);
 int launch_split(const float *x, size_t n, _Float16 *h, _Float16 *l, hipStream_t st);
+// fused MLP of a GNN layer (h2mlp.hip): x <- x + W2 relu(W1 [x ; o] + b1) + b2 on the split planes, in place
+int launch_h2mlp(_Float16 *xh, _Float16 *xl, const _Float16 *oh, const _Float16 *ol, const _Float16 *w1h,
+                 const _Float16 *w1l, const _Float16 *w2h, const _Float16 *w2l, const float *b1, const float *b2,
+                 const int *counts, int rows, int nimg, hipStream_t st);
 int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                    const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st);
 }  // namespace urf

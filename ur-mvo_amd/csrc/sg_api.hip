@@ -6,6 +6,7 @@
 #include "h2.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -427,6 +428,19 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
     if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
     if (launch_attn_h2(h->qkh, h->qkl, h->vth, h->vtl, h->counts, l & 1, h->oh, h->ol, NI, st)) return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
+    // URF_GNN_FUSED=1: the layer's MLP as ONE launch with the hidden activations in LDS (h2mlp.hip; bit-identical
+    // results).  Measured and NOT the default: it needs 144 KB of LDS, i.e. one workgroup per CU with two waves per
+    // SIMD, and loses against two h2gemm launches at four waves per SIMD -- 1.87 vs 1.77 ms per 8 pairs serialised,
+    // 1590 vs 1720 frames/s in the 3-stream pipeline (it also keeps the other streams' kernels off its CUs).
+    static int fused = -1;
+    if (fused < 0) { const char *e = getenv("URF_GNN_FUSED"); fused = e ? (atoi(e) != 0) : 0; }
+    if (fused) {
+      // merge + MLP0 + ReLU + MLP1 + residual in ONE launch, the hidden activations stay in LDS (h2mlp.hip)
+      if (launch_h2mlp(h->xh, h->xl, h->oh, h->ol, h->d_wh + h->H[l].w1, h->d_wl + h->H[l].w1, h->d_wh + h->H[l].w2,
+                       h->d_wl + h->H[l].w2, h->d_w + h->L[l].b1f, h->d_w + h->L[l].b2, h->counts, NP, NI, st))
+        return -1;
+      continue;
+    }
     // merge + first MLP layer in one GEMM over [x ; o] (weights folded at build())
     if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->oh, h->ol, 256, 256, h->H[l].w1, h->L[l].b1f, 512, nullptr, h->hh,
                   h->hl, 512, true, nullptr, false))
