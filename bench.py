@@ -9,10 +9,14 @@ per GPU per step).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
-the library's own stream; `cpu_baseline` times the CPU oracle on one frame.
+The K-step timed region (barrier + synchronize on both sides, max over ranks) is run --repeats times back to
+back; `value` / `ms_per_step` are the MEDIAN region, `repeats` holds every region (boxes and clocks vary by
+several per cent from run to run).  Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events
+on the library's own stream; `cpu_baseline` times the CPU oracle on a bounded sample.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -67,12 +71,19 @@ def sg_attn_gflop(n0, n1):
 
 
 
+def kernel_source_sha():
+    """sha256 over the HIP sources of the library: a PMC summary is only quoted for the kernels it was taken on"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ur-mvo_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ur-mvo_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_label, resolution, prec):
-    """HBM-side bytes per step of the dominant kernel family, from the committed summary of the two
-    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py) of this same command.
-    bench.py cannot collect counters about itself: the summary is the newest profiles/r*_pmc_hbm*.json
-    for this resolution; None when there is none (or for the exact mode, not profiled)."""
-    import glob
+    """HBM-side bytes per step of a kernel family, from the committed summary of the two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py) of this same command.  bench.py cannot collect counters about
+    itself: the summary is the newest profiles/r*_pmc_hbm*.json for this resolution whose `source_sha` equals the
+    sha of the kernel sources in this tree -- a summary taken on other kernels is refused (traffic = null)."""
     if prec != 1:
         return None, "no PMC pass for the exact mode"
     tag = "" if resolution == "640x480" else "_" + resolution
@@ -80,7 +91,11 @@ def pmc_traffic(kernel_label, resolution, prec):
     if not files:
         return None, "no committed PMC summary for this resolution"
     d = json.load(open(files[-1]))
+    if d.get("source_sha") != kernel_source_sha():
+        return None, (f"{os.path.basename(files[-1])} was taken on other kernel sources (sha {d.get('source_sha')} != "
+                      f"{kernel_source_sha()}): refused")
     fam = ("h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
+           else "sinkhorn_resident_kernel" if "resident" in kernel_label
            else "sinkhorn_half_kernel" if "inkhorn" in kernel_label else "h2conv_kernel<pool,fuse1a>")
     k = d["kernels"].get(fam)
     if not k:
@@ -90,11 +105,16 @@ def pmc_traffic(kernel_label, resolution, prec):
                                            f"{k['launches'] // calls} {fam} launches of a step; L2-miss traffic incl. "
                                            f"Infinity-Cache hits; {os.path.basename(files[-1])}")
 
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--batch-per-gpu", type=int, default=8,
+                    help="frames (and pairs) per GPU per step: 8 = BASELINE configs[2]; 4 with --gpus 8 and --resolution "
+                         "1241x376 = configs[3] (batch 32 sharded over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="1 = fast (split-f16 MFMA, fp32-equivalent accuracy, default); 0 = exact fp32 (bit-identical to the oracle)")
@@ -102,7 +122,9 @@ def main():
     ap.add_argument("--resolution", default="640x480", choices=["640x480", "1241x376"],
                     help="frame size WxH: 640x480 (headline, BASELINE configs[2]) or the KITTI-size stream of configs[3]")
     args = ap.parse_args()
-    global H, W, GF_CONV1
+    global H, W, GF_CONV1, BATCH
+    BATCH = args.batch_per_gpu
+    assert 1 <= BATCH <= 64
     if args.resolution == "1241x376":
         H, W = 376, 1241
         GF_CONV1 = (22.649 + 0.354) * (376 * 1241) / (480 * 640)
@@ -183,10 +205,21 @@ def main():
             pms.append(pm_b)
 
     if async_exchange:
+        # the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI, not torch.distributed.  Two communicators:
+        # the slot all-gather runs on its own stream, the gather of the match lists to rank 0 on the matcher streams,
+        # and RCCL operations of ONE communicator must not be in flight on several streams at once.
+        ids = [D.Comm.unique_id(), D.Comm.unique_id()] if rank == 0 else [None, None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm_ag = D.Comm(world, rank, local_rank, ids[0])
+        comm_g = D.Comm(world, rank, local_rank, ids[1])
         sp_ext = torch.cuda.ExternalStream(sp.stream_ptr(), device=dev)
         pm_ext = [torch.cuda.ExternalStream(m.stream_ptr(), device=dev) for m in pms]
         comm = torch.cuda.Stream(device=dev)
         gathered_buf = torch.zeros((NB, world * BATCH, slot_floats), dtype=torch.float32, device=dev)
+        # rank 0 (where the serial tracker lives) receives every rank's match lists: counts and 12-byte matches
+        all_counts = torch.zeros((world, BATCH), dtype=torch.int32, device=dev)
+        all_matches = torch.zeros((world, BATCH * 1024 * 3), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
 
     sp_calls = [0]   # number of SP calls enqueued so far (batch index of the latest = sp_calls-1)
@@ -247,10 +280,9 @@ def main():
             ev_sp = torch.cuda.Event()
             ev_sp.record(sp_ext)                                    # tail of the SuperPoint stream = SP(b)
             comm.wait_event(ev_sp)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(gathered_buf[k], ring[k])   # RCCL over xGMI
-                ev_ag = torch.cuda.Event()
-                ev_ag.record(comm)
+            comm_ag.allgather_slots(ring[k].data_ptr(), BATCH, gathered_buf[k].data_ptr(), comm.cuda_stream)   # RCCL over xGMI
+            ev_ag = torch.cuda.Event()
+            ev_ag.record(comm)
             pm_ext[b % len(pms)].wait_event(ev_ag)
             gathered[k] = gathered_buf[k]
         elif exchange:                                              # gloo test rig: host-staged, synchronous
@@ -260,6 +292,11 @@ def main():
         if OVERLAP:
             mt.wait_for_sp(sp)                  # match(b) needs SP(b)
         pm_step(b, mt)
+        if async_exchange:
+            # match lists -> rank 0, on the matcher's own stream right behind its kernels (12 KB x pairs per rank)
+            d_m, d_n = mt.device_results()
+            comm_g.gather(d_n, BATCH * 4, all_counts.data_ptr(), 0, mt.stream_ptr())
+            comm_g.gather(d_m, BATCH * 1024 * 12, all_matches.data_ptr(), 0, mt.stream_ptr())
         if OVERLAP == 1:
             mt.let_sp_overlap_sinkhorn(sp)      # SP(b+1) starts when match(b) reaches Sinkhorn
         sp_step(b + 1)
@@ -286,22 +323,31 @@ def main():
     while pending:
         collect(False)
     sp.sync()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    checks = []
-    t0 = time.perf_counter()
-    for b in range(args.warmup, args.warmup + args.steps):
-        one_step(b, True)
-    while pending:
-        collect(True)
-    sp.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev, world)
+    # `repeats` timed regions of exactly --steps steps, each bracketed by barrier + synchronize, max over ranks
+    region_s = []
+    nb = args.warmup
+    for rep in range(max(1, args.repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in range(nb, nb + args.steps):
+            one_step(b, True)
+        while pending:
+            collect(True)
+        sp.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        region_s.append(D.max_over_ranks(time.perf_counter() - t0, dev, world))
+        nb += args.steps
+    dt = float(np.median(region_s))
+    args_last_batch = nb - 1
     total_frames = args.steps * BATCH * world
     fps = total_frames / dt
+    gathered_total = None
+    if async_exchange and rank == 0:
+        gathered_total = int(all_counts.sum().item())          # the last step's matches of ALL ranks, as rank 0 received them
     insitu = {"superpoint": float(np.mean(sp_ms)) if sp_ms else None, "matching": float(np.mean(pm_ms)),
               "linear": float(np.mean(lin_ms)), "attention": float(np.mean(attn_ms))}
 
@@ -311,7 +357,7 @@ def main():
     # --kernel-trace serialises dispatches too, so these are the numbers it reports.
     del sp_ms[:], conv1_ms[:], pm_ms[:], lin_ms[:], attn_ms[:], sink_ms[:], ransac_ms[:]
     if rank == 0:
-        bl = args.warmup + args.steps
+        bl = args_last_batch + 1
         for b in range(bl, bl + 5):
             sp_step(b)
             sp.sync()
@@ -341,14 +387,20 @@ def main():
                  sg_linear_gbytes(n_avg, n_avg, PREC == 1) * BATCH + SG_WEIGHT_GB),
             ("SuperGlue attention (attn_h2_kernel)" if PREC else "SuperGlue attention (attn_kernel)"):
                 (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH, sg_attn_gbytes(n_avg, n_avg) * BATCH),
+        }
+        resident = PREC == 1 and os.environ.get("URF_SINKHORN_RESIDENT", "1") != "0"
+        if resident:
+            # LDS-resident Sinkhorn (sinkhorn_resident.hip): the couplings are read from HBM/L2 once per (re)absorption
+            # (initially and after iterations 1, 2, 4, ... 64: 8 times), 2 fma per element and iteration; no roof binds
+            # it -- an iteration is one inter-CU exchange (latency)
+            per_step["Sinkhorn (sinkhorn_resident_kernel, %d iterations in LDS)" % SINK_ITERS] = (
+                np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 2 / 1e9, 8 * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
+        else:
             # log-Sinkhorn: 2 passes per iteration, each streams one (n0+1) x (n1+1) f32 matrix (C or C^T) once
             # (SURVEY section 8d); ~6 flop per element (add, sub, exp, add, max)
-            "Sinkhorn (sinkhorn_half_kernel x %d)" % (2 * SINK_ITERS):
-                (np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 6 / 1e9,
-                 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 4 / 1e9),
-        }
-        dom = max(per_step, key=lambda k: per_step[k][0])
-        ms, gf, gb = per_step[dom]
+            per_step["Sinkhorn (sinkhorn_half_kernel x %d)" % (2 * SINK_ITERS)] = (
+                np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 6 / 1e9,
+                2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
         # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); the MFMA roof is priced on the
         # ALGORITHMIC flops (counted once), so its fraction is <= 1/3 by construction
         peak_tf = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
@@ -359,6 +411,14 @@ def main():
             t_mfma, t_hbm = gf_ * issue / peak_tf, gb_ / HBM_PEAK_GBS * 1e3      # ms at each roof
             return ("hbm" if t_hbm > t_mfma else "mfma"), t_mfma, t_hbm
 
+        def frac_of(v):
+            b_, tm_, th_ = roofs(*v)
+            return max(tm_, th_) / v[0]           # minimum time at the binding roof / measured time
+
+        # the kernel family reported = the one that loses the most time against its roof, ms x (1 - frac): stable from
+        # run to run (the largest ms alone flips between two families that are within noise of each other)
+        dom = max(per_step, key=lambda k: per_step[k][0] * (1.0 - frac_of(per_step[k])))
+        ms, gf, gb = per_step[dom]
         bound, t_mfma, t_hbm = roofs(ms, gf, gb)      # the binding roof = the one with the larger minimum time
         traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
         if bound == "hbm":
@@ -377,7 +437,8 @@ def main():
                                 "(the timed region overlaps 3 streams; rocprofv3 --kernel-trace serialises as well)",
                     "in_timed_region_ms_per_step": {k: (round(v, 3) if v is not None else None) for k, v in insitu.items()},
                     "all_kernels": {k: {"ms_per_step": round(float(v[0]), 3), "tflops_logical": round(v[1] / v[0], 2),
-                                        "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(*v)[0]}
+                                        "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(*v)[0],
+                                        "frac": round(frac_of(v), 4), "ms_below_roof": round(float(v[0] * (1 - frac_of(v))), 3)}
                                     for k, v in per_step.items()}}
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
@@ -393,7 +454,7 @@ def main():
             pm2.share_stream(sp2)
             ring2 = torch.zeros_like(ring)
             nst = min(4, args.steps)
-            last = args.warmup + args.steps - 1          # last timed batch of the fast run
+            last = args_last_batch                       # last timed batch of the fast run
             b0 = last - nst + 1
             # the fast ring still holds batches last-3 .. last+1: batches last-2 .. last are comparable
             cmp_batches = [b for b in range(last - 2, last + 1) if b >= b0 + 1 and b in kept]
@@ -448,23 +509,29 @@ def main():
         out = {
             "metric": f"VO front-end frames/sec (SP+SG+RANSAC) @{args.resolution}", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "repeats": {"regions": len(region_s), "reported": "median",
+                        "frames_per_s": [round(total_frames / r, 2) for r in region_s],
+                        "min": round(total_frames / max(region_s), 2), "max": round(total_frames / min(region_s), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
                       if PREC == 1 else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.resolution} grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
-                                   f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json configs[2])",
+                                   f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json "
+                                   f"{'configs[3]: batch 32 over 8 GPUs' if (BATCH * world == 32 and args.resolution == '1241x376') else 'configs[2]'})",
                        "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
                        "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
                        "weights": "seeded synthetic (reference ships none)",
                        "streams": {0: "one in-order stream", 1: "2 streams: SP(b+1) beside Sinkhorn(b)",
                                    2: "3 streams: Sinkhorn(b) beside GNN(b+1) and SP(b+2)"}[OVERLAP],
-                       "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step"},
+                       "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step (urf_comm_*, C ABI) + "
+                                      f"gather of the match lists to rank 0"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "exact_mode": exact,
             "stage_ms_per_step": stage_means,
             "matches_per_step": round(float(np.mean(n_matches)), 1),
+            "matches_last_step_all_ranks_at_rank0": gathered_total,
         }
         print(json.dumps(out))
     if world > 1 or force_dist:

@@ -12,9 +12,22 @@ the memory side of L2, i.e. Infinity-Cache hits are included: this is L2-miss tr
 bound on HBM bytes.
 """
 import collections
+import glob
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """must equal bench.kernel_source_sha(): bench.py refuses a summary taken on other kernel sources"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ur-mvo_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ur-mvo_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(db):
@@ -28,7 +41,7 @@ def per_kernel(db):
 def family(name):
     if "h2conv_kernel<true, true" in name:
         return "h2conv_kernel<pool,fuse1a>"      # conv1a+conv1b fused: its own line (bench.py's conv1 kernel)
-    for key in ("ransac_", "h2gemm", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "conv_mfma_kernel",
+    for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
                 "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel"):
         if key in name:
@@ -56,9 +69,9 @@ def main():
                   "FETCH_SIZE_KiB_per_launch_raw": round(v["fetch_kib"] / n, 1),
                   "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
                   "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
-    pm_calls = max(fam.get("sinkhorn_half_kernel", {"launches": 0})["launches"] // 200, 1)
+    pm_calls = max(fam.get("decode_kernel", {"launches": 0})["launches"], 1)      # one decode_kernel launch per matcher call
     sp_calls = max(fam.get("topk_kernel", {"launches": 0})["launches"], 1)
-    json.dump({"command": cmd, "matcher_calls": pm_calls, "superpoint_calls": sp_calls, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
+    json.dump({"command": cmd, "source_sha": kernel_source_sha(), "matcher_calls": pm_calls, "superpoint_calls": sp_calls, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
                "scope": "L2-miss (fabric) traffic incl. Infinity-Cache hits; separate --pmc passes",
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
