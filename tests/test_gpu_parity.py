@@ -343,7 +343,7 @@ def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
          "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-         "--warmup", "1"], env=env, text=True, stderr=subprocess.DEVNULL)
+         "--warmup", "1", "--repeats", "1"], env=env, text=True, stderr=subprocess.DEVNULL)
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
@@ -363,10 +363,12 @@ def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
     for force in ("0", "1"):
         env = dict(os.environ, URF_BENCH_FORCE_DIST=force, MASTER_PORT="29541")
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
-                                       "--no-cpu-baseline", "--no-exact-check"], env=env, text=True, stderr=subprocess.DEVNULL)
+                                       "--repeats", "2", "--no-cpu-baseline", "--no-exact-check"], env=env, text=True, stderr=subprocess.DEVNULL)
         res.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
     assert res[0]["matches_per_step"] == res[1]["matches_per_step"] > 8 * 600
     assert res[1]["n_gpus"] == 1 and res[1]["value"] > 0.5 * res[0]["value"]
+    # the match lists also travelled through the gather to rank 0 (urf_comm_gather on the matcher stream)
+    assert res[0]["matches_last_step_all_ranks_at_rank0"] is None and res[1]["matches_last_step_all_ranks_at_rank0"] > 8 * 600
 
 
 def test_bench_json_line_follows_the_contract():
@@ -389,10 +391,16 @@ def test_bench_json_line_follows_the_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 3 * 8 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
+    rp = d["repeats"]
+    assert rp["regions"] == 5 and len(rp["frames_per_s"]) == 5 and rp["min"] <= d["value"] <= rp["max"]
+    assert d["value"] == sorted(rp["frames_per_s"])[2]                 # the median region
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] in (8000.0, 2500.0, 157.3)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
-    assert isinstance(r["traffic"], int) and r["traffic"] > 1e8
+    # traffic: bytes from the committed PMC summary of these very kernel sources, or null with the reason
+    assert (isinstance(r["traffic"], int) and r["traffic"] > 1e7) or (r["traffic"] is None and "refused" in r["traffic_note"])
+    lost = {k: v["ms_below_roof"] for k, v in r["all_kernels"].items()}
+    assert r["kernel"] == max(lost, key=lost.get)                      # the family that loses the most time against its roof
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and 0 < c["value"] < 50 and 1 <= c["cores"] <= 32 and c["sample"]
     assert d["exact_mode"]["value"] > 100 and d["exact_mode"]["match_jaccard_fast_vs_exact"] > 0.99
