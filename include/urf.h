@@ -323,6 +323,37 @@ int urf_fe_in_flight(urf_fe *h);
 urf_sp *urf_fe_superpoint(urf_fe *h);
 urf_pm *urf_fe_matcher(urf_fe *h, int i);
 
+/* ------------------------------------------------------------------ pose stage -- */
+/* The per-frame pose computation that consumes the front-end's matches, batched over the
+ * frames of a step: SolvePnPWithCV (src/g2o_optimization.cc:323-377) and FrameOptimization (:179-321).
+ * cv::solvePnPRansac and g2o are un-vendored third-party code: the arithmetic is the written specification of
+ * DESIGN.md "Pose stage" (parity unpinned), every parameter of the reference's call sites is kept. */
+typedef struct urf_pose urf_pose;
+/* buffers for up to max_batch frames of up to `capacity` observations each, on `device` */
+int urf_pose_create(int device, int max_batch, int capacity, urf_pose **out);
+void urf_pose_destroy(urf_pose *h);
+typedef struct {
+  double fx, fy, cx, cy;       /* Camera::GetCamerMatrix (:329-330); images are undistorted, dist_coeffs = 0 */
+  int iterations;              /* 0 -> 100   (cv::solvePnPRansac(..., false, 100, 20.0, 0.99, inliers), :352-353) */
+  double reprojection_error;   /* 0 -> 20.0 px */
+  double confidence;           /* 0 -> 0.99 */
+  uint32_t seed;
+} urf_pnp_config;
+/* B frames; frame f has n[f] <= cap correspondences obj[f][cap][3] (cv::Point3f) / img[f][cap][2] (cv::Point2f).
+ * pose[f]: Twc, 4x4 row-major f64 (:363-367); inliers[f][cap]: 1 = cv_inliers lists the correspondence;
+ * n_inliers[f] = the function's return value (0: fewer than 8 correspondences (:352) or no valid hypothesis). */
+int urf_solve_pnp_ransac(urf_pose *h, const urf_pnp_config *cfg, int B, const int *n, const float *obj, const float *img,
+                         int cap, double *pose, uint8_t *inliers, int *n_inliers);
+typedef struct {
+  double fx, fy, cx, cy;
+  double chi2_threshold;       /* 0 -> 5.991 (OptimizationConfig::mono_point) */
+} urf_poseopt_config;
+/* FrameOptimization over the mono observations of B frames: Xw[f][cap][3] map points, obs[f][cap][2] keypoints;
+ * q_wc[f][4] (w, x, y, z) / p_wc[f][3]: the prior pose Twc in, the optimised pose out; inlier[f][cap]: the
+ * re-classified MonoPointConstraint::inlier flags; n_inliers[f] = the function's return value (n - outliers). */
+int urf_frame_optimization(urf_pose *h, const urf_poseopt_config *cfg, int B, const int *n, const double *Xw,
+                           const double *obs, int cap, double *q_wc, double *p_wc, uint8_t *inlier, int *n_inliers);
+
 /* ------------------------------------------------ map-point projection search -- */
 /* Mapping::SearchByProjection(frame, mappoints, thr, good_projections), src/mapping.cc:667-735
  * (SURVEY.md section 8 f4): projection (include/camera.h:48-68), window search

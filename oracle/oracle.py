@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "liburf_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c", "map_oracle.c",
+    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c", "map_oracle.c", "pnp_oracle.c",
                                               "urf_oracle.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -347,3 +347,37 @@ def search_by_projection(cfg, feat, mp_pos, mp_desc, occupied=None, mp_valid=Non
     out = np.full(pos.shape[0], -2, np.int32)
     lib().osbp_search(C.byref(cfg), _p(f), f.shape[0], _p(occ), _p(pos), _p(desc), _p(val), pos.shape[0], _p(out))
     return out
+
+
+class PnpConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("iterations", C.c_int),
+                ("reprojection_error", C.c_double), ("confidence", C.c_double), ("seed", C.c_uint32)]
+
+
+def solve_pnp_ransac(cam, obj, img, iterations=100, reprojection_error=20.0, confidence=0.99, seed=0):
+    """SolvePnPWithCV (src/g2o_optimization.cc:323-377) -> (n_inliers, Twc[4,4], inlier flags[n])"""
+    cfg = PnpConfig(*[float(v) for v in cam], iterations, reprojection_error, confidence, seed)
+    obj = np.ascontiguousarray(obj, np.float32)
+    img = np.ascontiguousarray(img, np.float32)
+    n = obj.shape[0]
+    pose = np.zeros(16, np.float64)
+    inl = np.zeros(max(n, 1), np.uint8)
+    k = lib().opnp_solve_ransac(C.byref(cfg), _p(obj), _p(img), n, _p(pose), _p(inl))
+    return int(k), pose.reshape(4, 4), inl[:n]
+
+
+class PoseOptConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("chi2_threshold", C.c_double)]
+
+
+def frame_optimization(cam, Xw, obs, q_wc, p_wc, inlier=None, chi2_threshold=5.991):
+    """FrameOptimization (src/g2o_optimization.cc:179-321) -> (n - outliers, q_wc[4] (w,x,y,z), p_wc[3], inlier flags)"""
+    cfg = PoseOptConfig(*[float(v) for v in cam], chi2_threshold)
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    n = Xw.shape[0]
+    q = np.array(q_wc, np.float64).copy()
+    p = np.array(p_wc, np.float64).copy()
+    inl = np.ones(max(n, 1), np.uint8) if inlier is None else np.ascontiguousarray(inlier, np.uint8).copy()
+    k = lib().oframe_optimization(C.byref(cfg), _p(Xw), _p(obs), n, _p(q), _p(p), _p(inl))
+    return int(k), q, p, inl[:n]

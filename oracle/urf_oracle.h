@@ -132,6 +132,24 @@ int oepi_reconstruct_sets(const oepi_config *cfg, const float *keys1, int n1, co
                           const int *matches12, const int *sets, float *T21, float *P3D, uint8_t *tri, int *model,
                           float *scores);
 
+/* ---------------- pose stage (pnp_oracle.c) ---------------- */
+typedef struct {
+  double fx, fy, cx, cy;       /* Camera::GetCamerMatrix, src/g2o_optimization.cc:329-330 */
+  int iterations;              /* 100 (:352-353) */
+  double reprojection_error;   /* 20.0 px */
+  double confidence;           /* 0.99 */
+  uint32_t seed;
+} opnp_config;
+/* SolvePnPWithCV src/g2o_optimization.cc:323-377.  pose: Twc 4x4 row-major; returns the inlier count */
+int opnp_solve_ransac(const opnp_config *cfg, const float *obj, const float *img, int n, double *pose, uint8_t *inliers);
+typedef struct {
+  double fx, fy, cx, cy;
+  double chi2_threshold;       /* cfg.mono_point (5.991) */
+} oposeopt_config;
+/* FrameOptimization src/g2o_optimization.cc:179-321 (mono edges).  q_wc (w,x,y,z) / p_wc in-out; returns n - outliers */
+int oframe_optimization(const oposeopt_config *cfg, const double *Xw, const double *obs, int n, double *q_wc, double *p_wc,
+                        uint8_t *inlier);
+
 /* ---------------- camera ---------------- */
 typedef struct {
   int width, height;       /* image_width / image_height, src/camera.cc:16-17 */

@@ -198,3 +198,34 @@ def check_find_F_golden(g, score, inliers, F):
     assert not (diff & (g["marginF"] > 1e-2)).any() and diff.sum() <= 3
     a, b = F.reshape(-1) / np.linalg.norm(F), g["F21"].reshape(-1) / np.linalg.norm(g["F21"])
     assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-3
+
+
+def pose_scene(seed, n=300, noise=0.3, outliers=40, W=640, H=480):
+    """map points seen by a camera at a known pose Twc: (cam(fx,fy,cx,cy), Xw [n,3], uv [n,2], Rwc, pwc, outlier mask)"""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 420.0, 415.0, 321.5, 238.25
+    ax = rng.normal(0, 0.15, 3)
+    th = np.linalg.norm(ax)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rwc = np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
+    pwc = rng.normal(0, 0.5, 3)
+    uv = np.c_[rng.uniform(10, W - 10, n), rng.uniform(10, H - 10, n)]
+    depth = rng.uniform(2, 15, n)
+    pc = np.c_[(uv[:, 0] - cx) / fx, (uv[:, 1] - cy) / fy, np.ones(n)] * depth[:, None]
+    Xw = pc @ Rwc.T + pwc
+    uv = uv + rng.normal(0, noise, uv.shape)
+    bad = np.zeros(n, bool)
+    if outliers:
+        idx = rng.choice(n, outliers, replace=False)
+        uv[idx] = np.c_[rng.uniform(0, W, outliers), rng.uniform(0, H, outliers)]
+        bad[idx] = True
+    return (fx, fy, cx, cy), Xw, uv, Rwc, pwc, bad
+
+
+def quat_wxyz(R):
+    """rotation matrix -> unit quaternion (w, x, y, z), w >= 0"""
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = np.sqrt(max(0.0, 1 + R[0, 0] - R[1, 1] - R[2, 2])) / 2 * np.sign(R[2, 1] - R[1, 2] or 1)
+    y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2 * np.sign(R[0, 2] - R[2, 0] or 1)
+    z = np.sqrt(max(0.0, 1 - R[0, 0] - R[1, 1] + R[2, 2])) / 2 * np.sign(R[1, 0] - R[0, 1] or 1)
+    return np.array([w, x, y, z])

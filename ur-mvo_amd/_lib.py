@@ -27,7 +27,7 @@ SYMBOLS = [
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
     "urf_comm_unique_id", "urf_comm_init", "urf_comm_init_all", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
     "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results",
-    "urf_probe_sinkhorn_stamps",
+    "urf_probe_sinkhorn_stamps", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization",
 ]
 
 
@@ -66,6 +66,15 @@ class SbpConfig(C.Structure):
                 ("device", C.c_int)]
 
 
+class PnpConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("iterations", C.c_int),
+                ("reprojection_error", C.c_double), ("confidence", C.c_double), ("seed", C.c_uint32)]
+
+
+class PoseOptConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("chi2_threshold", C.c_double)]
+
+
 class DMatch(C.Structure):
     _fields_ = [("queryIdx", C.c_int), ("trainIdx", C.c_int), ("distance", C.c_float)]
 
@@ -102,6 +111,7 @@ def lib():
         L.urf_cam_destroy.restype = None
         L.urf_fe_destroy.restype = None
         L.urf_comm_destroy.restype = None
+        L.urf_pose_destroy.restype = None
         L.urf_fe_superpoint.restype = C.c_void_p
         L.urf_fe_matcher.restype = C.c_void_p
         L.urf_sp_stream.restype = C.c_void_p

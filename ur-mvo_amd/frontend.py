@@ -532,3 +532,55 @@ def minimal_sets(sampler, seed, n, iterations):
     sets = np.zeros((iterations, 8), np.int32)
     check(_lib.lib().urf_minimal_sets(int(sampler), C.c_uint32(seed), int(n), int(iterations), _p(sets)), "urf_minimal_sets")
     return sets
+
+
+class PoseStage:
+    """SolvePnPWithCV and FrameOptimization (src/g2o_optimization.cc:323-377, 179-321) batched over frames
+    (urf_pose_*): lists of per-frame arrays in, lists out."""
+
+    def __init__(self, camera_fxfycxcy, max_batch=8, capacity=1024, device=0):
+        self.cam = [float(v) for v in camera_fxfycxcy]
+        self.max_batch, self.cap = max_batch, capacity
+        self._h = C.c_void_p()
+        check(_lib.lib().urf_pose_create(device, max_batch, capacity, C.byref(self._h)), "urf_pose_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.lib().urf_pose_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _pack(self, arrays, width, dtype):
+        B = len(arrays)
+        n = np.array([len(a) for a in arrays], np.int32)
+        cap = max(int(n.max()) if B else 1, 1)
+        out = np.zeros((B, cap, width), dtype)
+        for f, a in enumerate(arrays):
+            out[f, :len(a)] = np.asarray(a, dtype).reshape(-1, width)
+        return n, cap, out
+
+    def SolvePnPWithCV(self, object_points, image_points, iterations=100, reprojection_error=20.0, confidence=0.99, seed=0):
+        """per frame: (n_inliers, Twc[4,4], inlier flags[n])"""
+        n, cap, obj = self._pack(object_points, 3, np.float32)
+        _, _, img = self._pack(image_points, 2, np.float32)
+        B = len(n)
+        cfg = _lib.PnpConfig(*self.cam, iterations, reprojection_error, confidence, seed)
+        pose = np.zeros((B, 4, 4), np.float64)
+        inl = np.zeros((B, cap), np.uint8)
+        k = np.zeros(B, np.int32)
+        check(_lib.lib().urf_solve_pnp_ransac(self._h, C.byref(cfg), B, _p(n), _p(obj), _p(img), cap, _p(pose), _p(inl), _p(k)),
+              "urf_solve_pnp_ransac")
+        return [(int(k[f]), pose[f].copy(), inl[f, :n[f]].copy()) for f in range(B)]
+
+    def FrameOptimization(self, map_points, keypoints, q_wc, p_wc, chi2_threshold=5.991):
+        """per frame: (n - outliers, q_wc (w,x,y,z), p_wc, inlier flags[n])"""
+        n, cap, X = self._pack(map_points, 3, np.float64)
+        _, _, obs = self._pack(keypoints, 2, np.float64)
+        B = len(n)
+        q = np.ascontiguousarray(np.asarray(q_wc, np.float64).reshape(B, 4)).copy()
+        p = np.ascontiguousarray(np.asarray(p_wc, np.float64).reshape(B, 3)).copy()
+        cfg = _lib.PoseOptConfig(*self.cam, chi2_threshold)
+        inl = np.zeros((B, cap), np.uint8)
+        k = np.zeros(B, np.int32)
+        check(_lib.lib().urf_frame_optimization(self._h, C.byref(cfg), B, _p(n), _p(X), _p(obs), cap, _p(q), _p(p), _p(inl),
+                                                _p(k)), "urf_frame_optimization")
+        return [(int(k[f]), q[f].copy(), p[f].copy(), inl[f, :n[f]].copy()) for f in range(B)]
