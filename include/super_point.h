@@ -93,7 +93,29 @@ class SuperPoint {
       cv::circle(image_display, cv::Point(keypoint[0], keypoint[1]), 1, cv::Scalar(255, 0, 0), -1, 16);
     cv::imwrite(image_name + ".jpg", image_display);
 #else
-    (void)image_name; (void)image;
+    // no OpenCV in the build: the same picture as a binary PPM (image_name + ".ppm"), grey image replicated to RGB,
+    // every keypoint a radius-1 disc (centre + 4 neighbours) in the reference's colour, BGR (255, 0, 0) = blue
+    if (image.empty()) return;
+    std::vector<unsigned char> rgb((size_t)image.rows * image.cols * 3);
+    for (int y = 0; y < image.rows; ++y)
+      for (int x = 0; x < image.cols; ++x) {
+        const unsigned char v = image.data[(size_t)y * image.step + x];
+        unsigned char *px = &rgb[((size_t)y * image.cols + x) * 3];
+        px[0] = px[1] = px[2] = v;
+      }
+    static const int disc[5][2] = {{0, 0}, {1, 0}, {-1, 0}, {0, 1}, {0, -1}};
+    for (auto &keypoint : keypoints_)
+      for (auto &d : disc) {
+        const int x = keypoint[0] + d[0], y = keypoint[1] + d[1];
+        if (x < 0 || y < 0 || x >= image.cols || y >= image.rows) continue;
+        unsigned char *px = &rgb[((size_t)y * image.cols + x) * 3];
+        px[0] = 0; px[1] = 0; px[2] = 255;
+      }
+    if (FILE *f = std::fopen((image_name + ".ppm").c_str(), "wb")) {
+      std::fprintf(f, "P6\n%d %d\n255\n", image.cols, image.rows);
+      std::fwrite(rgb.data(), 1, rgb.size(), f);
+      std::fclose(f);
+    }
 #endif
   }
 

@@ -82,7 +82,8 @@ size_t urf_slot_bytes(void);
 int urf_sp_infer_device(urf_sp *h, int B, const uint8_t *d_imgs, int rows, int cols,
                         void *d_slots);
 int urf_sp_sync(urf_sp *h);
-/* copy one slot (device) to a host 259 x cap f64 matrix (exact widening). */
+/* copy one slot (device) to a host 259 x cap f64 matrix (exact widening).  Synchronous on the NULL stream: the
+ * producer of the slot must have finished (urf_sp_sync, or a fetched match batch that consumed it). */
 int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K);
 
 /* debug / parity taps (tests): dense tensors of the LAST single-frame call.
@@ -151,7 +152,8 @@ int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, int n1,
  * slot pointers).  out: P x cap matches, nout: P counts (host). */
 int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1,
                      int outlier_rejection, urf_dmatch *out, int cap, int *nout);
-/* same, asynchronous: results stay in the handle until urf_pm_fetch(). */
+/* same, asynchronous: results stay in the handle until urf_pm_fetch(h, P, ...) with the same P; a fetch without a
+ * batch in flight, or for another pair count, is an error. */
 int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0,
                            const void *const *d_slots1, int outlier_rejection);
 int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
@@ -274,6 +276,7 @@ int urf_cam_create(const urf_cam_config *cfg, urf_cam **out);
  * the drop-in a maintainer uses, OpenCV's own maps stay the source of truth. */
 int urf_cam_create_from_maps(const float *map1, const float *map2, int width, int height, int device, urf_cam **out);
 void urf_cam_destroy(urf_cam *h);
+int urf_cam_size(const urf_cam *h, int *width, int *height);   /* size of the maps = of the undistorted frames */
 int urf_cam_maps(urf_cam *h, float *map1, float *map2);
 /* Camera::UndistortImage(image, image_undistorted), src/camera.cc:116-118: host u8 in, host u8 out. */
 int urf_cam_undistort(urf_cam *h, const uint8_t *img, int rows, int cols, size_t step, uint8_t *out, size_t ostep);
@@ -371,7 +374,8 @@ typedef struct {
  * NULL; best_idx[m] = keypoint index of an accepted projection, else -1. */
 int urf_search_by_projection(const urf_sbp_config *cfg, const double *feat, int K, const uint8_t *occupied,
                              const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M, int *best_idx);
-/* same, features taken from a device feature slot (f32, widened exactly: what the host copy holds) */
+/* same, features taken from a device feature slot (f32, widened exactly: what the host copy holds); the slot's
+ * producer must have finished (urf_sp_sync) -- the search is not ordered against the SuperPoint stream */
 int urf_search_by_projection_slot(const urf_sbp_config *cfg, const void *d_slot, int K, const uint8_t *occupied,
                                   const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M,
                                   int *best_idx);

@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
   std::thread t1(extract_point_and_match);
   t1.join();
   if (!ok0 || !ok1) return 1;
+  if (argc > 7) superpoint->visualization(argv[7], image1);      // SuperPoint::visualization, src/super_point.cpp:388-400
   printf("K0=%ld K1=%ld matches=%d\n", (long)features0.cols(), (long)features1.cols(), n);
   for (int i = 0; i < n; ++i) printf("%d %d %.9g\n", matches[i].queryIdx, matches[i].trainIdx, matches[i].distance);
   // EpipolarGeometry compiles against the same handle (mono init, src/tracking.cc:52-55,559)

@@ -172,6 +172,12 @@ def test_superglue_state_dict_import_folds_batchnorm_and_reorders_heads(U, tmp_p
     W.write_onnx(p, folded, nodes)
     got = W.superglue_from_onnx(p)
     assert got.shape == blob.shape and np.array_equal(got, blob)
+    # the same graph with a BatchNormalization node left in (renamed initialisers): the positional path would
+    # silently drop it -- refused
+    p2 = str(tmp_path / "sg_bn.onnx")
+    W.write_onnx(p2, folded, nodes[:3] + [("BatchNormalization", ["a'", "s", "b", "m", "v"], ["a''"])] + nodes[3:])
+    with pytest.raises(ValueError, match="BatchNormalization"):
+        W.superglue_from_onnx(p2)
 
 
 def test_minimal_sets_glibc_stream_equals_the_c_library(U, O):

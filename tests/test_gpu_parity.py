@@ -313,7 +313,8 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     f0p, f1p = str(tmp_path / "f0.raw"), str(tmp_path / "f1.raw")
     fr[0].tofile(f0p)
     fr[1].tofile(f1p)
-    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True).strip().split("\n")
+    vis = str(tmp_path / "keypoints")
+    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W), vis], text=True).strip().split("\n")
     # the shims pick the precision mode from URF_PRECISION: the fast handles give the same lists here
     fast = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True,
                                    env=dict(os.environ, URF_PRECISION="1")).strip().split("\n")
@@ -325,6 +326,17 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])
     m = pm.MatchingPoints(f0, f1, True)
     assert out[0] == f"K0={f0.shape[0]} K1={f1.shape[0]} matches={len(m)}"
+    # SuperPoint::visualization (src/super_point.cpp:388-400; PPM without OpenCV): the frame with every keypoint in blue
+    raw = open(vis + ".ppm", "rb").read()
+    hdr = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(hdr)
+    pic = np.frombuffer(raw[len(hdr):], np.uint8).reshape(H, W, 3)
+    for r in f1:
+        assert tuple(pic[int(r[2]), int(r[1])]) == (0, 0, 255)
+    blue = (pic[..., 2] == 255) & (pic[..., 0] == 0) & (pic[..., 1] == 0)
+    assert f1.shape[0] <= blue.sum() <= 5 * f1.shape[0]
+    untouched = ~blue
+    assert np.array_equal(pic[..., 0][untouched], fr[1][untouched])
     got = [tuple(l.split()) for l in out[1:]]
     assert [(int(a), int(b)) for a, b, _ in got] == [(q, t) for q, t, _ in m]
     assert np.allclose([float(c) for _, _, c in got], [d for _, _, d in m], rtol=0, atol=1e-7)
@@ -673,6 +685,25 @@ def test_c_abi_errors_are_negative_codes_with_text_and_leave_outputs_untouched(U
     assert len(m) > 4
     assert L.urf_match(pm._h, f0.ctypes.data_as(C.c_void_p), 50, f0.ctypes.data_as(C.c_void_p), 50, 0, out, 4) < 0
     assert b"cap" in L.urf_last_error()
+    # a fetch without a batch in flight, or for another pair count than the batch in flight
+    fresh = F.PointMatching(F.SuperGlueConfig(), max_pairs=2)
+    assert fresh.build(sg_blob)
+    with pytest.raises(RuntimeError, match="no batch in flight"):
+        fresh.fetch(1)
+    # configuration errors are reported at create time
+    with pytest.raises(RuntimeError, match="negative"):
+        F.SuperPoint(F.SuperPointConfig(keypoint_threshold=-1e-3), max_height=64, max_width=64)
+    # urf_last_error() is process-wide: readable from another thread than the one that failed
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.urf_last_error()))
+    t.start(); t.join()
+    assert b"negative" in seen[0]
+    # a camera whose maps do not have the size the caller states
+    cam = F.Camera(320, 240, np.array([[300.0, 0, 160], [0, 300, 120], [0, 0, 1]]), [0.0, 0, 0, 0])
+    fs = F.FrameStream(F.SuperPointConfig(), F.SuperGlueConfig(), batch=2, max_height=240, max_width=320)
+    assert L.urf_fe_set_camera(fs._h, cam._h, 480, 640) < 0 and b"maps are 240 x 320" in L.urf_last_error()
+    assert L.urf_fe_set_camera(fs._h, cam._h, 240, 320) == 0
 
 
 # ------------------------------------------------------------------ map-point projection search

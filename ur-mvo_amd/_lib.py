@@ -20,7 +20,7 @@ SYMBOLS = [
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
     "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_probe_h2gemm_variant", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
-    "urf_cam_undistort_device", "urf_cam_sync",
+    "urf_cam_undistort_device", "urf_cam_sync", "urf_cam_size",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
     "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",

@@ -198,6 +198,12 @@ extern "C" int urf_cam_create_from_maps(const float *map1, const float *map2, in
   return 0;
 }
 
+extern "C" int urf_cam_size(const urf_cam *h, int *width, int *height) {
+  URF_CHECK(h && width && height, "urf_cam_size: null argument");
+  *width = h->width; *height = h->height;
+  return 0;
+}
+
 extern "C" void urf_cam_destroy(urf_cam *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);

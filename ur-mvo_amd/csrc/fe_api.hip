@@ -26,6 +26,7 @@ constexpr int kMaxMatchers = 4;
 
 struct urf_fe {
   urf_fe_config cfg{};
+  bool deferred_error = false;        // a match call enqueued on behalf of a later batch failed: reported by the next collect
   int B = 0, M = 0, NB = 0;           // frames per batch, matchers, ring depth (batches)
   int rows = 0, cols = 0;             // raw frame geometry (fixed at the first submit)
   int frows = 0, fcols = 0;           // geometry fed to SuperPoint (the camera's map size when undistorting)
@@ -139,6 +140,13 @@ extern "C" void urf_fe_destroy(urf_fe *h) {
 extern "C" int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols) {
   URF_CHECK(h && h->next_batch == 0, "urf_fe_set_camera: set the camera before the first submit");
   URF_CHECK(!cam || (map_rows > 0 && map_cols > 0), "urf_fe_set_camera: give the map size");
+  if (cam) {   // the remap writes height x width bytes per frame: the size comes from the handle, the arguments are checked
+    int cw = 0, ch = 0;
+    if (urf_cam_size(cam, &cw, &ch)) return -1;
+    URF_CHECK(cw == map_cols && ch == map_rows, "urf_fe_set_camera: the camera's maps are %d x %d, not %d x %d", ch, cw, map_rows, map_cols);
+    const int aH = h->cfg.sp.max_height > 0 ? h->cfg.sp.max_height : 1500, aW = h->cfg.sp.max_width > 0 ? h->cfg.sp.max_width : 1500;
+    URF_CHECK(ch <= aH && cw <= aW, "urf_fe_set_camera: maps %d x %d exceed the SuperPoint arena %d x %d", ch, cw, aH, aW);
+  }
   h->cam = cam;
   h->frows = cam ? map_rows : 0;
   h->fcols = cam ? map_cols : 0;
@@ -242,6 +250,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
 //   of 259 x URF_MAX_KEYPOINTS f64 (column-major, the reference's Eigen storage).
 extern "C" int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat) {
   URF_CHECK(h && h->built && nframes && K && matches && nmatch, "urf_fe_collect: bad argument");
+  if (h->deferred_error) { h->deferred_error = false; return -1; }   // urf_last_error() still holds the enqueue failure
   URF_CHECK(!h->pending.empty(), "urf_fe_collect: nothing submitted");
   URF_HIP(hipSetDevice(h->cfg.sp.device));
   const urf_fe::Pending &p0 = h->pending.front();
@@ -266,7 +275,11 @@ extern "C" int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *match
   *nframes = p.n;
   h->pending.pop_front();
   for (auto &q : h->pending)     // the matcher handle is free again: enqueue the batch that was waiting for it
-    if (!q.matched && q.batch % h->M == p.batch % h->M) return fe_enqueue_match(h, q);
+    if (!q.matched && q.batch % h->M == p.batch % h->M) {
+      // this batch has been delivered: a failure of the deferred enqueue belongs to the NEXT call
+      if (fe_enqueue_match(h, q)) h->deferred_error = true;
+      break;
+    }
   return 0;
 }
 

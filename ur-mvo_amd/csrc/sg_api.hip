@@ -96,6 +96,7 @@ struct urf_pm {
   hipEvent_t ev_attn[18][2];
   float stage_ms[PT_COUNT + 1];
   bool ev_valid = false;
+  int pending_P = 0;     // pairs of the batch enqueued by urf_match_device_async and not fetched yet (0 = none)
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -654,6 +655,7 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipEventRecord(h->ev_done, h->st));
+  h->pending_P = P;
   return 0;
 }
 
@@ -667,6 +669,8 @@ extern "C" int urf_pm_sync(urf_pm *h) {
 
 extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(h->pending_P > 0, "urf_pm_fetch: no batch in flight (urf_match_device_async first)");
+  URF_CHECK(P == h->pending_P, "urf_pm_fetch: %d pairs asked, the batch in flight has %d", P, h->pending_P);
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
@@ -678,6 +682,7 @@ extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nou
     nout[p] = n;
     memcpy(out + (size_t)p * cap, h->h_matches + (size_t)p * NP, (size_t)n * sizeof(urf_dmatch));
   }
+  h->pending_P = 0;
   return 0;
 }
 

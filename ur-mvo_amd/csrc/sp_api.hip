@@ -9,12 +9,17 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 namespace urf {
 
-static thread_local char g_err[512] = "";
+// the last error text is process-wide (not thread-local): the reference calls from a fresh std::thread every time
+// (src/tracking.cc:334-335) and reports from whichever thread joins it
+static char g_err[512] = "";
+static std::mutex g_err_mu;
 void set_error(const char *fmt, ...) {
+  std::lock_guard<std::mutex> lock(g_err_mu);
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -108,6 +113,7 @@ extern "C" int urf_sp_create(const urf_sp_config *cfg, urf_sp **out) {
   URF_HIP(hipGetDeviceCount(&ndev));
   URF_CHECK(ndev > 0, "no HIP device: liburf_front needs a gfx950 GPU (there is no CPU fallback)");
   URF_CHECK(cfg->device >= 0 && cfg->device < ndev, "device %d out of range (%d devices)", cfg->device, ndev);
+  URF_CHECK(cfg->keypoint_threshold >= 0.0, "keypoint_threshold %g is negative", cfg->keypoint_threshold);
   urf_sp *h = new urf_sp();
   h->cfg = *cfg;
   h->device = cfg->device;
@@ -256,7 +262,9 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->ss, B * Hs * Ws)) return -1;
   if (dalloc(&h->mask, B * Hs * Ws)) return -1;
   if (dalloc(&h->supp, B * Hs * Ws)) return -1;
-  h->cand_cap = (int)(Hs * Ws / 16 + 1024);
+  // every pixel can be a candidate (a tied plateau survives simple_nms whole; the reference keeps every candidate
+  // before top_k_keypoints, src/super_point.cpp:196-251): 2 x 4 B per pixel and frame
+  h->cand_cap = (int)(Hs * Ws);
   if (dalloc(&h->counts, B * (size_t)select_nchunk((int)Hs, (int)Ws))) return -1;
   if (dalloc(&h->cand_score, B * (size_t)h->cand_cap)) return -1;
   if (dalloc(&h->cand_idx, B * (size_t)h->cand_cap)) return -1;

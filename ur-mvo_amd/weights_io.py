@@ -248,6 +248,12 @@ def superglue_from_onnx(path):
     inits, nodes = read_onnx(path)
     if "final_proj.weight" in inits and "gnn.layers.0.attn.proj.0.weight" in inits and "kenc.encoder.1.running_mean" in inits:
         return superglue_from_state_dict(inits)
+    # the positional path assumes the exporter folded BatchNorm into the Conv weights: a graph that still carries
+    # BatchNormalization nodes has the same Conv count and would silently lose them
+    bn = [op for op, _ins, _outs in nodes if op == "BatchNormalization"]
+    if bn:
+        raise ValueError(f"{path}: {len(bn)} BatchNormalization nodes with renamed initialisers: export with constant "
+                         f"folding (BatchNorm folded into the Conv weights) or keep the parameter names")
     convs = [(W[:, :, 0] if W.ndim == 3 else W, b) for W, b in _convs_in_order(inits, nodes)]
     want = 5 + 6 * synth.SG_LAYERS + 1
     if len(convs) != want:
@@ -312,7 +318,7 @@ def main(argv=None):
         blob = superpoint_from_onnx(src) if a.superpoint else superglue_from_onnx(src)
     else:
         import torch
-        sd = torch.load(src, map_location="cpu")
+        sd = torch.load(src, map_location="cpu", weights_only=True)    # tensors only: a .pth is a pickle
         sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
         blob = superpoint_from_state_dict(sd) if a.superpoint else superglue_from_state_dict(sd)
     save_container(a.out, KIND_SP if a.superpoint else KIND_SG, blob)
