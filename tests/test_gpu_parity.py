@@ -95,8 +95,8 @@ def test_superpoint_full_size_640x480_and_kitti(U, O, sp_blob, sp640):
 @pytest.mark.parametrize("name", ["sp_sparse_240x320.npz", "sp_sparse_376x1241.npz", "sp_sparse_480x640.npz"])
 def test_superpoint_vs_reference_graph_golden(F, sp_blob, name, prec):
     """HIP output vs the torch run of the reference's model.py (committed fixture).  Exact mode: the same
-    keypoint set.  Fast mode (not bit-reproducible): at most 1 % of the keypoints may differ -- scores that
-    are near-ties at the top-k cut or at the threshold -- and every common keypoint is within tolerance."""
+    keypoint set.  Fast mode (not bit-reproducible): at most one swapped pair of keypoints -- a near-tie at the
+    top-k cut -- and every common keypoint is within tolerance."""
     g = golden(name)
     H, W = g["image"].shape
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=int(g["k"])), max_height=H, max_width=W, precision=prec)
@@ -107,7 +107,7 @@ def test_superpoint_vs_reference_graph_golden(F, sp_blob, name, prec):
     if prec == 0:
         assert set(ko) == set(want)                                                   # same keypoint set
     else:
-        assert len(set(ko) ^ set(want)) <= 0.01 * len(want)
+        assert len(set(ko) ^ set(want)) <= 2          # at most one swapped pair at the top-k cut (measured: 0 on all three)
     common = sorted(set(ko) & set(want))
     pf = np.array([ko[c] for c in common]); pg = np.array([want[c] for c in common])
     np.testing.assert_allclose(f[pf, 0], g["score"][pg], rtol=1e-3, atol=1e-5)
@@ -491,7 +491,7 @@ def test_fast_mode_superglue_matches_exact_mode(F, O, sg_blob, n0, n1, seed):
     assert np.abs(Zf - Z).max() < 1e-3
     conf = m0 > 0.6                                          # matches away from the 0.5 threshold
     assert np.array_equal(i0[conf], j0[conf])
-    assert (i0 != j0).sum() <= max(1, n0 // 200) and (i1 != j1).sum() <= max(1, n1 // 200)
+    assert (i0 != j0).sum() <= 1 and (i1 != j1).sum() <= 1        # measured: 0
     assert np.abs(q0 - m0).max() < 1e-3
 
 
@@ -513,7 +513,7 @@ def test_fast_mode_superpoint_matches_exact_mode(U, F, O, sp_blob, H, W, seed):
     assert ((se != 0) != (sf != 0)).sum() <= 2                       # NMS support: at most a near-tie flips
     ke = {(int(r[1]), int(r[2])) for r in fe}
     kf = {(int(r[1]), int(r[2])) for r in ff}
-    assert len(ke ^ kf) <= max(2, len(ke) // 200)
+    assert len(ke ^ kf) <= 2                                 # at most one swapped pair at the top-k cut (measured: 0)
     common = sorted(ke & kf)
     de = {(int(r[1]), int(r[2])): r for r in fe}
     df = {(int(r[1]), int(r[2])): r for r in ff}
