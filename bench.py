@@ -205,14 +205,14 @@ def main():
             pms.append(pm_b)
 
     if async_exchange:
-        # the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI, not torch.distributed.  Two communicators:
-        # the slot all-gather runs on its own stream, the gather of the match lists to rank 0 on the matcher streams,
-        # and RCCL operations of ONE communicator must not be in flight on several streams at once.
-        ids = [D.Comm.unique_id(), D.Comm.unique_id()] if rank == 0 else [None, None]
+        # the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI, not torch.distributed.  One communicator
+        # per stream that carries RCCL calls: the slot all-gather runs on its own stream, the gather of the match lists
+        # to rank 0 on each matcher's stream (operations of ONE communicator must not be in flight on several streams).
+        ids = [D.Comm.unique_id() for _ in range(1 + len(pms))] if rank == 0 else [None] * (1 + len(pms))
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         comm_ag = D.Comm(world, rank, local_rank, ids[0])
-        comm_g = D.Comm(world, rank, local_rank, ids[1])
+        comm_g = [D.Comm(world, rank, local_rank, ids[1 + i]) for i in range(len(pms))]
         sp_ext = torch.cuda.ExternalStream(sp.stream_ptr(), device=dev)
         pm_ext = [torch.cuda.ExternalStream(m.stream_ptr(), device=dev) for m in pms]
         comm = torch.cuda.Stream(device=dev)
@@ -295,8 +295,9 @@ def main():
         if async_exchange:
             # match lists -> rank 0, on the matcher's own stream right behind its kernels (12 KB x pairs per rank)
             d_m, d_n = mt.device_results()
-            comm_g.gather(d_n, BATCH * 4, all_counts.data_ptr(), 0, mt.stream_ptr())
-            comm_g.gather(d_m, BATCH * 1024 * 12, all_matches.data_ptr(), 0, mt.stream_ptr())
+            cg = comm_g[b % len(pms)]
+            cg.gather(d_n, BATCH * 4, all_counts.data_ptr(), 0, mt.stream_ptr())
+            cg.gather(d_m, BATCH * 1024 * 12, all_matches.data_ptr(), 0, mt.stream_ptr())
         if OVERLAP == 1:
             mt.let_sp_overlap_sinkhorn(sp)      # SP(b+1) starts when match(b) reaches Sinkhorn
         sp_step(b + 1)

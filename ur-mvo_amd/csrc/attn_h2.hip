@@ -18,6 +18,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// (p0, p1) -> packed f16 pairs hi = f16(p), lo = f16(p - hi).  The residuals come from v_fma_mix{lo,hi}_f16, which read
+// hi straight from its packed half and round p - hi to f16 in one instruction each (the difference is exact in fp32, so
+// the result is the same as convert-back / subtract / convert: 3 VALU instructions per pair instead of 6)
+__device__ __forceinline__ void split_pair(float p0, float p1, unsigned &hi, unsigned &lo) {
+  const f16x2 h = {(_Float16)p0, (_Float16)p1};
+  hi = __builtin_bit_cast(unsigned, h);
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(p0), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(p1), "v"(hi));
+  lo = l;
+}
+
 constexpr int ANP = kCap;
 constexpr int AS = 80;       // K rows: 160 B, conflict-free ds_read_b128
 constexpr int VS = 72;       // V^T rows: 144 B, conflict-free ds_read_b64
@@ -195,17 +210,25 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     for (int kp = 0; kp < 2; ++kp) {
       f16x8 ph[QT], pl[QT];
 #pragma unroll
-      for (int t = 0; t < QT; ++t)
+      for (int t = 0; t < QT; ++t) {
+        unsigned hw[4], lw[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float sv = s[t][2 * kp + (e >> 2)][e & 3];
-          float p = __builtin_amdgcn_exp2f(sv - mn[t]);
-          if (MASK) p = (sv == -FLT_MAX) ? 0.0f : p;
-          part[t] = part[t] + p;
-          const _Float16 h = (_Float16)p;
-          ph[t][e] = h;
-          pl[t][e] = (_Float16)(p - (float)h);
+        for (int e2 = 0; e2 < 4; ++e2) {
+          float pv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = 2 * e2 + u;
+            const float sv = s[t][2 * kp + (e >> 2)][e & 3];
+            float p = __builtin_amdgcn_exp2f(sv - mn[t]);
+            if (MASK) p = (sv == -FLT_MAX) ? 0.0f : p;
+            part[t] = part[t] + p;
+            pv[u] = p;
+          }
+          split_pair(pv[0], pv[1], hw[e2], lw[e2]);
         }
+        ph[t] = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+        pl[t] = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+      }
       const _Float16 *vph = vbuf[buf][0] + px * VS + (2 * kp) * 16 + 4 * g;
       const _Float16 *vpl = vbuf[buf][1] + px * VS + (2 * kp) * 16 + 4 * g;
 #pragma unroll

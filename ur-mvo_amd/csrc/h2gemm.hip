@@ -330,13 +330,17 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
   URF_CHECK(a.t_from == 0 || (variant == 2 && (a.t_from % 128) == 0 && a.ohT),
             "h2gemm: the dual epilogue needs the LDS-DMA kernel and a 128-aligned split");
   if (variant == 2) {
-    const size_t lds = sizeof(_Float16) * 2 * 4 * GP;   // 64 KiB: two stages of four planes
+    // 64 KiB: two stages of four planes (+ URF_H2GEMM_LDS_PAD bytes: occupancy experiments -- a padded workgroup keeps
+    // its CU to itself and leaves registers / LDS for another stream's kernel)
+    static long pad = -1;
+    if (pad < 0) { const char *e = getenv("URF_H2GEMM_LDS_PAD"); pad = e ? atol(e) : 0; if (pad < 0 || pad > 96 * 1024) pad = 0; }
+    const size_t lds = sizeof(_Float16) * 2 * 4 * GP + (size_t)pad;
     dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
     static bool attr_set = false;
     if (!attr_set) {
-      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
     if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, a);
