@@ -218,8 +218,8 @@ def main():
         comm = torch.cuda.Stream(device=dev)
         gathered_buf = torch.zeros((NB, world * BATCH, slot_floats), dtype=torch.float32, device=dev)
         # rank 0 (where the serial tracker lives) receives every rank's match lists: counts and 12-byte matches
-        all_counts = torch.zeros((world, BATCH), dtype=torch.int32, device=dev)
-        all_matches = torch.zeros((world, BATCH * 1024 * 3), dtype=torch.int32, device=dev)
+        all_counts = [torch.zeros((world, BATCH), dtype=torch.int32, device=dev) for _ in pms]
+        all_matches = [torch.zeros((world, BATCH * 1024 * 3), dtype=torch.int32, device=dev) for _ in pms]
         torch.cuda.synchronize()
 
     sp_calls = [0]   # number of SP calls enqueued so far (batch index of the latest = sp_calls-1)
@@ -295,9 +295,9 @@ def main():
         if async_exchange:
             # match lists -> rank 0, on the matcher's own stream right behind its kernels (12 KB x pairs per rank)
             d_m, d_n = mt.device_results()
-            cg = comm_g[b % len(pms)]
-            cg.gather(d_n, BATCH * 4, all_counts.data_ptr(), 0, mt.stream_ptr())
-            cg.gather(d_m, BATCH * 1024 * 12, all_matches.data_ptr(), 0, mt.stream_ptr())
+            mi = b % len(pms)
+            comm_g[mi].gather(d_n, BATCH * 4, all_counts[mi].data_ptr(), 0, mt.stream_ptr())
+            comm_g[mi].gather(d_m, BATCH * 1024 * 12, all_matches[mi].data_ptr(), 0, mt.stream_ptr())
         if OVERLAP == 1:
             mt.let_sp_overlap_sinkhorn(sp)      # SP(b+1) starts when match(b) reaches Sinkhorn
         sp_step(b + 1)
@@ -348,7 +348,7 @@ def main():
     fps = total_frames / dt
     gathered_total = None
     if async_exchange and rank == 0:
-        gathered_total = int(all_counts.sum().item())          # the last step's matches of ALL ranks, as rank 0 received them
+        gathered_total = int(all_counts[args_last_batch % len(pms)].sum().item())   # the last step's matches of ALL ranks, as rank 0 received them
     insitu = {"superpoint": float(np.mean(sp_ms)) if sp_ms else None, "matching": float(np.mean(pm_ms)),
               "linear": float(np.mean(lin_ms)), "attention": float(np.mean(attn_ms))}
 

@@ -141,6 +141,10 @@ void urf_normalize_keypoints(const double *feat, int n, int width, int height, d
 int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f1, int n1,
                  int *idx0, int *idx1, double *ms0, double *ms1, float *Zout);
 
+/* debug / parity tap (tests): the couplings matrix of the last urf_sg_infer call -- scores m0^T m1 / 16 with the
+ * dustbin row and column (src/super_glue.cpp:466-474), (n0+1) x (n1+1) f32: the input of the Sinkhorn iterations */
+int urf_sg_debug_couplings(urf_pm *h, int n0, int n1, float *out);
+
 /* PointMatching::MatchingPoints(features0, features1, matches,
  * outlier_rejection), src/point_matching.cc:14-61.  Returns the match count
  * (>=0) or <0 on error.  The cv::findFundamentalMat call (:50) is replaced by

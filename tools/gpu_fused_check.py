@@ -12,7 +12,7 @@ from __graft_entry__ import load_pkg  # noqa: E402
 from conftest import make_features  # noqa: E402
 
 U = load_pkg(); F, synth = U.frontend, U.synth
-sg = F.SuperGlue(F.SuperGlueConfig(), precision=1)
+sg = F.SuperGlue(F.SuperGlueConfig(), precision=int(os.environ.get("URF_CHECK_PRECISION", "1")))
 assert sg.build(synth.pack_sg(synth.sg_weights(0)))
 out = []
 for (n0, n1, seed) in [(1000, 1000, 1), (317, 64, 2), (1024, 999, 3)]:

@@ -737,6 +737,15 @@ extern "C" int urf_ransac_find_F_sets(urf_pm *h, const float *pts0, const float 
   return pm_find_F(h, pts0, pts1, n, sets, iterations, inliers, F21, score);
 }
 
+// debug / parity tap (tests): the couplings matrix (scores + dustbins) of pair 0 of the LAST call, (n0+1) x (n1+1) f32
+extern "C" int urf_sg_debug_couplings(urf_pm *h, int n0, int n1, float *out) {
+  URF_CHECK(h && h->built && out && n0 >= 1 && n1 >= 1 && n0 <= NP && n1 <= NP, "urf_sg_debug_couplings: bad argument");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamSynchronize(h->st));
+  URF_HIP(hipMemcpy2D(out, (size_t)(n1 + 1) * 4, h->C, (size_t)LDC * 4, (size_t)(n1 + 1) * 4, n0 + 1, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts) {
   URF_CHECK(h && h->built && d_matches && d_counts, "urf_pm_device_results: bad argument");
   *d_matches = h->fmatches;

@@ -159,13 +159,16 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Pt = lds;                      // [32][1024] plan rows of this workgroup
   float *bvec = Pt + RS_ROWS * RS_NP;   // [1024] b_j (0 for j >= n1)
-  float *v0vec = bvec + RS_NP;          // [1024] v0_j
-  float *avec = v0vec + RS_NP;          // [32] a_i of the own rows (0 for i >= n0)
-  float *u0vec = avec + RS_ROWS;        // [32]
-  float *pcvec = u0vec + RS_ROWS;       // [32] dustbin-column entries exp(alpha + u0_i + v0_dust)
+  float *avec = bvec + RS_NP;           // [32] a_i of the own rows (0 for i >= n0)
+  float *pcvec = avec + RS_ROWS;        // [32] dustbin-column entries exp(alpha + u0_i + v0_dust)
   float *wsum = pcvec + RS_ROWS;        // [16] per-wave partials of the dustbin-row sum
   float *misc = wsum + 16;              // [0] = b of the dustbin column, [1] = "the launch gave up", [2] = one XCD
   float *csumv = misc + 16;             // [1025 (+3)] reduced column sums of this iteration
+  // the absorbed potentials are kept in f64: they are sums of up to eight logarithms of magnitude ~50-100, and the
+  // argument of every exponential, C + u0 + v0, cancels them against each other -- in f32 that cancellation alone
+  // costs ~1e-5 relative on the plan (measured: max |Z - exact| 5.3e-4 with f32 potentials)
+  double *v0vec = (double *)(csumv + 1028);   // [1024] v0_j
+  double *u0vec = v0vec + RS_NP;              // [32] u0_i
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pl = (int)blockIdx.x % a.npairs, w = (int)blockIdx.x / a.npairs;   // pairs congruent mod 8 share an XCD at 8 pairs
@@ -183,8 +186,9 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   // owner of the dustbin column's slot: thread n1 (its own column is invalid) or, at n1 == 1024, thread 0's second slot
   const bool own_dust = (n1 < RS_NP) ? (t == n1) : (t == 0);
 
-  float b_t = col_ok ? 1.0f : 0.0f, v0_t = 0.0f, pd_t = 0.0f;
-  float u0d = -alpha, v0d = 0.0f, Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
+  float b_t = col_ok ? 1.0f : 0.0f, pd_t = 0.0f;
+  double v0_t = 0.0, u0d = -(double)alpha, v0d = 0.0;
+  float Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
 
   // ---- u0_i = -max_j C_ij over the valid columns and the dustbin entry alpha (local to the row's owner)
   {
@@ -203,9 +207,9 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
         }
       }
       m = bfly64_max(m);
-      if (lane == 0) u0vec[ri] = -m;
+      if (lane == 0) u0vec[ri] = -(double)m;
     }
-    v0vec[t] = 0.0f;
+    v0vec[t] = 0.0;
   }
 
   // (re)build the plan tile from the couplings: P_ij = exp(C_ij + u0_i + v0_j); b = 1
@@ -214,27 +218,26 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
       const int ri = r0 + rr, i = i0 + ri;
-      const float u0i = u0vec[ri];
+      const double u0i = u0vec[ri];
 #pragma unroll 2
       for (int q = 0; q < 4; ++q) {
         const int c = 256 * q + 4 * lane;
         f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (i < n0) {
           const f32x4 x = *(const f32x4 *)(Cp + (size_t)i * RS_LDC + c);
-          const f32x4 vv = *(const f32x4 *)(v0vec + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (c + e < n1) pv[e] = __expf((x[e] + u0i) + vv[e]);
+            if (c + e < n1) pv[e] = __expf((float)(((double)x[e] + u0i) + v0vec[c + e]));
         }
         *(f32x4 *)(Pt + ri * RS_NP + c) = pv;
       }
-      if (lane == 0) pcvec[ri] = (i < n0) ? __expf((alpha + u0i) + v0d) : 0.0f;
+      if (lane == 0) pcvec[ri] = (i < n0) ? __expf((float)(((double)alpha + u0i) + v0d)) : 0.0f;
     }
     bvec[t] = col_ok ? 1.0f : 0.0f;
     if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
     __syncthreads();
-    pd_t = col_ok ? __expf((alpha + u0d) + v0_t) : 0.0f;
-    Pdd = __expf((alpha + u0d) + v0d);
+    pd_t = col_ok ? __expf((float)(((double)alpha + u0d) + v0_t)) : 0.0f;
+    Pdd = __expf((float)(((double)alpha + u0d) + v0d));
     b_t = col_ok ? 1.0f : 0.0f;
     bdust = 1.0f;
   };
@@ -372,23 +375,23 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
       next_absorb *= 2;
       __syncthreads();                    // misc[0] written
       bdust = misc[0];
-      if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + __logf(avec[tid]);
-      u0d = u0d + __logf(ad);
-      if (col_ok) v0_t = v0_t + __logf(b_t);
+      if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
+      u0d = u0d + (double)__logf(ad);
+      if (col_ok) v0_t = v0_t + (double)__logf(b_t);
       v0vec[t] = v0_t;
-      v0d = v0d + __logf(bdust);
+      v0d = v0d + (double)__logf(bdust);
       absorb();
     }
   }
   // ---------------- u = u0 + log a, v = v0 + log b
   __syncthreads();
   bdust = misc[0];
-  if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = u0vec[tid] + __logf(avec[tid]);
+  if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
   if (w == 0) {
-    if (col_ok) a.v[(size_t)p * RS_LDC + t] = v0_t + __logf(b_t);
+    if (col_ok) a.v[(size_t)p * RS_LDC + t] = (float)(v0_t + (double)__logf(b_t));
     if (tid == 0) {
-      a.u[(size_t)p * RS_LDC + n0] = u0d + __logf(ad);
-      a.v[(size_t)p * RS_LDC + n1] = v0d + __logf(bdust);
+      a.u[(size_t)p * RS_LDC + n0] = (float)(u0d + (double)__logf(ad));
+      a.v[(size_t)p * RS_LDC + n1] = (float)(v0d + (double)__logf(bdust));
     }
   }
 }
@@ -426,7 +429,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   URF_CHECK(iters >= 1 && iters < 4096, "sinkhorn_resident: iterations %d outside [1, 4095]", iters);
   RsDevice &d = g_rs_dev[device];
   std::lock_guard<std::mutex> lock(d.mu);
-  const size_t lds = sizeof(float) * (RS_ROWS * RS_NP + 2 * RS_NP + 3 * RS_ROWS + 32 + 1028);
+  const size_t lds = sizeof(float) * (RS_ROWS * RS_NP + RS_NP + 2 * RS_ROWS + 32 + 1028) + sizeof(double) * (RS_NP + RS_ROWS);
   if (d.cus < 0) {
     hipDeviceProp_t prop;
     URF_HIP(hipGetDeviceProperties(&prop, device));
