@@ -396,6 +396,9 @@ int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, i
 int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
 /* diagnostic: s_memtime stamps of the LDS-resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
 int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
+/* roof probe: the split-f16 MFMA inner loop on register-resident random operands, no memory, `waves_per_cu` in {4, 8, 16}:
+ * PFLOP/s of MFMA issue and the in-kernel clock the chip holds under that load */
+int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, float *pflops, float *ghz);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
 
 #ifdef __cplusplus

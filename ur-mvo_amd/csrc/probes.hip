@@ -135,3 +135,81 @@ extern "C" int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const fl
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Roof probe: the split-f16 inner loop of h2gemm / h2conv / h2mlp (24 x v_mfma_f32_16x16x32_f16 on 12 operand
+// fragments) with the fragments held in registers -- no LDS, no memory, no barrier.  What the chip sustains on random
+// operands at `waves_per_cu` waves per CU is the ceiling the real kernels can be compared with (the clock the chip holds
+// under matrix load is well below 2.4 GHz: MI355X_MICROARCH.md, DVFS give-back).
+namespace urf {
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(512) probe_mfma_roof_kernel(const _Float16 *seed, float *sink, int iters, long long *clocks) {
+  const int lane = threadIdx.x & 63;
+  pf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { ah[m] = *(const pf16x8 *)(seed + (lane + 64 * m) * 8); al[m] = *(const pf16x8 *)(seed + (lane + 64 * (m + 4)) * 8); }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) { bh[r] = *(const pf16x8 *)(seed + (lane + 64 * (r + 8)) * 8); bl[r] = *(const pf16x8 *)(seed + (lane + 64 * (r + 10)) * 8); }
+  pf32x4 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { acc[m][0] = pf32x4{0, 0, 0, 0}; acc[m][1] = pf32x4{0, 0, 0, 0}; }
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[r], acc[m][r], 0, 0, 0);
+        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[r], acc[m][r], 0, 0, 0);
+        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
+      }
+  }
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+  float s = 0.0f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += acc[m][0][q] + acc[m][1][q];
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
+}
+}  // namespace urf
+
+// returns PFLOP/s of MFMA issue (every MFMA counted) in *pflops and the in-kernel clock (GHz) in *ghz
+extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, float *pflops, float *ghz) {
+  URF_CHECK(pflops && ghz && iters > 0 && (waves_per_cu == 4 || waves_per_cu == 8 || waves_per_cu == 16), "probe_mfma_roof: bad argument");
+  URF_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  URF_HIP(hipGetDeviceProperties(&prop, device));
+  const int cus = prop.multiProcessorCount;
+  const int threads = waves_per_cu >= 8 ? 512 : 256, blocks = cus * (waves_per_cu * 64 / threads);
+  _Float16 *seed; float *sink; long long *clk;
+  URF_HIP(hipMalloc((void **)&seed, 64 * 12 * 8 * 2));
+  URF_HIP(hipMalloc((void **)&sink, (size_t)blocks * threads * 4));
+  URF_HIP(hipMalloc((void **)&clk, 16));
+  std::string dummy;
+  {
+    _Float16 h[64 * 12 * 8];
+    uint32_t x = 12345u;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (_Float16)(((float)(x >> 8) / 16777216.0f - 0.5f) * 0.25f); }
+    URF_HIP(hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1;
+  URF_HIP(hipEventCreate(&e0)); URF_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(urf::probe_mfma_roof_kernel, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters / 10 + 1, clk);   // warm-up
+  URF_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(urf::probe_mfma_roof_kernel, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters, clk);
+  URF_HIP(hipEventRecord(e1, 0));
+  URF_HIP(hipDeviceSynchronize());
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  long long c[2] = {0, 1};
+  URF_HIP(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
+  const double flop = (double)blocks * (threads / 64) * (double)iters * 24.0 * 16384.0;
+  *pflops = (float)(flop / (ms * 1e-3) / 1e15);
+  *ghz = (float)((double)c[0] / (double)c[1] * 0.1);      // s_memrealtime ticks at 100 MHz
+  (void)hipFree(seed); (void)hipFree(sink); (void)hipFree(clk);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+}
