@@ -396,9 +396,13 @@ int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, i
 int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
 /* diagnostic: s_memtime stamps of the LDS-resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
 int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
-/* roof probe: the split-f16 MFMA inner loop on register-resident random operands, no memory, `waves_per_cu` in {4, 8, 16}:
- * PFLOP/s of MFMA issue and the in-kernel clock the chip holds under that load */
-int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, float *pflops, float *ghz);
+/* roof probe: the split-f16 MFMA inner loop, `waves_per_cu` in {4, 8, 16}: PFLOP/s of MFMA issue and the in-kernel clock the
+ * chip holds under that load.  mode 0 = register-resident operands, no memory; 1 = plus the linear-layer kernel's fragment reads
+ * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM */
+int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float *pflops, float *ghz);
+/* diagnostics of the linear-layer kernel for tools/gpu_h2fixed.py: 1 = non-temporal stores, 2 = no stores, 4 = one K chunk only
+ * (2 and 4 give wrong results: timing only); 0 restores the product behaviour */
+int urf_probe_h2gemm_xflags(int flags);
 int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
 
 #ifdef __cplusplus

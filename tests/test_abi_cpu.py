@@ -199,3 +199,32 @@ def test_minimal_sets_glibc_stream_equals_the_c_library(U, O):
     assert F.minimal_sets(1, 0, 100, 1)[0, 0] == int((r / 2147483648.0) * 100)
     with pytest.raises(RuntimeError):
         F.minimal_sets(1, 0, 7, 1)              # fewer than 8 matches cannot seed a hypothesis
+
+
+def test_register_and_lds_budgets_keep_the_pipeline_coresident(tmp_path):
+    """in the three-stream pipeline one h2conv workgroup (one wave per SIMD) runs beside one attn_h2 workgroup
+    (two waves per SIMD) on the same CU, which needs 2 x VGPR(attention) + VGPR(conv) <= 512 and LDS(attention) + LDS(conv)
+    <= 160 KB.  A kernel edit that crosses the budget costs ~5 % of the step without showing in any serialised timing."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    usage = {}
+    for name in ("attn_h2", "h2conv"):
+        out = tmp_path / f"{name}.s"
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "ur-mvo_amd", "csrc", f"{name}.hip"), "-o", str(out)], check=True, capture_output=True)
+        text = out.read_text()
+        for m in re.finditer(r"^(_ZN3urf\w+):.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; LDSByteSize: (\d+)", text, re.S | re.M):
+            usage[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
+    attn = [v for k, v in usage.items() if "attn_h2_kernelILi2ELi8E" in k]
+    convs = [v for k, v in usage.items() if "h2conv_kernel" in k]
+    assert len(attn) == 1 and len(convs) == 4, usage
+    up8 = lambda n: (n + 7) // 8 * 8                   # VGPR allocation granule
+    for vg, scratch, _ in convs:
+        assert 2 * up8(attn[0][0]) + up8(vg) <= 512, (attn, convs)
+        assert scratch <= 64, convs                     # a handful of spilled address registers at most
+    assert attn[0][1] == 0
+    conv_lds = 2 * (2 * 10 * 18 * 80 + 2 * 64 * 80) + 12 * 20 * 4      # launch_h2conv's dynamic LDS, fused variant
+    assert attn[0][2] + conv_lds <= 160 * 1024

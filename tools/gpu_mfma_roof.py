@@ -9,9 +9,11 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 L = load_pkg()._lib.lib()
-for waves in (4, 8, 16):
-    for iters in (2000, 20000):
-        pf, ghz = C.c_float(0), C.c_float(0)
-        assert L.urf_probe_mfma_roof(0, waves, iters, C.byref(pf), C.byref(ghz)) == 0
-        print(f"{waves:2d} waves/CU, {iters:6d} x 24 MFMA per wave: {pf.value:.3f} PFLOP/s of MFMA issue "
-              f"({pf.value / 3:.3f} PFLOP/s logical at 3 MFMAs per product), in-kernel clock {ghz.value:.2f} GHz")
+MODES = ["registers only", "+ LDS fragment reads", "+ barrier per step", "+ LDS-DMA (L2 sources)", "+ LDS-DMA (HBM activations)"]
+for mode in range(5):
+    for waves in ((4, 8, 16) if mode == 0 else (8, 16)):
+        for iters in (2000, 20000):
+            pf, ghz = C.c_float(0), C.c_float(0)
+            assert L.urf_probe_mfma_roof(0, waves, iters, mode, C.byref(pf), C.byref(ghz)) == 0, L.urf_last_error()
+            print(f"mode {mode} ({MODES[mode]:28s}) {waves:2d} waves/CU, {iters:6d} x 24 MFMA per wave: {pf.value:.3f} PFLOP/s of MFMA "
+                  f"issue ({pf.value / 3:.3f} logical), in-kernel clock {ghz.value:.2f} GHz", flush=True)

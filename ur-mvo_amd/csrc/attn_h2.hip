@@ -46,6 +46,7 @@ constexpr int VS = 72;       // V^T rows: 144 B, conflict-free ds_read_b64
 // LDS and shared by the 8 waves.
 // QT query tiles (16 queries each) per wave, NW waves per workgroup: every K / V^T fragment read from
 // LDS feeds QT MFMAs instead of one.
+// At most 192 VGPRs: see h2conv_kernel (co-residency with SuperPoint's convolutions in the pipeline)
 template <int QT, int NW>
 __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, const _Float16 *qkl,
                                                           const _Float16 *vth, const _Float16 *vtl, const int *counts,
@@ -124,8 +125,10 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     }
   };
 
-  if (ns >= 64) issue(0, std::false_type{});
-  else issue(0, std::true_type{});
+  // the Q fragments are loaded BEFORE the first staging loads: the wait that commit(0) needs then covers them too.  Loaded
+  // after, they are still "pending" where the chunk loop is entered, and the counter wait the compiler has to place in
+  // front of their first use inside the loop is a vmcnt(0) -- which in every later iteration waits out the staging loads
+  // of the NEXT chunk right after they were issued
   f16x8 qh[QT][2], ql[QT][2];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -136,6 +139,9 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       ql[t][ks] = *(const f16x8 *)(qkl + qo + 32 * ks);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  if (ns >= 64) issue(0, std::false_type{});
+  else issue(0, std::true_type{});
   commit(0);
   __syncthreads();
 
@@ -156,17 +162,30 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
     constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = ch & 1;
     if (ch + 1 < nchunk) issue(ch + 1, next_tag);
+    // Fragment reads run AHEAD of the MFMAs that use them (K: one 16-key tile, V^T: two 16-d tiles) and are pinned there
+    // with sched_barrier: left to itself the scheduler reloads into the registers the previous MFMAs just read (shortest
+    // live ranges), so every group of MFMAs starts with a full LDS round trip that only the second wave of the SIMD can hide.
     // ---- S^T = K Q^T for the 64 keys of this chunk
     f32x4 s[QT][4];
     const _Float16 *kph = kbuf[buf][0] + px * AS + 8 * g;
     const _Float16 *kpl = kbuf[buf][1] + px * AS + 8 * g;
+    f16x8 kf[2][2][2];   // [ring][ks][plane]
+    auto load_k = [&](int kt) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[kt & 1][ks][0] = *(const f16x8 *)(kph + kt * 16 * AS + 32 * ks);
+        kf[kt & 1][ks][1] = *(const f16x8 *)(kpl + kt * 16 * AS + 32 * ks);
+      }
+    };
+    load_k(0);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
+      if (kt + 1 < 4) load_k(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[QT];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const f16x8 ah = *(const f16x8 *)(kph + kt * 16 * AS + 32 * ks);
-        const f16x8 al = *(const f16x8 *)(kpl + kt * 16 * AS + 32 * ks);
+        const f16x8 ah = kf[kt & 1][ks][0], al = kf[kt & 1][ks][1];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           // the first product of a tile takes the constant 0 as its C operand (no zeroed registers)
@@ -184,7 +203,21 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         }
         s[t][kt] = acc[t];
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // V^T fragments of step i = 4 kp + dt (32 keys x 16 d): ring of three, two in flight
+    const _Float16 *vph = vbuf[buf][0] + px * VS + 4 * g;
+    const _Float16 *vpl = vbuf[buf][1] + px * VS + 4 * g;
+    constexpr int VR = 2;   // ring depth (3 = two steps in flight costs 8 more VGPRs: 200, over the co-residency budget)
+    f16x4 vf[VR][4];     // [ring][hi keys 0-3 | hi keys 16-19 | lo keys 0-3 | lo keys 16-19]
+    auto load_v = [&](int i) {
+      const int kp = i >> 2, dt = i & 3, o = (2 * kp) * 16 + dt * 16 * VS;
+      vf[i % VR][0] = *(const f16x4 *)(vph + o); vf[i % VR][1] = *(const f16x4 *)(vph + o + 16);
+      vf[i % VR][2] = *(const f16x4 *)(vpl + o); vf[i % VR][3] = *(const f16x4 *)(vpl + o + 16);
+    };
+#pragma unroll
+    for (int i = 0; i + 1 < VR; ++i) load_v(i);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax update (per query = per px; the 4 lanes g share it)
     float mn[QT];
 #pragma unroll
@@ -229,15 +262,15 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         ph[t] = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
         pl[t] = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
       }
-      const _Float16 *vph = vbuf[buf][0] + px * VS + (2 * kp) * 16 + 4 * g;
-      const _Float16 *vpl = vbuf[buf][1] + px * VS + (2 * kp) * 16 + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
+        const int i = 4 * kp + dt;
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + VR - 1 < 8) load_v(i + VR - 1);
+        __builtin_amdgcn_sched_barrier(0);
         f16x8 ah, al;
-        const f16x4 a0 = *(const f16x4 *)(vph + dt * 16 * VS), a1 = *(const f16x4 *)(vph + dt * 16 * VS + 16);
-        const f16x4 b0 = *(const f16x4 *)(vpl + dt * 16 * VS), b1 = *(const f16x4 *)(vpl + dt * 16 * VS + 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ah[e] = a0[e]; ah[4 + e] = a1[e]; al[e] = b0[e]; al[4 + e] = b1[e]; }
+        for (int e = 0; e < 4; ++e) { ah[e] = vf[i % VR][0][e]; ah[4 + e] = vf[i % VR][1][e]; al[e] = vf[i % VR][2][e]; al[4 + e] = vf[i % VR][3][e]; }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[t], oacc[t][dt], 0, 0, 0);
@@ -246,6 +279,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (ch + 1 < nchunk) commit(buf ^ 1);
     __syncthreads();
   };

@@ -27,6 +27,7 @@ struct H2Args {
   // dual launch (LDS-DMA kernel): cout tiles below t_from take the normal epilogue (out/oh/ol), tiles from
   // t_from on the transposed one with row index cout - t_from: Q|K and V^T of a GNN layer in ONE launch
   int t_from;
+  int xflags;                // diagnostics (urf_probe_h2gemm_xflags): 1 = non-temporal stores, 2 = no stores, 4 = no K loop
 };
 // fast 3x3 convolution (h2conv.hip).  Activations: NHWC f16 planes [B][H][W][Cin].
 struct H2ConvArgs {

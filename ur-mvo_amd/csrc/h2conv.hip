@@ -18,7 +18,10 @@ constexpr int CTH = 8, CTW = 16, CPH = 10, CPW = 18;
 constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-free ds_read_b128
 
 template <bool POOL, bool FUSE1A, bool OUTF32>
-__global__ void __launch_bounds__(256, 2) h2conv_kernel(H2ConvArgs a) {
+// launch bound of 4 workgroups per CU = a budget of 128 VGPRs (LDS keeps the real number at 2); 128 VGPRs and 78 KB of LDS on purpose: one wave per SIMD of this kernel then fits beside the two 192-register waves per
+// SIMD (and the 78 KB) of attn_h2_kernel on the same CU -- in the three-stream pipeline SuperPoint's convolutions fill the
+// MFMA bubbles of the matcher's attention, worth more (5 %) than what either kernel gains alone from more registers
+__global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 csm[];
   _Float16 *in_h = csm, *in_l = csm + CPH * CPW * CS;          // [180][72] each
   _Float16 *w_h = in_l + CPH * CPW * CS, *w_l = w_h + 64 * CS;  // [64 cout][72] each
@@ -111,6 +114,9 @@ __global__ void __launch_bounds__(256, 2) h2conv_kernel(H2ConvArgs a) {
       __syncthreads();
       if (tap + 1 < 9) issue_w(ch, tap + 1);
       else if (ch + 1 < nchunks) issue_w(ch + 1, 0);
+      // keep the weight loads of the next tap HERE: left alone, the scheduler sinks them below most of this tap's MFMAs
+      // (shorter live ranges) and the commit at the top of the next tap then waits out their whole latency
+      __builtin_amdgcn_sched_barrier(0);
       const int toff = ((tap / 3) * CPW + (tap % 3)) * CS;
       const _Float16 *bp0 = in_h + ((2 * wave) * CPW + px) * CS + 8 * g + toff;
       const _Float16 *bp1 = bp0 + CPW * CS;

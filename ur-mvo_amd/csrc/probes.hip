@@ -144,18 +144,64 @@ extern "C" int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const fl
 namespace urf {
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
-__global__ void __launch_bounds__(512) probe_mfma_roof_kernel(const _Float16 *seed, float *sink, int iters, long long *clocks) {
-  const int lane = threadIdx.x & 63;
+// mode 0: the 24 MFMAs on register-resident fragments.  1: + the GEMM's 12 ds_read_b128 per step.  2: + its barrier.
+// 3: + its LDS-DMA (4 x global_load_lds_dwordx4 per wave per step, vmcnt(0) before the barrier), sources L2-resident.
+// 4: as 3 with the two activation planes streamed from a buffer larger than the Infinity Cache.
+typedef __attribute__((address_space(3))) void probe_lds_void;
+typedef const __attribute__((address_space(1))) void probe_gbl_void;
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) probe_mfma_roof_kernel(const _Float16 *seed, float *sink, int iters, long long *clocks,
+                                                                 const _Float16 *big, size_t big_halfs) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 psm[];   // [stage][Ah | Al | Bh | Bl][128][32]
+  constexpr int GP = 128 * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int wc = (wave >> 2) & 1, wr = wave & 3;
   pf16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
   for (int m = 0; m < 4; ++m) { ah[m] = *(const pf16x8 *)(seed + (lane + 64 * m) * 8); al[m] = *(const pf16x8 *)(seed + (lane + 64 * (m + 4)) * 8); }
 #pragma unroll
   for (int r = 0; r < 2; ++r) { bh[r] = *(const pf16x8 *)(seed + (lane + 64 * (r + 8)) * 8); bl[r] = *(const pf16x8 *)(seed + (lane + 64 * (r + 10)) * 8); }
+  if (MODE >= 1) {
+    for (int i = tid; i < 8 * GP / 8; i += blockDim.x) *(pf16x8 *)(psm + 8 * i) = *(const pf16x8 *)(seed + 8 * (i % 768));
+    __syncthreads();
+  }
   pf32x4 acc[4][2];
 #pragma unroll
   for (int m = 0; m < 4; ++m) { acc[m][0] = pf32x4{0, 0, 0, 0}; acc[m][1] = pf32x4{0, 0, 0, 0}; }
+  const int swz = 8 * (g ^ ((-(px >> 2)) & 3));
+  const int aoff = (wc * 64 + px) * 32 + swz, boff = (wr * 32 + px) * 32 + swz;
+  const int drow = (wave & 7) * 16 + (lane >> 2);
+  const _Float16 *srcA = seed + (size_t)(drow * 4 + (lane & 3)) * 8 % 6000;
+  auto issue = [&](int it, int stage) {
+    _Float16 *base = psm + stage * 4 * GP + (wave & 7) * 16 * 32;
+    const _Float16 *sb = srcA;
+    if (MODE >= 4) sb = big + (((size_t)blockIdx.x * (size_t)iters + (size_t)it) * 8192 + (size_t)(drow * 4 + (lane & 3)) * 8) % (big_halfs - 8192);
+    __builtin_amdgcn_global_load_lds((probe_gbl_void *)(srcA), (probe_lds_void *)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((probe_gbl_void *)(srcA + 8), (probe_lds_void *)(base + GP), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((probe_gbl_void *)(sb), (probe_lds_void *)(base + 2 * GP), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((probe_gbl_void *)(sb + 4096), (probe_lds_void *)(base + 3 * GP), 16, 0, 0);
+  };
   const long long t0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+  if (MODE >= 3) issue(0, 0);
   for (int it = 0; it < iters; ++it) {
+    if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 3) issue(it + 1, (it + 1) & 1);
+    if (MODE >= 1) {
+      asm volatile("" ::: "memory");
+      const _Float16 *st = psm + (it & 1) * 4 * GP;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ah[m] = *(const pf16x8 *)(st + aoff + m * 16 * 32);
+        al[m] = *(const pf16x8 *)(st + GP + aoff + m * 16 * 32);
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        bh[r] = *(const pf16x8 *)(st + 2 * GP + boff + r * 16 * 32);
+        bl[r] = *(const pf16x8 *)(st + 3 * GP + boff + r * 16 * 32);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -165,6 +211,7 @@ __global__ void __launch_bounds__(512) probe_mfma_roof_kernel(const _Float16 *se
         acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
       }
   }
+  if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const long long t1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
   float s = 0.0f;
 #pragma unroll
@@ -177,18 +224,21 @@ __global__ void __launch_bounds__(512) probe_mfma_roof_kernel(const _Float16 *se
 }  // namespace urf
 
 // returns PFLOP/s of MFMA issue (every MFMA counted) in *pflops and the in-kernel clock (GHz) in *ghz
-extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, float *pflops, float *ghz) {
-  URF_CHECK(pflops && ghz && iters > 0 && (waves_per_cu == 4 || waves_per_cu == 8 || waves_per_cu == 16), "probe_mfma_roof: bad argument");
+extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float *pflops, float *ghz) {
+  URF_CHECK(pflops && ghz && iters > 0 && (waves_per_cu == 4 || waves_per_cu == 8 || waves_per_cu == 16) && mode >= 0 && mode <= 4,
+            "probe_mfma_roof: bad argument");
+  URF_CHECK(mode == 0 || waves_per_cu >= 8, "probe_mfma_roof: modes 1-4 model the 8-wave GEMM workgroup");
   URF_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   URF_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount;
   const int threads = waves_per_cu >= 8 ? 512 : 256, blocks = cus * (waves_per_cu * 64 / threads);
-  _Float16 *seed; float *sink; long long *clk;
+  const size_t big_halfs = mode >= 4 ? ((size_t)512 << 20) / 2 : 0;
+  _Float16 *seed, *big = nullptr; float *sink; long long *clk;
   URF_HIP(hipMalloc((void **)&seed, 64 * 12 * 8 * 2));
   URF_HIP(hipMalloc((void **)&sink, (size_t)blocks * threads * 4));
   URF_HIP(hipMalloc((void **)&clk, 16));
-  std::string dummy;
+  if (big_halfs) { URF_HIP(hipMalloc((void **)&big, big_halfs * 2)); URF_HIP(hipMemset(big, 0x11, big_halfs * 2)); }
   {
     _Float16 h[64 * 12 * 8];
     uint32_t x = 12345u;
@@ -197,11 +247,22 @@ extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, floa
   }
   hipEvent_t e0, e1;
   URF_HIP(hipEventCreate(&e0)); URF_HIP(hipEventCreate(&e1));
-  hipLaunchKernelGGL(urf::probe_mfma_roof_kernel, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters / 10 + 1, clk);   // warm-up
+  const size_t lds = mode >= 1 ? 65536 : 0;
+  auto launch = [&](int n) {
+    switch (mode) {
+      case 0: hipLaunchKernelGGL(urf::probe_mfma_roof_kernel<0>, dim3(blocks), dim3(threads), lds, 0, seed, sink, n, clk, big, big_halfs); break;
+      case 1: hipLaunchKernelGGL(urf::probe_mfma_roof_kernel<1>, dim3(blocks), dim3(threads), lds, 0, seed, sink, n, clk, big, big_halfs); break;
+      case 2: hipLaunchKernelGGL(urf::probe_mfma_roof_kernel<2>, dim3(blocks), dim3(threads), lds, 0, seed, sink, n, clk, big, big_halfs); break;
+      case 3: hipLaunchKernelGGL(urf::probe_mfma_roof_kernel<3>, dim3(blocks), dim3(threads), lds, 0, seed, sink, n, clk, big, big_halfs); break;
+      default: hipLaunchKernelGGL(urf::probe_mfma_roof_kernel<4>, dim3(blocks), dim3(threads), lds, 0, seed, sink, n, clk, big, big_halfs); break;
+    }
+  };
+  launch(iters / 10 + 1);   // warm-up
   URF_HIP(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(urf::probe_mfma_roof_kernel, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters, clk);
+  launch(iters);
   URF_HIP(hipEventRecord(e1, 0));
   URF_HIP(hipDeviceSynchronize());
+  URF_HIP(hipGetLastError());
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, e0, e1);
   long long c[2] = {0, 1};
@@ -210,6 +271,7 @@ extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, floa
   *pflops = (float)(flop / (ms * 1e-3) / 1e15);
   *ghz = (float)((double)c[0] / (double)c[1] * 0.1);      // s_memrealtime ticks at 100 MHz
   (void)hipFree(seed); (void)hipFree(sink); (void)hipFree(clk);
+  if (big) (void)hipFree(big);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
 }
