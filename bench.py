@@ -534,6 +534,7 @@ def main():
             "stage_ms_per_step": stage_means,
             "matches_per_step": round(float(np.mean(n_matches)), 1),
             "matches_last_step_all_ranks_at_rank0": gathered_total,
+            "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms),   # resident launches redone with the streaming kernels
         }
         print(json.dumps(out))
     if world > 1 or force_dist:

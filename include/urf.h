@@ -249,6 +249,11 @@ int urf_comm_plan_pairs(int world, int rank, int per_rank, int *first, int *seco
 /* device buffers holding the last batch of a matcher: matches [max_pairs][URF_MAX_KEYPOINTS] urf_dmatch and
  * counts [max_pairs] int (valid after the batch's kernels; order with urf_pm_stream) */
 int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts);
+/* How often this handle's LDS-resident Sinkhorn launch (fast mode) gave up -- its 32 workgroups per pair did not become
+ * co-resident within 0.25 s, e.g. another process holds CUs -- and the batch was redone with the streaming kernels before its
+ * results were handed out (the handle then stays on the streaming kernels).  Normally 0.  Results are the same either way;
+ * a caller that shipped the device lists elsewhere before fetching (the gather above) ships them again when this number moved. */
+int urf_pm_sinkhorn_fallbacks(const urf_pm *h);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */
@@ -396,6 +401,8 @@ int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, i
 int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
 /* diagnostic: s_memtime stamps of the LDS-resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
 int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
+/* test hook: the next `launches` resident Sinkhorn launches of this process report a give-up (exercises the recovery above) */
+int urf_probe_sinkhorn_fault(int launches);
 /* roof probe: the split-f16 MFMA inner loop, `waves_per_cu` in {4, 8, 16}: PFLOP/s of MFMA issue and the in-kernel clock the
  * chip holds under that load.  mode 0 = register-resident operands, no memory; 1 = plus the linear-layer kernel's fragment reads
  * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM */

@@ -240,6 +240,42 @@ def test_resident_sinkhorn_equals_the_streaming_kernels(tmp_path):
         o += zs + 2 * n0
 
 
+def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(U, F, sg_blob):
+    """a resident launch that reports a give-up (urf_probe_sinkhorn_fault; in the field: its workgroups never became
+    co-resident) costs nothing but time: the batch is redone with the streaming kernels before the results leave the
+    library, the handle stays on them, and the caller sees the same matches"""
+    import os
+    if os.environ.get("URF_SINKHORN_RESIDENT", "1") == "0":
+        pytest.skip("resident Sinkhorn switched off")
+    L = U._lib.lib()
+    rng = np.random.default_rng(77)
+    f0 = make_features(rng, 1000)
+    f1 = make_features(rng, 1024, planted_from=f0, m=600)
+    pm = F.PointMatching(F.SuperGlueConfig(), precision=1)
+    assert pm.build(sg_blob)
+    sg = F.SuperGlue(F.SuperGlueConfig(), precision=1)
+    assert sg.build(sg_blob)
+    nf0, nf1 = F.PointMatching.NormalizeKeypoints(None, f0, 640, 512), F.PointMatching.NormalizeKeypoints(None, f1, 640, 512)
+    want = pm.MatchingPoints(f0, f1, True)
+    i0, i1, m0, m1, Z = sg.infer(nf0, nf1, want_scores=True)
+    assert len(want) > 300 and pm.sinkhorn_fallbacks() == 0 and sg.sinkhorn_fallbacks() == 0
+    try:
+        assert L.urf_probe_sinkhorn_fault(1) == 0
+        got = pm.MatchingPoints(f0, f1, True)
+        assert pm.sinkhorn_fallbacks() == 1
+        assert L.urf_probe_sinkhorn_fault(1) == 0
+        j0, j1, q0, q1, Z2 = sg.infer(nf0, nf1, want_scores=True)
+        assert sg.sinkhorn_fallbacks() == 1
+    finally:
+        L.urf_probe_sinkhorn_fault(0)
+    assert [(q, t) for q, t, _ in got] == [(q, t) for q, t, _ in want]
+    assert np.abs(np.array([m[2] for m in got]) - np.array([m[2] for m in want])).max() < 1e-3
+    assert np.array_equal(i0, j0) and np.array_equal(i1, j1) and np.abs(Z - Z2).max() < 1e-3
+    # the handles stay on the streaming kernels: same answers, no further fallback
+    assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == [(q, t) for q, t, _ in want]
+    assert pm.sinkhorn_fallbacks() == 1
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_sinkhorn_stage_vs_float64_on_the_same_couplings(U, O, sg_exact, sg_fast, prec):
     """the optimal-transport layer alone: the couplings the GPU produced (urf_sg_debug_couplings) run through a float64

@@ -79,6 +79,8 @@ struct urf_pm {
   unsigned rs_salt = 0;
   int *rs_err = nullptr, *h_rs_err = nullptr;
   bool rs_on = false;
+  int rs_fallbacks = 0;                       // launches that gave up and were redone with the streaming kernels
+  int last_P = 0; bool last_Z = false, last_ransac = false;   // what the last pm_pipeline ran (pm_check_resident redoes its tail)
   int *mi0 = nullptr, *mi1 = nullptr, *idx0 = nullptr, *idx1 = nullptr, *nmatch = nullptr, *nfinal = nullptr;
   float *mv0 = nullptr, *mv1 = nullptr;
   double *ms0 = nullptr, *ms1 = nullptr;
@@ -461,6 +463,8 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
   return 0;
 }
 
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof);
+
 // the whole matching pipeline for P pairs whose inputs (counts, kin, kxy, x) are in place
 static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   hipStream_t st = h->st;
@@ -497,6 +501,15 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
                   nullptr, false))
       return -1;
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
+  h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
+  return pm_tail(h, P, want_Z, ransac, prof);
+}
+
+// scores -> Sinkhorn -> decode -> outlier stage, from the projected descriptors h->mdesc (which stay in place until the next
+// pm_pipeline of this handle: pm_check_resident can run this again)
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof) {
+  hipStream_t st = h->st;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
   (void)hipEventRecord(h->ev_sink, st);
@@ -521,15 +534,21 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   return 0;
 }
 
-// after the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?
+// After the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?  (Its workgroups spin on
+// each other, so a launch whose 32 workgroups per pair do not become co-resident within 0.25 s -- another process holding
+// CUs, say -- abandons the exchange.)  Then the handle goes back to the streaming kernels for good and the tail of the
+// batch is redone with them from the projected descriptors, synchronously.  Returns 1 when the device results were
+// rewritten that way (the caller repeats its copies), 0 when there was nothing to do.
 static int pm_check_resident(urf_pm *h) {
-  if (h->h_rs_err && h->h_rs_err[0] != 0) {
-    h->h_rs_err[0] = 0;
-    (void)hipMemsetAsync(h->rs_err, 0, sizeof(int), h->st);
-    URF_CHECK(false, "resident Sinkhorn timed out: its %d workgroups per pair never became co-resident (another process "
-                     "on this GPU?); set URF_SINKHORN_RESIDENT=0 to use the streaming kernels", 32);
-  }
-  return 0;
+  if (!(h->h_rs_err && h->h_rs_err[0] != 0)) return 0;
+  h->h_rs_err[0] = 0;
+  URF_HIP(hipMemsetAsync(h->rs_err, 0, sizeof(int), h->st));
+  h->rs_on = false;
+  h->rs_fallbacks += 1;
+  URF_CHECK(h->last_P >= 1, "resident Sinkhorn gave up and there is no batch to redo");
+  if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false)) return -1;
+  URF_HIP(hipStreamSynchronize(h->st));
+  return 1;
 }
 
 static void pm_collect_times(urf_pm *h) {
@@ -599,16 +618,20 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
   if (pm_upload_pair(h, f0, nullptr, n0, f1, nullptr, n1)) return -1;
   if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
   if (pm_pipeline(h, 1, Zout != nullptr, false)) return -1;
-  URF_HIP(hipMemcpyAsync(idx0, h->idx0, n0 * sizeof(int), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(idx1, h->idx1, n1 * sizeof(int), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(ms0, h->ms0, n0 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(ms1, h->ms1, n1 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  if (Zout)
-    URF_HIP(hipMemcpy2DAsync(Zout, (size_t)(n1 + 1) * 4, h->Z, (size_t)LDC * 4, (size_t)(n1 + 1) * 4, n0 + 1,
-                             hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipStreamSynchronize(h->st));
-  pm_collect_times(h);
-  if (pm_check_resident(h)) return -3;
+  for (int pass = 0; pass < 2; ++pass) {   // a second pass only after pm_check_resident redid the tail
+    URF_HIP(hipMemcpyAsync(idx0, h->idx0, n0 * sizeof(int), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipMemcpyAsync(idx1, h->idx1, n1 * sizeof(int), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipMemcpyAsync(ms0, h->ms0, n0 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipMemcpyAsync(ms1, h->ms1, n1 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    if (Zout)
+      URF_HIP(hipMemcpy2DAsync(Zout, (size_t)(n1 + 1) * 4, h->Z, (size_t)LDC * 4, (size_t)(n1 + 1) * 4, n0 + 1,
+                               hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipStreamSynchronize(h->st));
+    if (pass == 0) pm_collect_times(h);
+    const int redo = pm_check_resident(h);
+    if (redo < 0) return -3;
+    if (redo == 0) break;
+  }
   return 0;
 }
 
@@ -624,11 +647,15 @@ extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, 
   if (pm_upload_pair(h, nf0.data(), f0, n0, nf1.data(), f1, n1)) return -1;
   if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
   if (pm_pipeline(h, 1, false, outlier_rejection != 0)) return -1;
-  URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, sizeof(int), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipStreamSynchronize(h->st));
-  pm_collect_times(h);
-  if (pm_check_resident(h)) return -3;
+  for (int pass = 0; pass < 2; ++pass) {
+    URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipStreamSynchronize(h->st));
+    if (pass == 0) pm_collect_times(h);
+    const int redo = pm_check_resident(h);
+    if (redo < 0) return -3;
+    if (redo == 0) break;
+  }
   const int n = h->h_n[0];
   URF_CHECK(n <= cap, "match buffer too small: %d > cap %d", n, cap);
   memcpy(out, h->h_matches, (size_t)n * sizeof(urf_dmatch));
@@ -659,6 +686,8 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   return 0;
 }
 
+extern "C" int urf_pm_sinkhorn_fallbacks(const urf_pm *h) { return h ? h->rs_fallbacks : -1; }
+
 extern "C" int urf_pm_sync(urf_pm *h) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_HIP(hipSetDevice(h->device));
@@ -674,7 +703,15 @@ extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nou
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
-  if (pm_check_resident(h)) return -3;
+  {
+    const int redo = pm_check_resident(h);
+    if (redo < 0) return -3;
+    if (redo > 0) {   // the tail was redone with the streaming kernels: fetch the rewritten lists
+      URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
+      URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+      URF_HIP(hipStreamSynchronize(h->st));
+    }
+  }
   URF_CHECK(P >= 1 && P <= h->maxP && out && nout, "urf_pm_fetch: bad argument");
   for (int p = 0; p < P; ++p) {
     const int n = h->h_n[p];

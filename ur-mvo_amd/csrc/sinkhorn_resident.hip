@@ -27,6 +27,7 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -423,6 +424,8 @@ int sinkhorn_resident_enabled() {
 
 long long *g_rs_stamps = nullptr;   // set by urf_probe_sinkhorn_stamps
 
+static std::atomic<int> g_rs_fault{0};   // urf_probe_sinkhorn_fault: that many launches report a give-up (tests of the recovery)
+
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st) {
   URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
@@ -468,6 +471,10 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
   }
+  if (g_rs_fault.load() > 0) {
+    g_rs_fault.fetch_sub(1);
+    URF_HIP(hipMemsetAsync(err, 1, sizeof(int), st));
+  }
   return 0;
 }
 
@@ -491,4 +498,11 @@ extern "C" int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out) 
   (void)hipFree(urf::g_rs_stamps);
   urf::g_rs_stamps = nullptr;
   return rc;
+}
+
+// test hook: the next `launches` resident launches of this process report a give-up although they ran (the recovery path of
+// sg_api.hip is otherwise only reachable by starving the launch of CUs)
+extern "C" int urf_probe_sinkhorn_fault(int launches) {
+  urf::g_rs_fault.store(launches < 0 ? 0 : launches);
+  return 0;
 }

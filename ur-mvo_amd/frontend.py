@@ -168,6 +168,10 @@ class _PM:
             rc = L.urf_pm_build_file(self._h, self.cfg.engine_file.encode())
         return rc == 0
 
+    def sinkhorn_fallbacks(self):
+        """how often the resident Sinkhorn launch of this handle gave up and the batch was redone with the streaming kernels"""
+        return int(_lib.lib().urf_pm_sinkhorn_fallbacks(self._h))
+
     def stage_ms(self):
         ms = (C.c_float * 16)()
         n = check(_lib.lib().urf_pm_stage_ms(self._h, ms, 16), "stage_ms")
