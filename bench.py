@@ -110,8 +110,8 @@ def pmc_traffic(kernel_label, resolution, prec):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # 0.5 s per timed region: the drain of the last step is 1 % of it, not 5 %
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--batch-per-gpu", type=int, default=8,
                     help="frames (and pairs) per GPU per step: 8 = BASELINE configs[2]; 4 with --gpus 8 and --resolution "
