@@ -96,7 +96,8 @@ def pmc_traffic(kernel_label, resolution, prec):
         return None, (f"{os.path.basename(files[-1])} was taken on other kernel sources (sha {d.get('source_sha')} != "
                       f"{kernel_source_sha()}): refused")
     fam = ("h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
-           else "sinkhorn_resident_kernel" if "resident" in kernel_label
+           else "sinkhorn_regs_kernel" if "sinkhorn_regs_kernel" in kernel_label
+           else "sinkhorn_resident_kernel" if "sinkhorn_resident_kernel" in kernel_label
            else "sinkhorn_half_kernel" if "inkhorn" in kernel_label else "h2conv_kernel<pool,fuse1a>")
     k = d["kernels"].get(fam)
     if not k:
@@ -392,10 +393,12 @@ def main():
         }
         resident = PREC == 1 and os.environ.get("URF_SINKHORN_RESIDENT", "1") != "0"
         if resident:
-            # LDS-resident Sinkhorn (sinkhorn_resident.hip): the couplings are read from HBM/L2 once per (re)absorption
-            # (initially and after iterations 1, 2, 4, ... 64: 8 times), 2 fma per element and iteration; no roof binds
-            # it -- an iteration is one inter-CU exchange (latency)
-            per_step["Sinkhorn (sinkhorn_resident_kernel, %d iterations in LDS)" % SINK_ITERS] = (
+            # chip-resident Sinkhorn (sinkhorn_resident.hip; plan tile in registers, or in LDS with URF_SINKHORN_REGS=0): the
+            # couplings are read from HBM/L2 once per (re)absorption (initially and after iterations 1, 2, 4, ... 64: 8
+            # times), 2 fma per element and iteration; no roof binds it -- an iteration is one inter-CU exchange (latency)
+            rs_name = ("sinkhorn_resident_kernel, %d iterations in LDS" if os.environ.get("URF_SINKHORN_REGS", "1") == "0"
+                       else "sinkhorn_regs_kernel, %d iterations in registers")
+            per_step["Sinkhorn (" + rs_name % SINK_ITERS + ")"] = (
                 np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 2 / 1e9, 8 * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
         else:
             # log-Sinkhorn: 2 passes per iteration, each streams one (n0+1) x (n1+1) f32 matrix (C or C^T) once

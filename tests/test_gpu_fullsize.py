@@ -210,7 +210,8 @@ def test_sweep_superpoint_fast_vs_exact(U, F, sp_blob, seed):
 
 
 def test_resident_sinkhorn_equals_the_streaming_kernels(tmp_path):
-    """the LDS-resident Sinkhorn (one persistent launch, scaling form, exchange between CUs) against the 200 streaming
+    """the chip-resident Sinkhorn (one persistent launch, scaling form, exchange between CUs; plan tile in registers --
+    the default -- or in LDS) against the 200 streaming
     launches of the same fast mode, and the fused MLP kernel against the two GEMM launches: separate processes (the
     switches are read once), three seeded pairs incl. n = 1024 and ragged counts.  The fused MLP is bit-identical;
     the two Sinkhorn forms agree to 1e-3 on the whole log-assignment (the f32 log-domain form carries ~4e-4 of rounding
@@ -222,22 +223,26 @@ def test_resident_sinkhorn_equals_the_streaming_kernels(tmp_path):
     out = {}
     for name, env in (("stream", {"URF_SINKHORN_RESIDENT": "0"}), ("resident", {"URF_SINKHORN_RESIDENT": "1"}),
                       ("near_off", {"URF_SINKHORN_NEAR": "0"}), ("whole_chip", {"URF_SINKHORN_GROUP": "8"}),
-                      ("fused", {"URF_GNN_FUSED": "1"})):
+                      ("fused", {"URF_GNN_FUSED": "1"}), ("lds", {"URF_SINKHORN_REGS": "0"}),
+                      ("lds_near_off", {"URF_SINKHORN_REGS": "0", "URF_SINKHORN_NEAR": "0"}), ("regs128", {"URF_SINKHORN_REGS": "2"})):
         p = str(tmp_path / (name + ".npy"))
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gpu_fused_check.py"), p],
                               env=dict(os.environ, **env), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         out[name] = np.load(p)
     assert np.array_equal(out["fused"], out["resident"])                 # same arithmetic, same order
     assert np.array_equal(out["near_off"], out["resident"]) and np.array_equal(out["whole_chip"], out["resident"])
+    assert np.array_equal(out["regs128"], out["resident"])               # the register budget does not change the arithmetic
+    assert np.array_equal(out["lds_near_off"], out["lds"])
     n = [(1000, 1000), (317, 64), (1024, 999)]
-    o = 0
-    for n0, n1 in n:
-        zs = (n0 + 1) * (n1 + 1)
-        za, zb = out["stream"][o:o + zs], out["resident"][o:o + zs]
-        assert np.abs(za - zb).max() < 1e-3
-        ia, ib = out["stream"][o + zs:o + zs + n0], out["resident"][o + zs:o + zs + n0]
-        assert np.array_equal(ia, ib) and (ia >= 0).sum() > min(n0, n1) // 3
-        o += zs + 2 * n0
+    for other, tol in (("stream", 1e-3), ("lds", 1e-4)):      # the two chip-resident kernels differ only in summation order
+        o = 0
+        for n0, n1 in n:
+            zs = (n0 + 1) * (n1 + 1)
+            za, zb = out[other][o:o + zs], out["resident"][o:o + zs]
+            assert np.abs(za - zb).max() < tol
+            ia, ib = out[other][o + zs:o + zs + n0], out["resident"][o + zs:o + zs + n0]
+            assert np.array_equal(ia, ib) and (ia >= 0).sum() > min(n0, n1) // 3
+            o += zs + 2 * n0
 
 
 def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(U, F, sg_blob):

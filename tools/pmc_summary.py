@@ -42,7 +42,7 @@ def per_kernel(db):
 def family(name):
     if "h2conv_kernel<true, true" in name:
         return "h2conv_kernel<pool,fuse1a>"      # conv1a+conv1b fused: its own line (bench.py's conv1 kernel)
-    for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "conv_mfma_kernel",
+    for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "sinkhorn_regs_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
                 "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel"):
         if key in name:

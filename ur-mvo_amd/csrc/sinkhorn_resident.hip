@@ -20,7 +20,11 @@
 // polled with agent-scope loads -- the data is the flag, no fence (cdna_hip_programming.md G16/R2):
 //   hop 1: workgroup w -> reducer r = column / 32;   hop 2: reducer -> every workgroup.
 // Every spin is bounded (0.25 s of s_memrealtime): a launch that cannot become co-resident gives up,
-// raises *err and the host reports an error instead of hanging the GPU.
+// raises *err and the host redoes the batch with the streaming kernels (sg_api.hip) instead of hanging the GPU.
+//
+// Two kernels share the exchange: sinkhorn_resident_kernel keeps the plan tile in LDS (128 KiB, 1024 threads: the CU is
+// its alone), sinkhorn_regs_kernel -- the default -- keeps it in registers (512 threads, 64 VGPRs of plan per thread, 6 KB
+// of LDS, every pair of a batch in one launch).
 #include "urf_common.h"
 #include "urf_math.h"
 
@@ -398,6 +402,297 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Register-resident variant (URF_SINKHORN_REGS=1).  Same recurrence, same exchange, but the plan tile lives in VGPRs:
+// 512 threads, thread t owns columns t and t + 512 of the workgroup's 32 rows (64 registers).  LDS shrinks from 144 KB
+// to the vectors (7 KB) and the workgroup to two waves per SIMD, so a CU that hosts one can still take an h2gemm or an
+// h2conv workgroup of another stream -- the 144 KB kernel above keeps its CUs to itself.  The price: every row sum is
+// a reduction across the 512 threads (32 DPP wave sums per iteration instead of 2).
+constexpr int RG_T = 512;
+
+// wave-wide sum whose total is only valid in lane 63 (wave_sum_dpp without the broadcast)
+__device__ __forceinline__ float wave_sum_dpp_l63(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
+  };
+  v = v + dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});
+  v = v + dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});
+  v = v + dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});
+  v = v + dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});
+  v = v + dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
+  v = v + dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
+  return v;
+}
+
+// 32 values per lane (one per row) -> the 32 wave-wide sums, one per lane pair: a butterfly that halves the number of
+// live values at every level (reduce-scatter).  Levels: lane ^ 32 and lane ^ 16 by v_permlane32_swap / v_permlane16_swap
+// (one swap + one add per pair of rows), then row_mirror, row_half_mirror and the quad permutations on the DPP
+// network (select + DPP add).  70 VALU operations against 32 x 6 for one wave sum per row, and short dependency
+// chains.  Afterwards lane l (and l ^ 1) holds the sum of row rs_row_of_lane(l).
+typedef unsigned rs_u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float rs_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int rs_row_of_lane(int l) {
+  return 16 * (l >> 5) + 8 * ((l >> 4) & 1) + 4 * ((l >> 3) & 1) + 2 * ((l >> 2) & 1) + ((l >> 1) & 1);
+}
+template <typename VAL>
+__device__ __forceinline__ float rs_rows32_sum(VAL val, int lane) {   // val(r) = this lane's term of row r, evaluated once
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {      // lanes 0-31 keep row r, lanes 32-63 row r + 16
+    const rs_u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(val(r)), __float_as_uint(val(r + 16)), false, false);
+    v[r] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {       // 16-lane rows 0, 2 keep row r (+16), rows 1, 3 row r + 8 (+16)
+    const rs_u32x2 x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 8]), false, false);
+    v[r] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+  }
+  const bool b8 = (lane & 8) != 0, b4 = (lane & 4) != 0, b2 = (lane & 2) != 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {       // l <-> 15 - l within a row of 16: lanes with bit 3 keep row r + 4
+    const float keep = b8 ? v[r + 4] : v[r], send = b8 ? v[r] : v[r + 4];
+    v[r] = keep + rs_dpp<0x140>(send);
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {       // l <-> 7 - l within 8 lanes: bit 2 keeps row r + 2
+    const float keep = b4 ? v[r + 2] : v[r], send = b4 ? v[r] : v[r + 2];
+    v[r] = keep + rs_dpp<0x141>(send);
+  }
+  {
+    const float keep = b2 ? v[1] : v[0], send = b2 ? v[0] : v[1];   // lane ^ 2: bit 1 keeps row 1
+    v[0] = keep + rs_dpp<0x4E>(send);
+  }
+  return v[0] + rs_dpp<0xB1>(v[0]);   // lane ^ 1
+}
+
+template <int MINW>   // waves per SIMD the register budget is cut for: 3 -> 168 VGPRs, 4 -> 128
+__global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
+  __shared__ __attribute__((aligned(16))) float avec[RS_ROWS];      // a_i of the own rows (0 for i >= n0)
+  __shared__ __attribute__((aligned(16))) float pcvec[RS_ROWS];     // dustbin-column entries exp(alpha + u0_i + v0_dust)
+  __shared__ float rowpart[8][RS_ROWS];                             // per-wave partial row sums (or maxima)
+  __shared__ float wsum[8];                                         // per-wave partials of the dustbin-row sum
+  __shared__ float misc[4];                                         // [0] = b of the dustbin column, [1] = gave up, [2] = one XCD
+  __shared__ float csumv[1028];                                     // reduced column sums of this iteration
+  __shared__ double u0vec[RS_ROWS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pl = (int)blockIdx.x % a.npairs, w = (int)blockIdx.x / a.npairs;
+  const int p = a.pair0 + pl;
+  const int n0 = a.counts[2 * p], n1 = a.counts[2 * p + 1];
+  const float *Cp = a.C + (size_t)p * (RS_NP + 1) * RS_LDC;
+  // the couplings through a buffer resource: row = scalar offset, column = ONE VGPR (+ 2048 B for the second column).  With
+  // plain pointers the compiler keeps 64 loop-invariant 64-bit addresses, spills them, and every load of a re-absorption
+  // waits for its address to come back from scratch (measured: 76 k ticks per re-absorption against 11 k)
+  const __amdgpu_buffer_rsrc_t Crs = __builtin_amdgcn_make_buffer_rsrc((void *)Cp, 0, (RS_NP + 1) * RS_LDC * 4, 0x00020000);
+  auto Cload = [&](int row, int second) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Crs, 4 * (int)threadIdx.x + 2048 * second, row * (RS_LDC * 4), 0));
+  };
+  u64 *xin = a.xin + (size_t)p * RS_XIN, *xbc = a.xbc + (size_t)p * RS_XBC;
+  const float tot = (float)(n0 + n1);
+  const float mu = 1.0f / tot, mu_d = (float)n1 / tot, nu = 1.0f / tot, nu_d = (float)n0 / tot;
+  const float alpha = a.alpha;
+  const int i0 = w * RS_ROWS;
+  const int c0 = tid, c1 = tid + RG_T;        // this thread's two columns
+  const bool ok0 = c0 < n1, ok1 = c1 < n1;
+  // the dustbin column's sum travels in the slot of column n1 (an invalid column) or, at n1 == 1024, in the extra slot of thread 0
+  const bool dust0 = n1 < RS_NP && c0 == n1, dust1 = n1 < RS_NP && c1 == n1;
+  const bool own_dust = (n1 < RS_NP) ? (dust0 || dust1) : (tid == 0);
+  const int dust_wave = (n1 & (RG_T - 1)) >> 6;
+
+  float P0[RS_ROWS], P1[RS_ROWS];
+  float b0 = ok0 ? 1.0f : 0.0f, b1 = ok1 ? 1.0f : 0.0f, pd0 = 0.0f, pd1 = 0.0f;
+  double v00 = 0.0, v01 = 0.0, u0d = -(double)alpha, v0d = 0.0;
+  float Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
+
+  // ---- u0_i = -max_j C_ij over the valid columns and the dustbin entry alpha (all 64 loads first, then the wave maxima)
+  {
+    float mv[RS_ROWS];
+#pragma unroll
+    for (int i = 0; i < RS_ROWS; ++i) {
+      // unconditional loads (every (row, column) read here exists in the buffer); rows >= n0 too: their maxima are
+      // never used (a wave-uniform test here would come back as a branch with a full wait behind every load)
+      const float x0 = Cload(i0 + i, 0), x1 = Cload(i0 + i, 1);
+      float m = alpha;
+      m = ok0 ? fmaxf(m, x0) : m;
+      m = ok1 ? fmaxf(m, x1) : m;
+      mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ROWS; ++i) {
+      const float m = bfly64_max(mv[i]);
+      if (lane == 0) rowpart[wv][i] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < RS_ROWS) {
+    float m = rowpart[0][tid];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) m = fmaxf(m, rowpart[q][tid]);
+    u0vec[tid] = (i0 + tid < n0) ? -(double)m : -1.0e300;   // rows past the count: exp(C + u0 + v0) = 0 without a test in absorb()
+  }
+
+  auto absorb = [&]() {
+    __syncthreads();                      // u0vec written, nobody still reads avec / pcvec
+#pragma unroll
+    for (int i = 0; i < RS_ROWS; ++i) {
+      const double u0i = u0vec[i];
+      const float x0 = Cload(i0 + i, 0), x1 = Cload(i0 + i, 1);
+      const float q0 = __expf((float)(((double)x0 + u0i) + v00)), q1 = __expf((float)(((double)x1 + u0i) + v01));
+      P0[i] = ok0 ? q0 : 0.0f;          // rows >= n0: u0 = -1e300, the exponential is 0
+      P1[i] = ok1 ? q1 : 0.0f;
+    }
+    if (tid < RS_ROWS) pcvec[tid] = (i0 + tid < n0) ? __expf((float)(((double)alpha + u0vec[tid]) + v0d)) : 0.0f;
+    if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
+    pd0 = ok0 ? __expf((float)(((double)alpha + u0d) + v00)) : 0.0f;
+    pd1 = ok1 ? __expf((float)(((double)alpha + u0d) + v01)) : 0.0f;
+    Pdd = __expf((float)(((double)alpha + u0d) + v0d));
+    b0 = ok0 ? 1.0f : 0.0f; b1 = ok1 ? 1.0f : 0.0f;
+    bdust = 1.0f;
+    __syncthreads();
+  };
+  absorb();
+
+  // ---- placement (see sinkhorn_resident_kernel)
+  bool near = false;
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned tag0 = (a.salt << 12) | 0xFFFu;
+    if (tid == 0) rs_store(xbc + 1056 + w, tag0, (float)(xcc & 15u), false);
+    if (wv == 0) {
+      float ids = 0.0f;
+      const bool alive = rs_sweep<1, true>(xbc + 1056, RS_WG, tag0, ids, nullptr, lane, a.err);
+      const float first = __shfl(ids, 0, 64);
+      const bool same = __all(lane >= RS_WG || ids == first);
+      if (lane == 0) { misc[2] = same ? 1.0f : 0.0f; if (!alive) misc[1] = 1.0f; }
+    }
+    __syncthreads();
+    if (misc[1] != 0.0f) return;
+    near = misc[2] != 0.0f && a.allow_near != 0;
+  }
+
+  int next_absorb = 1;
+  const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  for (int k = 1; k <= a.iters; ++k) {
+    const unsigned tag = (a.salt << 12) | (unsigned)k;
+    // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust); 32 wave sums, 8 partials per row through LDS
+    __syncthreads();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
+    bdust = misc[0];
+    RS_STAMP(0);
+    {
+      const float sv = rs_rows32_sum([&](int r) { return fma_rn(P0[r], b0, P1[r] * b1); }, lane);
+      if ((lane & 1) == 0) rowpart[wv][rs_row_of_lane(lane)] = sv;
+    }
+    {
+      const float part = wave_sum_dpp_l63(fma_rn(pd0, b0, pd1 * b1));   // dustbin row: sum_j pd_j b_j
+      if (lane == 63) wsum[wv] = part;
+    }
+    RS_STAMP(1);
+    __syncthreads();
+    if (tid < RS_ROWS) {
+      float r = rowpart[0][tid];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) r = r + rowpart[q][tid];
+      r = fma_rn(pcvec[tid], bdust, r);
+      avec[tid] = (i0 + tid < n0) ? mu / r : 0.0f;
+    }
+    {
+      float rd = wsum[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) rd = rd + wsum[q];
+      rd = fma_rn(Pdd, bdust, rd);
+      ad = mu_d / rd;
+    }
+    __syncthreads();                      // avec written
+    RS_STAMP(2);
+    // ---------------- column pass: partial sums over the own 32 rows, all in registers
+    float creg0 = 0.0f, creg1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < RS_ROWS / 4; ++q) {
+      const f32x4 x = *(const f32x4 *)(avec + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        creg0 = fma_rn(x[e], P0[4 * q + e], creg0);
+        creg1 = fma_rn(x[e], P1[4 * q + e], creg1);
+      }
+    }
+    if (!ok0) creg0 = 0.0f;
+    if (!ok1) creg1 = 0.0f;
+    float cdust = 0.0f;
+    if (wv == dust_wave) {                // the wave of the dustbin slot's owner (uniform branch)
+#pragma unroll
+      for (int q = 0; q < RS_ROWS / 4; ++q) {
+        const f32x4 x = *(const f32x4 *)(avec + 4 * q), y = *(const f32x4 *)(pcvec + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cdust = fma_rn(x[e], y[e], cdust);
+      }
+    }
+    // ---------------- all-reduce of the 1025 column sums over the 32 workgroups of the pair (layout as above)
+    rs_store(xin + ((size_t)((c0 >> 5) * RS_WG + w) * 32 + (c0 & 31)), tag, dust0 ? cdust : creg0, near);
+    rs_store(xin + ((size_t)((c1 >> 5) * RS_WG + w) * 32 + (c1 & 31)), tag, dust1 ? cdust : creg1, near);
+    if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, near);
+    RS_STAMP(3);
+    if (wv == 0) {
+      bool alive = true;
+      {
+        float x = 0.0f;
+        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err);
+        x = x + __shfl_xor(x, 32, 64);
+        if (alive && lane < 32) rs_store(xbc + 32 * w + lane, tag, x, near);
+        if (alive && w == 31) {
+          float y = 0.0f;
+          alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RS_WG, tag, y, nullptr, lane, a.err);
+          const float ys = half_sum32(lane < 32 ? y : 0.0f);
+          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, near);
+        }
+      }
+      RS_STAMP(4);
+      if (alive) {
+        float unused = 0.0f;
+        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err);
+      }
+      if (!alive && lane == 0) misc[1] = 1.0f;
+      RS_STAMP(5);
+    }
+    __syncthreads();
+    RS_STAMP(6);
+    if (misc[1] != 0.0f) return;
+    const float csum0 = csumv[c0], csum1 = csumv[c1], csum2 = csumv[1024];
+    // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
+    b0 = ok0 ? nu / fma_rn(ad, pd0, csum0) : 0.0f;
+    b1 = ok1 ? nu / fma_rn(ad, pd1, csum1) : 0.0f;
+    if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, (n1 < RS_NP) ? (dust0 ? csum0 : csum1) : csum2);
+    RS_STAMP(7);
+    // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
+    if (k == next_absorb && k < a.iters) {
+      next_absorb *= 2;
+      __syncthreads();                    // misc[0] written
+      bdust = misc[0];
+      if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
+      u0d = u0d + (double)__logf(ad);
+      if (ok0) v00 = v00 + (double)__logf(b0);
+      if (ok1) v01 = v01 + (double)__logf(b1);
+      v0d = v0d + (double)__logf(bdust);
+      absorb();
+    }
+  }
+  // ---------------- u = u0 + log a, v = v0 + log b
+  __syncthreads();
+  bdust = misc[0];
+  if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
+  if (w == 0) {
+    if (ok0) a.v[(size_t)p * RS_LDC + c0] = (float)(v00 + (double)__logf(b0));
+    if (ok1) a.v[(size_t)p * RS_LDC + c1] = (float)(v01 + (double)__logf(b1));
+    if (tid == 0) {
+      a.u[(size_t)p * RS_LDC + n0] = (float)(u0d + (double)__logf(ad));
+      a.v[(size_t)p * RS_LDC + n1] = (float)(v0d + (double)__logf(bdust));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Host side.  Two resident launches must never be in flight together (each needs every workgroup of
 // its grid on a CU of its own before any of them can finish): launches of one process are chained on a
 // per-device event.  Launches from another process are not seen here; the bounded spins turn that
@@ -445,8 +740,18 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // chip (4 pairs on an MI355X): the iterations are latency-bound (an exchange per iteration), so a second launch for
   // the other pairs costs little, and the free half keeps the MFMA kernels of the other streams running
   // (measured, 8 pairs, 3-stream pipeline: 8 per launch 1523 frames/s, 4 per launch 1697).  URF_SINKHORN_GROUP overrides.
+  // URF_SINKHORN_REGS: 1 (default) = the register-resident kernel at 168 VGPRs, every pair in ONE launch unless
+  // URF_SINKHORN_GROUP says otherwise; 2 = the same at 128 VGPRs (spills in the loop: slower); 0 = the LDS-resident kernel,
+  // half the chip per launch.  Measured, 8 pairs, 100 iterations: 0.49 / 0.70 / 1.24 ms serialised and 1895 / 1820 / 1780
+  // frames/s in the 3-stream pipeline
+  static int regs = -1;
+  if (regs < 0) { const char *e = getenv("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 1; if (regs < 0 || regs > 2) regs = 1; }
   int group = d.cus / RS_WG;
-  {
+  if (regs) {
+    const char *e = getenv("URF_SINKHORN_GROUP");
+    const int want = e ? atoi(e) : 0;
+    if (want >= 1 && want < group) group = want;
+  } else {
     static int knob = -1;
     if (knob < 0) { const char *e = getenv("URF_SINKHORN_GROUP"); knob = e ? atoi(e) : 0; }
     const int want = knob >= 1 ? knob : (group >= 2 ? group / 2 : group);
@@ -467,7 +772,9 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     }
     a.stamps = g_rs_stamps;
     URF_HIP(hipStreamWaitEvent(st, d.last, 0));
-    hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
+    if (regs == 2) hipLaunchKernelGGL(sinkhorn_regs_kernel<4>, dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
+    else if (regs) hipLaunchKernelGGL(sinkhorn_regs_kernel<3>, dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
+    else hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
   }
