@@ -13,6 +13,7 @@ namespace urf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CTH = 8, CTW = 16, CPH = 10, CPW = 18;
 constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-free ds_read_b128
@@ -94,19 +95,35 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
         in_l[p * CS + c] = (_Float16)(v - (float)hi);
       }
     } else {
-      // stage the input tile chunk: 2 planes x 180 pixels x 8 pieces
-      for (int i = tid; i < 2 * CPH * CPW * 8; i += 256) {
-        const int plane = i / (CPH * CPW * 8);
-        const int rem = i - plane * (CPH * CPW * 8);
-        const int p = rem >> 3, j = rem & 7;
-        const int yy = y0 - 1 + p / CPW, xx = x0 - 1 + p % CPW;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          const _Float16 *src = (plane ? a.xl : a.xh) + (size_t)b * a.H * a.W * a.Cin +
-                                ((size_t)yy * a.W + xx) * a.Cin + ch * 64 + 8 * j;
-          v = *(const f16x8 *)src;
+      // stage the input tile chunk: 2 planes x 180 pixels x 8 pieces = 2880 16-byte pieces, 12 per thread.  The loads of a
+      // plane are ALL issued before its first LDS write, from clamped (always valid) addresses with the zero padding applied afterwards:
+      // as a loop with the bounds test around the load, every piece was a basic block of its own -- load, full wait,
+      // write -- i.e. twelve dependent memory round trips per chunk in front of 4 us of MFMAs
+      // One batch of six per plane (twelve pieces in flight would not fit the 128-VGPR budget of this kernel, see above).
+      // The planes are read through buffer resources: a 32-bit offset per piece instead of a 64-bit address.
+      constexpr int PPP = CPH * CPW * 8, NB = (PPP + 255) / 256;      // pieces per plane (1440), loads per thread and plane
+      const unsigned plane_bytes = (unsigned)((size_t)gridDim.z * a.H * a.W * a.Cin * sizeof(_Float16));
+      const unsigned img_off = (unsigned)((size_t)b * a.H * a.W * a.Cin * sizeof(_Float16)) + (unsigned)(ch * 64 * sizeof(_Float16));
+#pragma unroll
+      for (int plane = 0; plane < 2; ++plane) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(plane ? a.xl : a.xh), 0, plane_bytes, 0x00020000);
+        u32x4 sv[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int i = tid + 256 * u < PPP ? tid + 256 * u : PPP - 1;
+          const int p = i >> 3, j = i & 7;
+          const int yy = y0 - 1 + p / CPW, xx = x0 - 1 + p % CPW;
+          const bool inb = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+          const int yc = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= a.W ? a.W - 1 : xx);
+          const unsigned off = (unsigned)(((yc * a.W + xc) * a.Cin + 8 * j) * (int)sizeof(_Float16));
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, img_off, 0);
+          sv[u] = inb ? v : u32x4{0u, 0u, 0u, 0u};
         }
-        *(f16x8 *)((plane ? in_l : in_h) + p * CS + 8 * j) = v;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int i = tid + 256 * u;
+          if (i < PPP) *(u32x4 *)((plane ? in_l : in_h) + (i >> 3) * CS + 8 * (i & 7)) = sv[u];
+        }
       }
     }
     for (int tap = 0; tap < 9; ++tap) {
