@@ -187,6 +187,40 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
       const int vec_per_pix = kc >> 2;
       const int vsh9 = 31 - __builtin_clz(vec_per_pix);
       const int total = PH * PW * vec_per_pix;
+      if (kc == 64) {
+        // every chunk of the SuperPoint convolutions: 180 pixels x 16 float4 = 2880 pieces, 12 per thread (the last one
+        // partial), in two batches of six with ALL loads of a batch in flight before its first LDS write -- from clamped,
+        // always valid offsets, the zero padding applied afterwards.  The generic loop below is load, full wait, write per
+        // piece: twelve dependent memory round trips per chunk.
+        constexpr int NPIECE = PH * PW * 16, NST = (NPIECE + 255) / 256, NB = NST % 6 == 0 ? 6 : (NST % 4 == 0 ? 4 : 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((const float *)a.in + (size_t)b * a.in_bstride), 0, (unsigned)((size_t)a.H * a.W * a.in_ld * sizeof(float)), 0x00020000);
+        const unsigned coff = (unsigned)((a.in_coff + c0) * (int)sizeof(float));
+#pragma unroll
+        for (int u0 = 0; u0 < NST; u0 += NB) {
+          f32x4 sv[NB];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * (u0 + u) < NPIECE ? tid + 256 * (u0 + u) : NPIECE - 1;
+            const int p = i >> 4, j = i & 15;
+            const int yy = y0 - 1 + p / PW, xx = x0 - 1 + p % PW;
+            const bool inb = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const int yc = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= a.W ? a.W - 1 : xx);
+            const unsigned off = (unsigned)(((yc * a.W + xc) * a.in_ld + 4 * j) * (int)sizeof(float));
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, coff, 0));
+            sv[u] = inb ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * (u0 + u);
+            if (i < NPIECE) {
+              float *dst = in_tile + (i >> 4) * IN_STRIDE + 4 * (i & 15);  // 8-byte aligned
+              *(float2 *)dst = make_float2(sv[u][0], sv[u][1]);
+              *(float2 *)(dst + 2) = make_float2(sv[u][2], sv[u][3]);
+            }
+          }
+        }
+      } else
       for (int i = tid; i < total; i += 256) {
         const int p = i >> vsh9, j = i & (vec_per_pix - 1);
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
