@@ -213,6 +213,39 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][N
   for (int ch = 0; ch < 8; ++ch) {
     if (ch < nrounds) {
       if (ch + 1 < nrounds) issue(vb, ch + 1);
+      if (ch * 64 + 64 <= nsl) {
+        // all 64 keys of the chunk valid (every chunk but the last): the V^T fragments of step s + 1 are read from LDS
+        // before the MFMAs of step s and pinned there (sched_barrier) -- left alone, the scheduler reads each fragment
+        // into the registers the previous MFMAs just released and every pair of MFMAs waits out an LDS round trip.
+        // Same operations in the same order as the generic path below.
+        const float *vbase = kv[ch & 1][kh] + (4 * g) * VSTR + px;
+        float va[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) va[0][dt] = vbase[dt * 16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int kt = s >> 2, r = s & 3, T = ch * 4 + kt;
+          if (r == 0 && T + 1 < 32 && (T + 1) * 16 < nsl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float p = exp_c_nonpos(sreg[T + 1 < 32 ? T + 1 : 31][q] - m);
+              sreg[T + 1 < 32 ? T + 1 : 31][q] = p;
+              part = part + p;
+            }
+          }
+          if (s + 1 < 16) {
+            const float *nb = vbase + (((s + 1) >> 2) * 16 + ((s + 1) & 3)) * VSTR;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) va[(s + 1) & 1][dt] = nb[dt * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const float pb = sreg[T][r];
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s & 1][dt], pb, oacc[dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const int T = ch * 4 + kt;
