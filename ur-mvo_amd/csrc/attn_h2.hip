@@ -47,6 +47,13 @@ constexpr int VS = 72;       // V^T rows: 144 B, conflict-free ds_read_b64
 // QT query tiles (16 queries each) per wave, NW waves per workgroup: every K / V^T fragment read from
 // LDS feeds QT MFMAs instead of one.
 // At most 192 VGPRs: see h2conv_kernel (co-residency with SuperPoint's convolutions in the pipeline)
+#ifdef URF_ATTN_STAMPS   // diagnostic build only (make ATTN_STAMPS=1; tools/gpu_attn_stamps.py): s_memtime at the phase boundaries
+__device__ long long g_attn_stamps[2][64][8];
+#define AT_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && ch < 64) g_attn_stamps[wave >> 2][ch][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AT_STAMP(i) do { } while (0)
+#endif
+
 template <int QT, int NW>
 __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, const _Float16 *qkl,
                                                           const _Float16 *vth, const _Float16 *vtl, const int *counts,
@@ -161,6 +168,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
   auto chunk = [&](int ch, auto mask_tag, auto next_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = ch & 1;
+    AT_STAMP(0);
     if (ch + 1 < nchunk) issue(ch + 1, next_tag);
     // Fragment reads run AHEAD of the MFMAs that use them (K: one 16-key tile, V^T: two 16-d tiles) and are pinned there
     // with sched_barrier: left to itself the scheduler reloads into the registers the previous MFMAs just read (shortest
@@ -218,6 +226,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 #pragma unroll
     for (int i = 0; i + 1 < VR; ++i) load_v(i);
     __builtin_amdgcn_sched_barrier(0);
+    AT_STAMP(1);
     // ---- online softmax update (per query = per px; the 4 lanes g share it)
     float mn[QT];
 #pragma unroll
@@ -238,6 +247,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[t][dt][r] = oacc[t][dt][r] * alpha;
     }
+    AT_STAMP(2);
     // ---- O^T += V^T P^T, 32 keys per k-step
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
@@ -280,8 +290,11 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    AT_STAMP(3);
     if (ch + 1 < nchunk) commit(buf ^ 1);
+    AT_STAMP(4);
     __syncthreads();
+    AT_STAMP(5);
   };
   const int nfull = ns >> 6;                          // chunks whose 64 keys are all valid
   for (int ch = 0; ch + 1 < nfull; ++ch) chunk(ch, std::false_type{}, std::false_type{});
@@ -334,3 +347,9 @@ int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth
 }
 
 }  // namespace urf
+
+#ifdef URF_ATTN_STAMPS
+extern "C" int urf_probe_attn_stamps(long long *out) {   // [2 wave groups][64 chunks][8 stamps]
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_attn_stamps), sizeof(long long) * 2 * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
