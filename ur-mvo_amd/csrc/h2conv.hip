@@ -8,6 +8,8 @@
 // bytes as fp32.  Opt-in precision mode.
 #include "h2.h"
 
+#include <type_traits>
+
 namespace urf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -17,6 +19,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CTH = 8, CTW = 16, CPH = 10, CPW = 18;
 constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-free ds_read_b128
+
+#ifdef URF_CONV_STAMPS   // diagnostic build only (make EXTRA=-DURF_CONV_STAMPS; tools/gpu_conv_stamps.py)
+__device__ long long g_conv_stamps[8];
+#define CV_STAMP(i) do { if (FUSE1A && blockIdx.x == 700 && blockIdx.z == 0 && tid == 0) g_conv_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CV_STAMP(i) do { } while (0)
+#endif
 
 template <bool POOL, bool FUSE1A, bool OUTF32>
 // launch bound of 4 workgroups per CU = a budget of 128 VGPRs (LDS keeps the real number at 2); 128 VGPRs and 78 KB of LDS on purpose: one wave per SIMD of this kernel then fits beside the two 192-register waves per
@@ -63,6 +72,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
   };
 
   const int nchunks = FUSE1A ? 1 : (a.Cin >> 6);
+  CV_STAMP(0);
   issue_w(0, 0);
   for (int ch = 0; ch < nchunks; ++ch) {
     if (FUSE1A) {
@@ -80,20 +90,45 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
       for (int t = 0; t < 9; ++t) w1[t] = a.w1a[t * 64 + c];
       const float b1 = a.b1a[c];
       __syncthreads();
-      for (int p = tid >> 6; p < CPH * CPW; p += 4) {
-        const int py = p / CPW, pxx = p % CPW;
-        const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
-        float v = 0.0f;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          v = b1;
+      CV_STAMP(1);
+      // Work item = half a row of the 10 x 18 tile (9 pixels) for the thread's channel: the 3 x 12 patch values it needs come
+      // in with nine independent 16-byte broadcast reads, then 81 independent-per-pixel fma chains run from registers.  (As
+      // a loop over single pixels -- nine dependent 4-byte reads in front of every chain, a bounds branch per pixel -- this
+      // prologue took 18.5 k cycles per workgroup against 14.8 k for the 432 MFMAs per wave that follow.)  Same chain per
+      // pixel as before: bias, then the taps in raster order.
+      auto half_rows = [&](auto hx_tag) {
+        constexpr int hx = decltype(hx_tag)::value;     // which half of the row: the same for every item of a wave (wave & 1)
+#pragma unroll 1
+        for (int it = tid >> 6; it < 2 * CPH; it += 4) {
+          const int py = it >> 1;
+          f32x4 r[3][3];                                // patch rows py .. py + 2, columns 8 hx .. 8 hx + 11
 #pragma unroll
-          for (int t = 0; t < 9; ++t) v = __builtin_fmaf(patch[(py + t / 3) * 20 + pxx + t % 3], w1[t], v);
-          v = v > 0.0f ? v : 0.0f;
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[dy][q] = *(const f32x4 *)(patch + (py + dy) * 20 + 8 * hx + 4 * q);
+          const int yy = y0 - 1 + py;
+          const bool rowin = yy >= 0 && yy < a.H;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const int pxx = 9 * hx + k;                 // column in the tile; patch column pxx + dx = 8 hx + (k + hx + dx)
+            float v = b1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              const int j = k + hx + t % 3;
+              v = __builtin_fmaf(r[t / 3][j >> 2][j & 3], w1[t], v);
+            }
+            v = v > 0.0f ? v : 0.0f;
+            const int xx = x0 - 1 + pxx;
+            if (!(rowin && xx >= 0 && xx < a.W)) v = 0.0f;
+            const _Float16 hi = (_Float16)v;
+            const int p = py * CPW + pxx;
+            in_h[p * CS + c] = hi;
+            in_l[p * CS + c] = (_Float16)(v - (float)hi);
+          }
         }
-        const _Float16 hi = (_Float16)v;
-        in_h[p * CS + c] = hi;
-        in_l[p * CS + c] = (_Float16)(v - (float)hi);
-      }
+      };
+      if ((tid >> 6) & 1) half_rows(std::integral_constant<int, 1>{});
+      else half_rows(std::integral_constant<int, 0>{});
     } else {
       // stage the input tile chunk: 2 planes x 180 pixels x 8 pieces = 2880 16-byte pieces, 12 per thread.  The loads of a
       // plane are ALL issued before its first LDS write, from clamped (always valid) addresses with the zero padding applied afterwards:
@@ -126,6 +161,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
         }
       }
     }
+    CV_STAMP(2);
     for (int tap = 0; tap < 9; ++tap) {
       commit_w();
       __syncthreads();
@@ -163,6 +199,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
     }
   }
 
+  CV_STAMP(3);
   // ---- epilogue
   auto store = [&](size_t off, f32x4 v) {
     if (OUTF32) {
@@ -204,6 +241,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
       }
     }
   }
+  CV_STAMP(4);
 }
 
 int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int batch, hipStream_t st) {
@@ -228,3 +266,9 @@ int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int 
 }
 
 }  // namespace urf
+
+#ifdef URF_CONV_STAMPS
+extern "C" int urf_probe_conv_stamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_conv_stamps), sizeof(long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
