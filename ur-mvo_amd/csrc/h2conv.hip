@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
             }
             v = v > 0.0f ? v : 0.0f;
             const int xx = x0 - 1 + pxx;
-            if (!(rowin && xx >= 0 && xx < a.W)) v = 0.0f;
+            // zero padding by a 0 / 1 factor (v >= 0 here, so the product is v or +0 exactly): as a test it is wave-uniform and
+            // comes back as a branch per pixel, which keeps the nine chains of a half row from interleaving
+            v = v * ((rowin && xx >= 0 && xx < a.W) ? 1.0f : 0.0f);
             const _Float16 hi = (_Float16)v;
             const int p = py * CPW + pxx;
             in_h[p * CS + c] = hi;
