@@ -84,53 +84,61 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = a.lut[img[(size_t)yy * a.W + xx]];
         patch[i] = v;
       }
-      const int c = tid & 63;
-      float w1[9];
+      // conv1a on the fp32 matrix core: D[cout][pixel] = bias + sum_t W[cout][t] X[t][pixel] with the nine taps (padded with
+      // three zero taps) as the K dimension of v_mfma_f32_16x16x4_f32, whose accumulation IS the ordered chain
+      // acc = fma(a_k, b_k, acc), k ascending (tests: test_mfma_f32_is_an_ordered_fma_chain) -- the same bits as the VALU
+      // chain "bias, then the taps in raster order" this replaces (a zero tap adds +0; relu maps -0 and +0 alike).
+      // 180 pixels = 12 groups of 16, four 16-cout tiles: 36 MFMAs per wave instead of 405 dependent-chain FMAs per thread
+      // (the VALU form took 18.5 k cycles per workgroup, 9.3 k after register blocking, against 14.5 k for the 432 MFMAs per
+      // wave of conv1b).  A lane's result is 4 consecutive couts of one pixel: 8-byte LDS stores.
+      f32x4 bias4[4];
+      float wa[4][3];                                  // A fragments: W[16 mt + px][4 ks + g]
 #pragma unroll
-      for (int t = 0; t < 9; ++t) w1[t] = a.w1a[t * 64 + c];
-      const float b1 = a.b1a[c];
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[mt][r] = a.b1a[16 * mt + 4 * g + r];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int t = 4 * ks + g;
+          wa[mt][ks] = t < 9 ? a.w1a[t * 64 + 16 * mt + px] : 0.0f;
+        }
+      }
       __syncthreads();
       CV_STAMP(1);
-      // Work item = half a row of the 10 x 18 tile (9 pixels) for the thread's channel: the 3 x 12 patch values it needs come
-      // in with nine independent 16-byte broadcast reads, then 81 independent-per-pixel fma chains run from registers.  (As
-      // a loop over single pixels -- nine dependent 4-byte reads in front of every chain, a bounds branch per pixel -- this
-      // prologue took 18.5 k cycles per workgroup against 14.8 k for the 432 MFMAs per wave that follow.)  Same chain per
-      // pixel as before: bias, then the taps in raster order.
-      auto half_rows = [&](auto hx_tag) {
-        constexpr int hx = decltype(hx_tag)::value;     // which half of the row: the same for every item of a wave (wave & 1)
-#pragma unroll 1
-        for (int it = tid >> 6; it < 2 * CPH; it += 4) {
-          const int py = it >> 1;
-          f32x4 r[3][3];                                // patch rows py .. py + 2, columns 8 hx .. 8 hx + 11
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
+      for (int gi = 0; gi < 3; ++gi) {
+        const int p = (wave + 4 * gi) * 16 + px;         // this lane's pixel of the group (>= 180: no pixel)
+        const int pc = p < CPH * CPW ? p : CPH * CPW - 1;
+        const int py = pc / CPW, pxx = pc % CPW;
+        float xb[3];                                     // B fragments: X[4 ks + g][pixel] = patch[(py + t / 3) * 20 + pxx + t % 3]
 #pragma unroll
-            for (int q = 0; q < 3; ++q) r[dy][q] = *(const f32x4 *)(patch + (py + dy) * 20 + 8 * hx + 4 * q);
-          const int yy = y0 - 1 + py;
-          const bool rowin = yy >= 0 && yy < a.H;
+        for (int ks = 0; ks < 3; ++ks) {
+          const int t = 4 * ks + g;
+          const int tt = t < 9 ? t : 8;
+          const float x = patch[(py + tt / 3) * 20 + pxx + tt % 3];
+          xb[ks] = t < 9 ? x : 0.0f;
+        }
+        const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+        const bool inb = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const int pxx = 9 * hx + k;                 // column in the tile; patch column pxx + dx = 8 hx + (k + hx + dx)
-            float v = b1;
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 d = bias4[mt];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-              const int j = k + hx + t % 3;
-              v = __builtin_fmaf(r[t / 3][j >> 2][j & 3], w1[t], v);
-            }
-            v = v > 0.0f ? v : 0.0f;
-            const int xx = x0 - 1 + pxx;
-            // zero padding by a 0 / 1 factor (v >= 0 here, so the product is v or +0 exactly): as a test it is wave-uniform and
-            // comes back as a branch per pixel, which keeps the nine chains of a half row from interleaving
-            v = v * ((rowin && xx >= 0 && xx < a.W) ? 1.0f : 0.0f);
-            const _Float16 hi = (_Float16)v;
-            const int p = py * CPW + pxx;
-            in_h[p * CS + c] = hi;
-            in_l[p * CS + c] = (_Float16)(v - (float)hi);
+          for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][ks], xb[ks], d, 0, 0, 0);
+          f16x4 h, l;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = d[r] > 0.0f ? d[r] : 0.0f;
+            v = inb ? v : 0.0f;
+            h[r] = (_Float16)v;
+            l[r] = (_Float16)(v - (float)h[r]);
+          }
+          if (p < CPH * CPW) {
+            *(f16x4 *)(in_h + p * CS + 16 * mt + 4 * g) = h;
+            *(f16x4 *)(in_l + p * CS + 16 * mt + 4 * g) = l;
           }
         }
-      };
-      if ((tid >> 6) & 1) half_rows(std::integral_constant<int, 1>{});
-      else half_rows(std::integral_constant<int, 0>{});
+      }
     } else {
       // stage the input tile chunk: 2 planes x 180 pixels x 8 pieces = 2880 16-byte pieces, 12 per thread.  The loads of a
       // plane are ALL issued before its first LDS write, from clamped (always valid) addresses with the zero padding applied afterwards:
