@@ -163,23 +163,54 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = a.lut[img[(size_t)yy * a.W + xx]];
         patch[i] = v;
       }
-      const int c = tid & 63;
-      float w1[9];
+      // conv1a on the fp32 matrix core (see h2conv.hip): the nine taps, padded with three zero taps, are the K dimension
+      // of v_mfma_f32_16x16x4_f32, whose accumulation is the ordered chain acc = fma(a_k, b_k, acc) -- the same bits as the
+      // VALU chain "bias, then the taps in raster order" of the oracle (a zero tap adds +0; relu maps -0 and +0 alike).
+      // 180 pixels = 12 groups of 16 x four 16-cout tiles: 36 MFMAs per wave instead of 405 chained FMAs per thread.
+      f32x4 bias4[4];
+      float wa[4][3];                                  // A fragments: W[16 mt + px][4 ks + g]
 #pragma unroll
-      for (int t = 0; t < 9; ++t) w1[t] = a.w1a[t * 64 + c];
-      const float b1 = a.b1a[c];
-      __syncthreads();
-      for (int p = tid >> 6; p < PH * PW; p += 4) {
-        const int py = p / PW, pxx = p % PW;
-        const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
-        float v = 0.0f;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          v = b1;
+      for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t) v = __builtin_fmaf(patch[(py + t / 3) * 20 + pxx + t % 3], w1[t], v);
-          v = v > 0.0f ? v : 0.0f;
+        for (int r = 0; r < 4; ++r) bias4[mt][r] = a.b1a[16 * mt + 4 * g + r];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int t = 4 * ks + g;
+          wa[mt][ks] = t < 9 ? a.w1a[t * 64 + 16 * mt + px] : 0.0f;
         }
-        in_tile[p * IN_STRIDE + c] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        const int p = (wave + 4 * gi) * 16 + px;         // this lane's pixel of the group (>= PH * PW: no pixel)
+        const int pc = p < PH * PW ? p : PH * PW - 1;
+        const int py = pc / PW, pxx = pc % PW;
+        float xb[3];                                     // B fragments: X[4 ks + g][pixel]
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int t = 4 * ks + g;
+          const int tt = t < 9 ? t : 8;
+          const float x = patch[(py + tt / 3) * 20 + pxx + tt % 3];
+          xb[ks] = t < 9 ? x : 0.0f;
+        }
+        const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+        const bool inb = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 d = bias4[mt];
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][ks], xb[ks], d, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = d[r] > 0.0f ? d[r] : 0.0f;
+            d[r] = inb ? v : 0.0f;
+          }
+          if (p < PH * PW) {
+            float *dst = in_tile + p * IN_STRIDE + 16 * mt + 4 * g;   // 8-byte aligned
+            *(float2 *)dst = make_float2(d[0], d[1]);
+            *(float2 *)(dst + 2) = make_float2(d[2], d[3]);
+          }
+        }
       }
     } else if (TAPS == 9) {
       // ---- stage the input tile chunk: each pixel's kc channels are contiguous
