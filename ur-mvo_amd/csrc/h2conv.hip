@@ -22,7 +22,10 @@ constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-f
 
 #ifdef URF_CONV_STAMPS   // diagnostic build only (make EXTRA=-DURF_CONV_STAMPS; tools/gpu_conv_stamps.py)
 __device__ long long g_conv_stamps[8];
-#define CV_STAMP(i) do { if (FUSE1A && blockIdx.x == 700 && blockIdx.z == 0 && tid == 0) g_conv_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#ifndef URF_CONV_STAMP_FUSED
+#define URF_CONV_STAMP_FUSED 1   // 0: stamp the plain (no pool, no conv1a) variant instead, workgroup 100 of its last large launch
+#endif
+#define CV_STAMP(i) do { if (FUSE1A == (URF_CONV_STAMP_FUSED != 0) && !POOL == !URF_CONV_STAMP_FUSED && blockIdx.x == (URF_CONV_STAMP_FUSED ? 700 : 100) && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) g_conv_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CV_STAMP(i) do { } while (0)
 #endif
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
         }
       }
     } else {
+      CV_STAMP(1);
       // stage the input tile chunk: 2 planes x 180 pixels x 8 pieces = 2880 16-byte pieces, 12 per thread.  The loads of a
       // plane are ALL issued before its first LDS write, from clamped (always valid) addresses with the zero padding applied afterwards:
       // as a loop with the bounds test around the load, every piece was a basic block of its own -- load, full wait,
@@ -164,6 +168,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
           const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, img_off, 0);
           sv[u] = inb ? v : u32x4{0u, 0u, 0u, 0u};
         }
+        __builtin_amdgcn_sched_barrier(0);   // the sixth load too: its write is conditional, and the load would follow it into that block
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int i = tid + 256 * u;
