@@ -123,6 +123,15 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr int GP = 128 * BK;   // halfs per plane per stage (128 rows x 32)
 
+#ifdef URF_GEMM_STAMPS   // diagnostic build only (make EXTRA=-DURF_GEMM_STAMPS; tools/gpu_gemm_stamps.py)
+__device__ long long g_gemm_stamps[2][8];
+#define GM_STAMP(i) do { if (blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 5)) g_gemm_stamps[wave != 0][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define GM_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#else
+#define GM_STAMP(i) do { } while (0)
+#define GM_NOW() 0ll
+#endif
+
 template <bool TOUT>
 __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,6 +140,7 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
   const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * 128;
   if (a.counts && row0 >= a.counts[b]) return;
   const int wc = wave >> 2, wr = wave & 3;
+  GM_STAMP(0);
   f32x4 acc[4][2];
   h2_init_acc<TOUT>(a, acc, cout_base, wc, px, g);
 
@@ -162,9 +172,16 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
   const int boff = (wr * 32 + px) * BK + swz;   // + r*16*BK
   const int nchunks = (a.xflags & 4) ? 1 : a.Cin / BK;
   issue(0, 0);
+  [[maybe_unused]] long long t_wait = 0, t_sync = 0;   // diagnostic build: cycles spent waiting for the DMA / at the barrier
+  GM_STAMP(1);
   for (int ch = 0; ch < nchunks; ++ch) {
+    const long long w0 = GM_NOW();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk ch has landed
+    const long long w1 = GM_NOW();
     __syncthreads();
+    const long long w2 = GM_NOW();
+    t_wait += w1 - w0; t_sync += w2 - w1;
+    if (ch == 0) GM_STAMP(2);
     if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
     const _Float16 *st = hsm + (ch & 1) * 4 * GP;
     f16x8 ah[4], al[4], bh[2], bl[2];
@@ -197,7 +214,12 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
         }
       }
   }
+  GM_STAMP(3);
+#ifdef URF_GEMM_STAMPS
+  if (blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 5)) { g_gemm_stamps[wave != 0][5] = t_wait; g_gemm_stamps[wave != 0][6] = t_sync; }
+#endif
   h2_epilogue<TOUT>(a, acc, b, cout_base, row0, wc, wr, px, g);
+  GM_STAMP(4);
 }
 
 // MODE 0: token-major outputs, 1: transposed outputs, 2: both in one launch (uniform branch per workgroup)
@@ -440,3 +462,9 @@ extern "C" int urf_probe_h2gemm(const float *X, const float *W, const float *bia
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return rc;
 }
+
+#ifdef URF_GEMM_STAMPS
+extern "C" int urf_probe_gemm_stamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_gemm_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
