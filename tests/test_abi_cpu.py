@@ -219,7 +219,7 @@ def test_register_and_lds_budgets_keep_the_pipeline_coresident(tmp_path):
         for m in re.finditer(r"^(_ZN3urf\w+):.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; LDSByteSize: (\d+)", text, re.S | re.M):
             usage[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
     attn = [v for k, v in usage.items() if "attn_h2_kernelILi2ELi8E" in k]
-    convs = [v for k, v in usage.items() if "h2conv_kernel" in k and k.endswith("ELb1EEEvNS_10H2ConvArgsE")]   # the default (LDS-DMA) variants
+    convs = [v for k, v in usage.items() if "h2conv_kernel" in k]
     assert len(attn) == 1 and len(convs) == 4, usage
     up8 = lambda n: (n + 7) // 8 * 8                   # VGPR allocation granule
     for vg, scratch, _ in convs:

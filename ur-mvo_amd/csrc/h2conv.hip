@@ -19,37 +19,35 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CTH = 8, CTW = 16, CPH = 10, CPW = 18;
-constexpr int CS = 80;   // halfs per LDS row (64 channels + 16 pad): conflict-free ds_read_b128
 
 #ifdef URF_CONV_STAMPS   // diagnostic build only (make EXTRA=-DURF_CONV_STAMPS; tools/gpu_conv_stamps.py)
 __device__ long long g_conv_stamps[8];
 #ifndef URF_CONV_STAMP_FUSED
 #define URF_CONV_STAMP_FUSED 1   // 0: stamp the plain (no pool, no conv1a) variant instead, workgroup 100 of its last large launch
 #endif
-#define CV_STAMP(i) do { if (DMA && FUSE1A == (URF_CONV_STAMP_FUSED != 0) && !POOL == !URF_CONV_STAMP_FUSED && blockIdx.x == (URF_CONV_STAMP_FUSED ? 700 : 100) && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) g_conv_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define CV_STAMP(i) do { if (FUSE1A == (URF_CONV_STAMP_FUSED != 0) && !POOL == !URF_CONV_STAMP_FUSED && blockIdx.x == (URF_CONV_STAMP_FUSED ? 700 : 100) && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) g_conv_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CV_STAMP(i) do { } while (0)
 #endif
 
-template <bool POOL, bool FUSE1A, bool OUTF32, bool DMA>
+template <bool POOL, bool FUSE1A, bool OUTF32>
 // launch bound of 4 workgroups per CU = a budget of 128 VGPRs (LDS keeps the real number at 2); 128 VGPRs and 78 KB of LDS on purpose: one wave per SIMD of this kernel then fits beside the two 192-register waves per
 // SIMD (and the 78 KB) of attn_h2_kernel on the same CU -- in the three-stream pipeline SuperPoint's convolutions fill the
 // MFMA bubbles of the matcher's attention, worth more (5 %) than what either kernel gains alone from more registers
 __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
-  // DMA = false: padded rows (CS = 80 halfs), weights of a tap staged through registers, two barriers per tap.
-  // DMA = true:  unpadded 128-byte rows whose eight 16-byte slots are XOR-swizzled by (row >> 1) & 7 -- the sixteen
-  //   lanes of a fragment read (16 consecutive rows, one k-group) then hit 16 distinct (row parity, slot) pairs = all 64
-  //   banks once -- so that a tap's weights can arrive by LDS-DMA (global_load_lds_dwordx4: lane l -> byte 16 l of a
-  //   1-KiB piece = row l >> 3, slot l & 7; the permutation is applied to the SOURCE address) into the stage the
-  //   previous tap is not reading: no register round trip, ONE barrier per tap.
-  constexpr int RS = DMA ? 64 : CS;                              // halfs per LDS row
-  constexpr int WST = DMA ? 2 : 1;                               // weight stages
+  // LDS: unpadded 128-byte rows whose eight 16-byte slots are XOR-swizzled by (row >> 1) & 7 -- the sixteen lanes of a
+  // fragment read (16 consecutive rows, one k-group) then hit 16 distinct (row parity, slot) pairs = all 64 banks once -- so
+  // that a tap's weights can arrive by LDS-DMA (global_load_lds_dwordx4: lane l -> byte 16 l of a 1-KiB piece = row l >> 3,
+  // slot l & 7; the permutation is applied to the SOURCE address) into the stage the previous tap is not reading: no register
+  // round trip, ONE barrier per tap.  (Round 1 / early round 2: padded 160-byte rows, weights staged through registers, two
+  // barriers per tap.)
+  constexpr int RS = 64;                                         // halfs per LDS row
   extern __shared__ __attribute__((aligned(1024))) _Float16 csm[];
-  _Float16 *w_h = csm, *w_l = csm + 64 * RS;                      // [stage][hi | lo][64 cout][RS]; stage stride 2 * 64 * RS
-  _Float16 *in_h = csm + WST * 2 * 64 * RS, *in_l = in_h + CPH * CPW * RS;   // [180][RS] each
+  _Float16 *w_h = csm, *w_l = csm + 64 * RS;                      // [2 stages][hi | lo][64 cout][RS]; stage stride 2 * 64 * RS
+  _Float16 *in_h = csm + 2 * 2 * 64 * RS, *in_l = in_h + CPH * CPW * RS;     // [180][RS] each
   float *patch = (float *)(in_l + CPH * CPW * RS);                // FUSE1A: [12][20] f32
   // element offset of (row, k-group kg) inside a tile
-  auto slot = [&](int row, int kg) { return DMA ? row * RS + 8 * (kg ^ ((row >> 1) & 7)) : row * RS + 8 * kg; };
+  auto slot = [&](int row, int kg) { return row * RS + 8 * (kg ^ ((row >> 1) & 7)); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, cout_base = blockIdx.y * 64;
@@ -65,26 +63,7 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
     acc[m][0] = bv; acc[m][1] = bv;
   }
 
-  // weights of one (chunk, tap): 2 planes x 64 cout x 8 pieces = 1024 pieces / 256 threads = 4
-  f16x8 wpf[4];
-  auto issue_w = [&](int ch, int tap) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 256 * u;
-      const int plane = i >> 9, co = (i >> 3) & 63, j = i & 7;
-      const _Float16 *w = plane ? a.wl : a.wh;  // [tap][Cout][Cin]
-      wpf[u] = *(const f16x8 *)(w + ((size_t)tap * a.Cout + cout_base + co) * a.Cin + ch * 64 + 8 * j);
-    }
-  };
-  auto commit_w = [&]() {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 256 * u;
-      const int plane = i >> 9, co = (i >> 3) & 63, j = i & 7;
-      *(f16x8 *)((plane ? w_l : w_h) + co * CS + 8 * j) = wpf[u];
-    }
-  };
-  // DMA: 16 pieces of 1 KiB per (chunk, tap) = 2 planes x 8 blocks of 8 rows; wave w issues pieces 4 w .. 4 w + 3
+  // weights of one (chunk, tap): 16 pieces of 1 KiB = 2 planes x 8 blocks of 8 rows; wave w issues pieces 4 w .. 4 w + 3
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void gbl_void;
   auto dma_w = [&](int ch, int tap, int stage) {
@@ -100,10 +79,9 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
 
   const int nchunks = FUSE1A ? 1 : (a.Cin >> 6);
   CV_STAMP(0);
-  if (DMA) dma_w(0, 0, 0);
-  else issue_w(0, 0);
+  dma_w(0, 0, 0);
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (DMA && ch > 0) __syncthreads();   // one barrier per tap: slower waves may still read the input tile for the previous chunk's last tap
+    if (ch > 0) __syncthreads();   // one barrier per tap: slower waves may still read the input tile for the previous chunk's last tap
     if (FUSE1A) {
       // conv1a on the VALU in fp32 (exact chain), split on the way into the LDS tile
       const uint8_t *img = a.img + (size_t)b * a.H * a.W;
@@ -205,21 +183,13 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
     }
     CV_STAMP(2);
     for (int tap = 0; tap < 9; ++tap) {
-      if (DMA) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tap's weights have landed
-        __syncthreads();                                    // everybody's have, and everybody is done with the other stage
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tap's weights have landed
+      __syncthreads();                                    // everybody's have, and everybody is done with the other stage
+      {
         const int nt = tap + 1 < 9 ? tap + 1 : 0, nc = tap + 1 < 9 ? ch : ch + 1;
         if (nc < nchunks) dma_w(nc, nt, (ch * 9 + tap + 1) & 1);
-      } else {
-        commit_w();
-        __syncthreads();
-        if (tap + 1 < 9) issue_w(ch, tap + 1);
-        else if (ch + 1 < nchunks) issue_w(ch + 1, 0);
-        // keep the weight loads of the next tap HERE: left alone, the scheduler sinks them below most of this tap's MFMAs
-        // (shorter live ranges) and the commit at the top of the next tap then waits out their whole latency
-        __builtin_amdgcn_sched_barrier(0);
       }
-      const int wst = DMA ? ((ch * 9 + tap) & 1) * 2 * 64 * RS : 0;
+      const int wst = ((ch * 9 + tap) & 1) * 2 * 64 * RS;
       const int p0 = (2 * wave + tap / 3) * CPW + px + tap % 3, p1 = p0 + CPW;   // this lane's two pixels for this tap
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -244,7 +214,6 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
             acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
           }
       }
-      if (!DMA) __syncthreads();
     }
   }
 
@@ -295,36 +264,21 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
 
 int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 64) == 0 && (fuse1a || (a.Cin % 64) == 0), "h2conv: unsupported shape");
-  // URF_H2CONV_DMA=0: the register-staged weight path (padded LDS rows, two barriers per tap); 1 (default): weights by LDS-DMA
-  static int dma = -1;
-  if (dma < 0) { const char *e = getenv("URF_H2CONV_DMA"); dma = e ? (atoi(e) != 0) : 1; }
-  const size_t lds = dma ? sizeof(_Float16) * (2 * 2 * 64 * 64 + 2 * CPH * CPW * 64) + (fuse1a ? 12 * 20 * 4 : 0)
-                         : sizeof(_Float16) * (2 * CPH * CPW * CS + 2 * 64 * CS) + (fuse1a ? 12 * 20 * 4 : 0);
+  const size_t lds = sizeof(_Float16) * (2 * 2 * 64 * 64 + 2 * CPH * CPW * 64) + (fuse1a ? 12 * 20 * 4 : 0);
   static bool attr_done = false;
   if (!attr_done) {
     const int mx = 80 * 1024;
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     attr_done = true;
   }
   dim3 grid(((a.W + CTW - 1) / CTW) * ((a.H + CTH - 1) / CTH), a.Cout / 64, batch), block(256);
-  if (dma) {
-    if (fuse1a) hipLaunchKernelGGL((h2conv_kernel<true, true, false, true>), grid, block, lds, st, a);
-    else if (pool) hipLaunchKernelGGL((h2conv_kernel<true, false, false, true>), grid, block, lds, st, a);
-    else if (outf32) hipLaunchKernelGGL((h2conv_kernel<false, false, true, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((h2conv_kernel<false, false, false, true>), grid, block, lds, st, a);
-  } else {
-    if (fuse1a) hipLaunchKernelGGL((h2conv_kernel<true, true, false, false>), grid, block, lds, st, a);
-    else if (pool) hipLaunchKernelGGL((h2conv_kernel<true, false, false, false>), grid, block, lds, st, a);
-    else if (outf32) hipLaunchKernelGGL((h2conv_kernel<false, false, true, false>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((h2conv_kernel<false, false, false, false>), grid, block, lds, st, a);
-  }
+  if (fuse1a) hipLaunchKernelGGL((h2conv_kernel<true, true, false>), grid, block, lds, st, a);
+  else if (pool) hipLaunchKernelGGL((h2conv_kernel<true, false, false>), grid, block, lds, st, a);
+  else if (outf32) hipLaunchKernelGGL((h2conv_kernel<false, false, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((h2conv_kernel<false, false, false>), grid, block, lds, st, a);
   URF_HIP(hipGetLastError());
   return 0;
 }
