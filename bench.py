@@ -160,7 +160,7 @@ def main():
     async_exchange = exchange and not shared_gpu
 
     U = load_pkg()
-    F, synth, D = U.frontend, U.synth, U.dist
+    F, synth, D, P = U.frontend, U.synth, U.dist, U.pipeline
     spb = synth.pack_sp(synth.sp_weights(0))
     sgb = synth.pack_sg(synth.sg_weights(0))
     PREC = args.precision
@@ -181,176 +181,91 @@ def main():
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
     del stream
-    slot_floats = U._lib.lib().urf_slot_bytes() // 4
-    # feature slots of the last NB global batches (ring): matching batch b needs the
-    # last slot of batch b-1 while SuperPoint already fills the slots of batch b+1
-    ring = torch.zeros((NB, BATCH, slot_floats), dtype=torch.float32, device=dev)
-    gathered = [None] * NB
     torch.cuda.synchronize()
     F.set_profiling(True)
-    # SuperPoint and the matcher share ONE in-order HIP stream:
-    #   SP(b) -> match(b) -> SP(b+1) -> match(b+1) ...
-    # The host enqueues one step ahead and only waits (event) for the match lists
-    # it reads, so the GPU never idles and HIP-event stage times are not blurred by
-    # cross-stream contention.
-    # URF_BENCH_OVERLAP: 0 = one in-order stream; 1 = SP(b+1) beside Sinkhorn(b) (two streams);
-    # 2 (default) = three streams: two matchers alternate, so the cache-bandwidth-bound
-    # Sinkhorn of batch b runs beside the MFMA-bound GNN of batch b+1 and SuperPoint of b+2
+    # The step loop is ur-mvo_amd/pipeline.py (SlotRingPipeline; tests/test_gpu_fullsize.py runs the same object against the
+    # CPU oracle).  URF_BENCH_OVERLAP: 0 = SuperPoint and the matcher on ONE in-order stream; 1 = SP(b+1) beside Sinkhorn(b)
+    # (two streams); 2 (default) = three streams: two matchers alternate, so the Sinkhorn of batch b runs beside the
+    # MFMA-bound GNN of batch b+1 and SuperPoint of b+2.  The host enqueues one step ahead and only waits (event) for the
+    # match lists it reads.
     pms = [pm]
-    if OVERLAP == 0:
-        pm.share_stream(sp)
-    elif OVERLAP == 2:
-        for _ in range(MATCHERS - 1):
-            pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                                   device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS)
-            assert pm_b.build(sgb), U._lib.lib().urf_last_error()
-            pms.append(pm_b)
+    for _ in range(MATCHERS - 1):
+        pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
+                               device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS)
+        assert pm_b.build(sgb), U._lib.lib().urf_last_error()
+        pms.append(pm_b)
 
+    comm = None
     if async_exchange:
-        # the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI, not torch.distributed.  One communicator
-        # per stream that carries RCCL calls: the slot all-gather runs on its own stream, the gather of the match lists
-        # to rank 0 on each matcher's stream (operations of ONE communicator must not be in flight on several streams).
-        ids = [D.Comm.unique_id() for _ in range(1 + len(pms))] if rank == 0 else [None] * (1 + len(pms))
+        # the exchange of include/urf.h (urf_comm_*): RCCL behind the C ABI, not torch.distributed.  ONE communicator and ONE
+        # stream per rank; per step gather(b - M) then all-gather(b), the same order on every rank (pipeline.py)
+        ids = [D.Comm.unique_id()] if rank == 0 else [None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        comm_ag = D.Comm(world, rank, local_rank, ids[0])
-        comm_g = [D.Comm(world, rank, local_rank, ids[1 + i]) for i in range(len(pms))]
-        sp_ext = torch.cuda.ExternalStream(sp.stream_ptr(), device=dev)
-        pm_ext = [torch.cuda.ExternalStream(m.stream_ptr(), device=dev) for m in pms]
-        comm = torch.cuda.Stream(device=dev)
-        gathered_buf = torch.zeros((NB, world * BATCH, slot_floats), dtype=torch.float32, device=dev)
-        # rank 0 (where the serial tracker lives) receives every rank's match lists: counts and 12-byte matches
-        all_counts = [torch.zeros((world, BATCH), dtype=torch.int32, device=dev) for _ in pms]
-        all_matches = [torch.zeros((world, BATCH * 1024 * 3), dtype=torch.int32, device=dev) for _ in pms]
-        torch.cuda.synchronize()
-
-    sp_calls = [0]   # number of SP calls enqueued so far (batch index of the latest = sp_calls-1)
-
-    def sp_step(b):
-        sp_calls[0] = b + 1
-        k = b % NB
-        sp.infer_device(d_frames[k * BATCH].data_ptr(), BATCH, H, W, ring[k].data_ptr())
-
-    def slots_of(b):
-        k = b % NB
-        return (ring[k], 0) if not exchange else (gathered[k], rank * BATCH)
-
-    def pm_step(b, matcher):
-        """enqueue the matching of the pairs this rank owns in global batch b"""
-        cur, base = slots_of(b)
-        prev_all = slots_of(b - 1)[0] if b > 0 else None
-        s0, s1 = [], []
-        for j in range(BATCH):
-            g = base + j
-            if g > 0:
-                s0.append(cur[g - 1].data_ptr())
-            elif prev_all is not None:
-                s0.append(prev_all[-1].data_ptr())      # globally last frame of the previous batch
-            else:
-                s0.append(cur[g].data_ptr())            # very first frame of the stream: matched with itself
-            s1.append(cur[g].data_ptr())
-        matcher.match_device_async(s0, s1, True)
+        comm = D.Comm(world, rank, local_rank, ids[0])
+    pipe = P.SlotRingPipeline(sp, pms, d_frames, BATCH, H, W, device=dev, rank=rank, world=world, comm=comm,
+                              gloo=exchange and not async_exchange, overlap=OVERLAP)
+    ring = pipe.ring
 
     sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
     n_matches = []
     kept = {}                      # batch index -> match lists (last steps), for the exact-mode cross-check
 
-    pending = []   # (batch, matcher) whose results have not been fetched yet
-
-    def collect(record):
-        b, mt = pending.pop(0)
-        res = mt.fetch(BATCH, as_arrays=True)      # waits (event) for that batch's match lists only
-        if record:
-            age = (sp_calls[0] - 1) - b            # SP(b) finished before match(b); how many SP calls ago?
-            if 0 <= age <= 3:
-                s = sp.stage_ms(age=age)
-                sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1])
-            p = mt.stage_ms()
-            pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
-            sink_ms.append(p[4]); ransac_ms.append(p[6])
-            n_matches.append(sum(len(r) for r in res))
-            kept[b] = res
-        return res
-
-    def one_step(b, record):
-        """enqueue match(b) and SP(b+1); fetch the oldest finished batch"""
-        mt = pms[b % len(pms)]
-        if async_exchange:
-            # SP(b) -> all-gather(b) -> match(b) ordered by events, no host wait: the RCCL kernel runs
-            # on its own stream beside SuperPoint(b+1) and the other matcher
-            k = b % NB
-            ev_sp = torch.cuda.Event()
-            ev_sp.record(sp_ext)                                    # tail of the SuperPoint stream = SP(b)
-            comm.wait_event(ev_sp)
-            comm_ag.allgather_slots(ring[k].data_ptr(), BATCH, gathered_buf[k].data_ptr(), comm.cuda_stream)   # RCCL over xGMI
-            ev_ag = torch.cuda.Event()
-            ev_ag.record(comm)
-            pm_ext[b % len(pms)].wait_event(ev_ag)
-            gathered[k] = gathered_buf[k]
-        elif exchange:                                              # gloo test rig: host-staged, synchronous
-            sp.sync()
-            gathered[b % NB] = D.all_gather_slots(ring[b % NB], world)
-            torch.cuda.synchronize()
-        if OVERLAP:
-            mt.wait_for_sp(sp)                  # match(b) needs SP(b)
-        pm_step(b, mt)
-        if async_exchange:
-            # match lists -> rank 0, on the matcher's own stream right behind its kernels (12 KB x pairs per rank)
-            d_m, d_n = mt.device_results()
-            mi = b % len(pms)
-            comm_g[mi].gather(d_n, BATCH * 4, all_counts[mi].data_ptr(), 0, mt.stream_ptr())
-            comm_g[mi].gather(d_m, BATCH * 1024 * 12, all_matches[mi].data_ptr(), 0, mt.stream_ptr())
-        if OVERLAP == 1:
-            mt.let_sp_overlap_sinkhorn(sp)      # SP(b+1) starts when match(b) reaches Sinkhorn
-        sp_step(b + 1)
-        pending.append((b, mt))
-        res = None
-        while len(pending) >= len(pms):         # keep len(pms)-1 batches in flight behind the host
-            res = collect(record)
-        return res
+    def record(b, mt, res):
+        age = (pipe.sp_calls - 1) - b          # SP(b) finished before match(b); how many SP calls ago?
+        if 0 <= age <= 3:
+            s = sp.stage_ms(age=age)
+            sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1])
+        p = mt.stage_ms()
+        pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
+        sink_ms.append(p[4]); ransac_ms.append(p[6])
+        n_matches.append(sum(len(r) for r in res))
+        kept[b] = res
 
     def match_coords(res, cur, prev_last):
         """match lists as sets of pixel correspondences (x0,y0,x1,y1): keypoint ORDER may differ
         between precision modes (score-sorted, near-ties swap), coordinates do not"""
-        feats = [F.slot_to_host(prev_last.data_ptr())[:, 1:3]] + [F.slot_to_host(cur[j].data_ptr())[:, 1:3] for j in range(BATCH)]
-        out = []
-        for j in range(BATCH):
-            f0, f1 = feats[j], feats[j + 1]
-            out.append({(f0[q, 0], f0[q, 1], f1[t, 0], f1[t, 1]) for q, t in zip(res[j]["queryIdx"], res[j]["trainIdx"])})
-        return out
+        feats = [F.slot_to_host(prev_last.data_ptr())] + [F.slot_to_host(cur[j].data_ptr()) for j in range(BATCH)]
+        return [P.match_coords(res[j], feats[j], feats[j + 1]) for j in range(BATCH)]
 
     # prologue: SP(0) so that the loop body is exactly one match + one SP per step
-    sp_step(0)
-    for b in range(args.warmup):
-        one_step(b, False)
-    while pending:
-        collect(False)
+    pipe.prologue()
+    pipe.run(0, args.warmup)
+    pipe.drain()
     sp.sync()
     # `repeats` timed regions of exactly --steps steps, each bracketed by barrier + synchronize, max over ranks
-    region_s = []
+    region_s, region_local = [], []
     nb = args.warmup
     for rep in range(max(1, args.repeats)):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for b in range(nb, nb + args.steps):
-            one_step(b, True)
-        while pending:
-            collect(True)
+        pipe.run(nb, args.steps, record)
+        pipe.drain(record)
+        pipe.finish_exchange(nb + args.steps - 1)     # the last batches' match lists reach rank 0 inside the timed region
         sp.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        region_s.append(D.max_over_ranks(time.perf_counter() - t0, dev, world))
+        region_local.append(time.perf_counter() - t0)
+        region_s.append(D.max_over_ranks(region_local[-1], dev, world))
         nb += args.steps
     dt = float(np.median(region_s))
     args_last_batch = nb - 1
     total_frames = args.steps * BATCH * world
     fps = total_frames / dt
-    gathered_total = None
-    if async_exchange and rank == 0:
-        gathered_total = int(all_counts[args_last_batch % len(pms)].sum().item())   # the last step's matches of ALL ranks, as rank 0 received them
+    gathered_total = pipe.gathered_matches_last      # the last step's matches of ALL ranks, as rank 0 received them
+    # per-rank health, gathered to rank 0: a rank that fell back to the streaming Sinkhorn (or redid near-ties) is slower than
+    # the others and would otherwise go unreported at N > 1
+    health = {"rank": rank, "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms),
+              "region_s": [round(time_r, 4) for time_r in region_local],
+              "superpoint_ms": round(float(np.mean(sp_ms)), 3) if sp_ms else None,
+              "matching_ms": round(float(np.mean(pm_ms)), 3) if pm_ms else None}
+    per_rank = [health]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, health)
     insitu = {"superpoint": float(np.mean(sp_ms)) if sp_ms else None, "matching": float(np.mean(pm_ms)),
               "linear": float(np.mean(lin_ms)), "attention": float(np.mean(attn_ms))}
 
@@ -362,12 +277,12 @@ def main():
     if rank == 0:
         bl = args_last_batch + 1
         for b in range(bl, bl + 5):
-            sp_step(b)
+            pipe.sp_step(b)
             sp.sync()
             if exchange:
-                gathered[b % NB] = ring[b % NB].repeat(world, 1)   # layout stand-in, no collective
+                pipe.gathered[b % NB] = ring[b % NB].repeat(world, 1)   # layout stand-in, no collective
             pms[0].wait_for_sp(sp) if OVERLAP else None
-            pm_step(b, pms[0])
+            pipe.pm_step(b, pms[0])
             pms[0].fetch(BATCH, as_arrays=True)
             s_ = sp.stage_ms(age=0)
             p_ = pms[0].stage_ms()
@@ -537,7 +452,8 @@ def main():
             "stage_ms_per_step": stage_means,
             "matches_per_step": round(float(np.mean(n_matches)), 1),
             "matches_last_step_all_ranks_at_rank0": gathered_total,
-            "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms),   # resident launches redone with the streaming kernels
+            "sinkhorn_fallbacks": sum(h_["sinkhorn_fallbacks"] for h_ in per_rank),   # resident launches redone with the streaming kernels, all ranks
+            "per_rank": per_rank,
         }
         print(json.dumps(out))
     if world > 1 or force_dist:

@@ -232,6 +232,11 @@ int urf_comm_unique_id(void *id);
 int urf_comm_init(int world, int rank, int device, const void *id, urf_comm **out);
 /* one process driving ndev devices: out[i] is the communicator of devices[i] (ncclCommInitAll) */
 int urf_comm_init_all(int ndev, const int *devices, urf_comm **out);
+/* one process acting as `world` logical ranks on ONE device (single-GPU rigs and tests of the N > 1 data path): out[r] is
+ * rank r's communicator.  Device copies instead of RCCL; a collective completes when every rank has made the call (any
+ * rank order, from one host thread), with the stream semantics of the real thing: results are ordered behind every rank's
+ * producer stream, and a rank's stream may reuse its send buffer afterwards. */
+int urf_comm_init_loopback(int world, int device, urf_comm **out);
 void urf_comm_destroy(urf_comm *c);
 int urf_comm_world(const urf_comm *c);
 int urf_comm_rank(const urf_comm *c);

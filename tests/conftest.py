@@ -229,3 +229,60 @@ def quat_wxyz(R):
     y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2 * np.sign(R[0, 2] - R[2, 0] or 1)
     z = np.sqrt(max(0.0, 1 - R[0, 0] - R[1, 1] + R[2, 2])) / 2 * np.sign(R[1, 0] - R[0, 1] or 1)
     return np.array([w, x, y, z])
+
+
+# ------------------------------------------------------------------ the bench stream through the CPU oracle (GPU tests)
+BENCH_STREAM_FRAMES = 40       # bench.py at one GPU: (matchers + 3) x batch = 5 x 8 frames of synth.shift_stream(100, 40, H, W)
+SG_CFG = (640, 512, 0.5, 100)
+_BENCH_ORACLE = {}
+
+
+def _bench_oracle_worker(args):
+    """one oracle job in a worker process (the C oracle uses <= 32 OpenMP threads; a GPU box has many more cores)"""
+    kind, payload = args
+    U = load_pkg()
+    from oracle import oracle as O
+    O.build()
+    if kind == "sp":
+        img, max_kp = payload if isinstance(payload, tuple) else (payload, 1000)
+        return O.sp_infer(U.synth.pack_sp(U.synth.sp_weights(0)), O.SPConfig(max_kp, 0.0005, 4), img)
+    f0, f1, ransac = payload
+    rc = O.ref_ransac() if ransac == "ref" else O.RansacConfig(200, 1.0, 0)
+    return O.match_points(U.synth.pack_sg(U.synth.sg_weights(0)), O.SGConfig(*SG_CFG), rc, f0, f1, True)
+
+
+def oracle_pool():
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    ncpu = len(os.sched_getaffinity(0))
+    return ProcessPoolExecutor(max(1, min(6, ncpu // 32)), mp_context=mp.get_context("spawn"))
+
+
+def oracle_frames_and_pairs(frames, pairs, max_kp=1000):
+    """O.sp_infer on every frame and O.match_points (default outlier stage, outlier rejection on) on every (first, second)
+    index pair, spread over worker processes: (features, match lists)"""
+    with oracle_pool() as ex:
+        feats = list(ex.map(_bench_oracle_worker, [("sp", (f, max_kp)) for f in frames]))
+        lists = list(ex.map(_bench_oracle_worker, [("pm", (feats[a], feats[b], "ref")) for a, b in pairs]))
+    return feats, lists
+
+
+def bench_stream_oracle(H, W, n_sigma1=8):
+    """The stream bench.py times -- synth.shift_stream(100, 40, H, W) -- through the CPU oracle:
+    frames, features of all 40 frames, the match list of every consecutive pair (j - 1, j) mod 40 with the handle's
+    default outlier stage (the reference call's 3 px / 0.99, O.ref_ransac()) as lists["ref"][j], and the first `n_sigma1`
+    pairs with EpipolarGeometry's own statement (sigma = 1, every hypothesis counts) as lists["sigma1"][j] (pair (j, j + 1)).
+    Computed once per session, oracle jobs spread over worker processes."""
+    if (H, W) in _BENCH_ORACLE:
+        return _BENCH_ORACLE[(H, W)]
+    U = load_pkg()
+    frames = U.synth.shift_stream(100, BENCH_STREAM_FRAMES, H, W)
+    n = BENCH_STREAM_FRAMES
+    with oracle_pool() as ex:
+        feats = list(ex.map(_bench_oracle_worker, [("sp", f) for f in frames]))
+        jobs = [("pm", (feats[(j - 1) % n], feats[j], "ref")) for j in range(n)]
+        jobs += [("pm", (feats[j], feats[j + 1], "sigma1")) for j in range(n_sigma1)]
+        res = list(ex.map(_bench_oracle_worker, jobs))
+    out = (frames, feats, {"ref": res[:n], "sigma1": res[n:]})
+    _BENCH_ORACLE[(H, W)] = out
+    return out

@@ -11,6 +11,11 @@ Fixtures are DATA (inputs + expected outputs), never reference source:
                         reference post-processing restated with torch ops
   sp_sparse_376x1241.npz same at the KITTI size (valid width 1240)
   sp_sparse_480x640.npz same at the size of BASELINE.json's headline configuration
+  sp_bench_stream_480x640.npz, sp_bench_stream_376x1241.npz
+                        frames 0..8 of the stream bench.py times (synth.shift_stream(100, 40, H, W)) through the
+                        reference graph: per frame the top-1000 keypoints (x, y u16; score f32, reference order), the score
+                        of the best candidate that did NOT make the cut and the candidate count.  The frames themselves are
+                        regenerated from the seed.
   sg_n96.npz            two feature sets and the (n0+1)x(n1+1) log-assignment
   sg_n320.npz           same at n = 320 (features regenerated from the stored seed: conftest.sg_golden_features)
   sg_n1000.npz          n = 1000 (the bench size): every 8th row of the log-assignment in f32 (Zrows), the full
@@ -93,6 +98,23 @@ def main():
                             desc=ds.astype(np.float16), k=np.int32(k),
                             n_candidates=np.int32(int((s.astype(np.float64) > 0.0005).sum())))
         print(H, W, "K", len(xs), "cands", int((s > 0.0005).sum()))
+
+    for (H, W) in [(480, 640), (376, 1241)]:
+        name = os.path.join(OUT, f"sp_bench_stream_{H}x{W}.npz")
+        if os.path.exists(name) and "--force" not in sys.argv:
+            continue
+        frames = synth.shift_stream(100, 40, H, W)[:9]          # bench.py: NB * batch * world = 40 frames at one GPU
+        xs_, ys_, sc_, nxt, ncand = [], [], [], [], []
+        for img in frames:
+            s, d = sp_run(m, img)
+            xs, ys, sc, _ = sp_post(s, d, k=1000)
+            x2, y2, sc2, _ = sp_post(s, d[:, :, :], k=1001)
+            assert len(xs) == 1000 and np.array_equal(xs, x2[:1000]) and np.array_equal(ys, y2[:1000])
+            xs_.append(xs.astype(np.uint16)); ys_.append(ys.astype(np.uint16)); sc_.append(sc)
+            nxt.append(sc2[1000]); ncand.append(len(sp_post(s, d, k=-1)[0]))
+        np.savez_compressed(name, x=np.stack(xs_), y=np.stack(ys_), score=np.stack(sc_), first_cut_score=np.array(nxt, np.float32),
+                            n_candidates=np.array(ncand, np.int32), seed=np.int32(100), stream_frames=np.int32(40))
+        print(name, "cands", ncand, "cut margins (relative)", [(a[-1] - b) / b for a, b in zip(sc_, nxt)])
 
     sg_cases = [(96, 40, 7, "sg_n96.npz"), (320, 150, 8, "sg_n320.npz"), (1000, 600, 9, "sg_n1000.npz")]
     sg_cases = [c for c in sg_cases if "--force" in sys.argv or not os.path.exists(os.path.join(OUT, c[3]))]

@@ -31,3 +31,111 @@ def test_rccl_allgather_and_gather_through_the_c_abi(U):
         D.Comm(2, 0, 0, None)                          # a world of two needs rank 0's unique id
     with pytest.raises(RuntimeError):
         D.Comm(2, 5, 0, D.Comm.unique_id())            # rank outside the world
+
+
+def test_loopback_world_collectives_have_the_layout_of_the_real_ones(U):
+    """urf_comm_init_loopback: 4 logical ranks of this process on one GPU; all-gather and gather through the same entry points,
+    every rank on its own stream, calls in a scrambled rank order; two gathers back to back (queued per rank)"""
+    import torch
+    L = U._lib.lib()
+    D = U.dist
+    world, n = 4, 2
+    sf = L.urf_slot_bytes() // 4
+    comms = D.Comm.loopback(world, 0)
+    assert [L.urf_comm_rank(c._h) for c in comms] == [0, 1, 2, 3] and L.urf_comm_world(comms[2]._h) == 4
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    local = [torch.full((n, sf), float(r + 1), device="cuda") + torch.arange(n, device="cuda")[:, None] * 0.25 for r in range(world)]
+    allb = [torch.zeros((world * n, sf), device="cuda") for _ in range(world)]
+    root_a = torch.zeros((world, 1000), device="cuda")
+    root_b = torch.zeros((world, 16), device="cuda")
+    torch.cuda.synchronize()
+    for r in (2, 0, 3, 1):
+        comms[r].allgather_slots(local[r].data_ptr(), n, allb[r].data_ptr(), streams[r].cuda_stream)
+    for r in (1, 3, 2, 0):
+        comms[r].gather(local[r].data_ptr(), 4000, root_a.data_ptr() if r == 0 else 0, 0, streams[r].cuda_stream)
+        comms[r].gather(local[r][1].data_ptr(), 64, root_b.data_ptr() if r == 0 else 0, 0, streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.cat(local)
+    for r in range(world):
+        assert torch.equal(allb[r], want)
+    for r in range(world):
+        assert torch.equal(root_a[r], local[r].reshape(-1)[:1000]) and torch.equal(root_b[r], local[r][1][:16])
+    with pytest.raises(RuntimeError, match="disagree"):
+        comms[0].gather(local[0].data_ptr(), 64, root_b.data_ptr(), 0, streams[0].cuda_stream)
+        for r in (1, 2, 3):
+            comms[r].gather(local[r].data_ptr(), 128, 0, 0, streams[r].cuda_stream)
+
+
+@pytest.mark.parametrize("world,B,prec", [(8, 4, 1), (2, 4, 0)])
+def test_sharded_pipeline_in_a_loopback_world_vs_oracle(U, sp_blob, sg_blob, world, B, prec):
+    """BASELINE.json configs[3] geometry on ONE GPU: 1241x376 frames, batch 32 sharded 4 per rank over 8 logical ranks
+    (urf_comm_init_loopback), every rank with its own SuperPoint and two matcher handles and the step loop bench.py runs
+    (pipeline.SlotRingPipeline): all-gather of the slots, pairs that straddle ranks, the slot carried over the step seam,
+    gather of the match lists to rank 0 -- every rank's fetched lists against O.match_points on the same frames, the gathered
+    slots against the ranks' own, and rank 0's gather buffers against what the ranks fetched."""
+    import torch
+    from conftest import bench_stream_oracle
+    F, D, P = U.frontend, U.dist, U.pipeline
+    H, W, M = 376, 1241, 2
+    frames, ofeats, olists = bench_stream_oracle(H, W)
+    n = len(frames)
+    NB = M + 3
+    dev = torch.device("cuda", 0)
+    comms = D.Comm.loopback(world, 0)
+    pipes = []
+    for r in range(world):
+        sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B, precision=prec)
+        assert sp.build(sp_blob)
+        pms = []
+        for _ in range(M):
+            pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B, precision=prec)
+            assert pm.build(sg_blob)
+            pms.append(pm)
+        idx = [((k * world + r) * B + j) % n for k in range(NB) for j in range(B)]
+        d_frames = torch.from_numpy(np.stack([frames[i] for i in idx])).to(dev)
+        pipes.append(P.SlotRingPipeline(sp, pms, d_frames, B, H, W, device=dev, rank=r, world=world, comm=comms[r],
+                                        keep_gathered=(r == 0)))
+    for p in pipes:
+        p.prologue()
+    steps = 3
+    got = P.run_lockstep(pipes, 0, steps)
+    fin = P.finish_lockstep(pipes, steps - 1)
+    fetched = [dict(a + b) for a, b in zip(got, fin)]
+    torch.cuda.synchronize()
+    # the all-gather: every rank holds every rank's slots of a batch, in global frame order
+    for k in range(steps):
+        want = torch.cat([p.ring[k] for p in pipes])
+        for p in pipes:
+            assert torch.equal(p.gathered_buf[k], want)
+    run_feats = {}
+    for b in range(steps):
+        for r in range(world):
+            for j in range(B):
+                run_feats[(b * world + r) * B + j] = F.slot_to_host(pipes[r].ring[b][j].data_ptr())
+    coords = lambda lst, f0, f1: {(f0[q, 1], f0[q, 2], f1[t, 1], f1[t, 2]) for q, t, _ in lst}   # noqa: E731
+    tup = lambda m: [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]   # noqa: E731
+    for r in range(world):
+        assert sorted(fetched[r]) == list(range(steps))
+        for b in range(steps):
+            for j in range(B):
+                G = (b * world + r) * B + j
+                if G == 0:
+                    continue                                  # the stream's first frame is matched with itself
+                lst, want = tup(fetched[r][b][j]), olists["ref"][G % n]
+                if prec == 0:
+                    assert np.array_equal(run_feats[G][:, :3], ofeats[G % n][:, :3])
+                    assert lst == want, (r, b, j)
+                else:
+                    assert {(x[1], x[2]) for x in run_feats[G]} == {(x[1], x[2]) for x in ofeats[G % n]}, G
+                    assert coords(lst, run_feats[G - 1], run_feats[G]) == coords(want, ofeats[(G - 1) % n], ofeats[G % n]), (r, b, j)
+                assert len(want) > 300 or G % n == 0
+    # rank 0's gather buffers: every rank's counts and lists of every batch, as the ranks fetched them
+    log = pipes[0].gather_log
+    assert sorted(log) == list(range(steps))
+    for b in range(steps):
+        cnt, mt = log[b]
+        for r in range(world):
+            for j in range(B):
+                m = fetched[r][b][j]
+                assert cnt[r, j] == len(m) and np.array_equal(mt[r, j, :len(m)], m), (b, r, j)
+    assert sum(m.sinkhorn_fallbacks() for p in pipes for m in p.pms) == 0

@@ -587,11 +587,17 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, sp640, pm):
+@pytest.mark.parametrize("prec", [0, 1])
+def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec):
     """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
-    SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)"""
+    SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)
+    (src/tracking.cc:321-377) as the CPU ORACLE runs it: O.sp_infer / O.match_points on the same 21 frames.
+    Exact mode: features and match lists bit for bit; fast mode: the same keypoint sets and correspondences."""
+    from conftest import oracle_frames_and_pairs
     frames = np.stack(U.synth.shift_stream(17, 21, 480, 640))
-    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=1000), F.SuperGlueConfig(), batch=8, max_height=480, max_width=640)
+    ofeats, olists = oracle_frames_and_pairs(list(frames), [(t - 1, t) for t in range(1, 21)])
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=1000), F.SuperGlueConfig(), batch=8, max_height=480, max_width=640,
+                       precision=prec)
     assert fs.build(sp_blob, sg_blob)
     got_K, got_m, got_f = [], [], []
     for b0 in (0, 8, 16):
@@ -603,14 +609,20 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
         K, m, f = fs.collect(want_features=True)
         got_K += list(K); got_m += m; got_f += f
     assert len(got_K) == 21
-    feats = [sp640.infer(fr) for fr in frames]
     assert len(got_m[0]) == 0                                # no predecessor
+    coords = lambda lst, f0, f1: {(f0[q, 1], f0[q, 2], f1[t_, 1], f1[t_, 2]) for q, t_, _ in lst}   # noqa: E731
     for t in range(21):
-        assert got_K[t] == feats[t].shape[0]
-        assert np.array_equal(got_f[t].astype(np.float32), feats[t].astype(np.float32))
+        assert got_K[t] == ofeats[t].shape[0]
+        if prec == 0:
+            assert np.array_equal(got_f[t].astype(np.float32), ofeats[t].astype(np.float32))
+        else:
+            assert {(r[1], r[2]) for r in got_f[t]} == {(r[1], r[2]) for r in ofeats[t]}, t
         if t > 0:
-            ref = pm.MatchingPoints(feats[t - 1], feats[t], True)
-            assert _as_tuples(got_m[t]) == ref, t
+            ref = olists[t - 1]
+            if prec == 0:
+                assert _as_tuples(got_m[t]) == ref, t
+            else:
+                assert coords(_as_tuples(got_m[t]), got_f[t - 1], got_f[t]) == coords(ref, ofeats[t - 1], ofeats[t]), t
             assert len(ref) > 300
 
 
@@ -624,9 +636,13 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     fs = F.FrameStream(F.SuperPointConfig(max_keypoints=600), F.SuperGlueConfig(), batch=4, max_height=480, max_width=640)
     assert fs.build(sp_blob, sg_blob)
     fs.set_camera(cam)
-    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=600), max_height=480, max_width=640)
-    assert sp.build(sp_blob)
-    feats = [sp.infer(O.cam_remap(fr, m1, m2)) for fr in frames]
+    from conftest import oracle_frames_and_pairs
+    refs = [None, 0, 1, 2, 0, 0, 5, 6, 0, 3, 7, 10]
+    # the reference's loop as the CPU oracle runs it: cv::remap, SuperPoint::infer, MatchingPoints(keyframe, frame, true)
+    om1, om2 = O.cam_init_maps(O.cam_config(640, 480, K, [-0.05, 0.01, 1e-4, -2e-4]))
+    assert np.array_equal(om1, m1) and np.array_equal(om2, m2)
+    feats, olists = oracle_frames_and_pairs([O.cam_remap(fr, om1, om2) for fr in frames], [(refs[t], t) for t in range(1, 12)] + [(9, 3)],
+                                            max_kp=600)
     out = []
     fs.submit(frames[0:4])                      # predecessor chain
     fs.submit(frames[4:8], ref=[0, 0, 5, -1])   # keyframe 0 (previous batch), an earlier frame of this batch, predecessor
@@ -635,15 +651,13 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
         fs.submit(frames[8:12])                 # matchers + 1 batches already in flight
     while fs.in_flight():
         out += fs.collect()[1]
-    refs = [None, 0, 1, 2, 0, 0, 5, 6, 0, 3, 7, 10]
     for t in range(1, 12):
-        want = pm.MatchingPoints(feats[refs[t]], feats[t], True)
-        assert _as_tuples(out[t]) == want, t
+        assert _as_tuples(out[t]) == olists[t - 1], t
     with pytest.raises(RuntimeError, match="left the ring"):
         fs.submit(frames[0:4], ref=[-1, -1, -1, 0])   # frame 0 is 3 batches back: outside the 2-batch window
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
-    assert _as_tuples(fs.collect()[1][3]) == pm.MatchingPoints(feats[9], feats[3], True)
+    assert _as_tuples(fs.collect()[1][3]) == olists[11]
 
 
 # ------------------------------------------------------------------ error behaviour of the boundary

@@ -73,6 +73,22 @@ def test_sp_infer_matches_reference_postprocess(O, sp_blob, name):
     assert np.abs(np.linalg.norm(f[:, 3:], axis=1) - 1).max() < 1e-12
 
 
+@pytest.mark.parametrize("H,W", [(480, 640), (376, 1241)])
+def test_bench_stream_keypoints_match_the_reference_graph(U, O, sp_blob, H, W):
+    """the first frames of the stream bench.py times (synth.shift_stream(100, 40, H, W)) through the oracle, against
+    the reference's own graph run under torch (tests/golden/make_golden.py -> sp_bench_stream_*.npz): the same 1000
+    keypoints, scores within 1e-5.  (A keypoint could only differ where the reference run's own cut margin is below the
+    2e-6 that separates torch's summation order from the canonical one; none of these frames is that close.)"""
+    g = golden(f"sp_bench_stream_{H}x{W}.npz")
+    frames = U.synth.shift_stream(int(g["seed"]), int(g["stream_frames"]), H, W)[:3]
+    for j, fr in enumerate(frames):
+        f = O.sp_infer(sp_blob, O.SPConfig(1000, 0.0005, 4), fr)
+        ref = {(int(x), int(y)): float(s) for x, y, s in zip(g["x"][j], g["y"][j], g["score"][j])}
+        got = {(int(r[1]), int(r[2])): float(r[0]) for r in f}
+        assert set(ref) == set(got), j
+        assert max(abs(ref[k] - got[k]) for k in ref) < 1e-5
+
+
 def test_sp_width_not_multiple_of_8_uses_valid_region(O, sp_blob):
     g = golden("sp_sparse_376x1241.npz")
     o = O.sp_dense(sp_blob, g["image"])

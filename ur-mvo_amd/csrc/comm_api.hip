@@ -10,11 +10,21 @@
 #include "urf_common.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <vector>
+
+// The few RCCL types this file needs, declared here (values as in <rccl/rccl.h> of ROCm 7.2: ncclSuccess = 0,
+// ncclChar = 0, a 128-byte unique id): a single-GPU build of the library does not need the RCCL headers.
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[URF_COMM_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclChar = 0;
 
 namespace urf {
 namespace {
@@ -72,12 +82,29 @@ int rccl_load() {
 }  // namespace urf
 using namespace urf;
 
-struct urf_comm {
-  int world = 1, rank = 0, device = 0;
-  ncclComm_t nccl = nullptr;     // null: a world of one without RCCL
+// Loopback world: one process acts as `world` logical ranks on ONE device (urf_comm_init_loopback).  A collective is a
+// rendezvous: every rank's call queues its arguments and records an event on its stream; the call that completes the head
+// of every rank's queue issues the device copies -- on each receiver's stream, behind every sender's event -- and then makes
+// every rank's stream wait for all copies (a rank may reuse its send buffer after the collective, as with RCCL).  Host calls
+// may come in any rank order from one thread; every rank makes the same sequence of collectives (also as with RCCL).
+struct LoopHub {
+  int world = 0, device = 0;
+  std::mutex mu;
+  struct Arg { int kind; const void *src; void *dst; size_t bytes; int root; hipStream_t st; };
+  std::vector<std::deque<Arg>> q;          // pending calls per rank, in call order
+  std::vector<hipEvent_t> ev_in, ev_out;   // per rank: "my send buffer is ready" / "my copies are done"
+  long collectives = 0;
+  ~LoopHub() {
+    for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_out) (void)hipEventDestroy(e);
+  }
 };
 
-static_assert(URF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "urf.h states the size of ncclUniqueId");
+struct urf_comm {
+  int world = 1, rank = 0, device = 0;
+  ncclComm_t nccl = nullptr;     // null: a world of one without RCCL, or a loopback rank
+  std::shared_ptr<LoopHub> hub;  // loopback world
+};
 
 extern "C" int urf_comm_unique_id(void *id) {
   URF_CHECK(id, "urf_comm_unique_id: null");
@@ -122,6 +149,64 @@ extern "C" int urf_comm_init_all(int ndev, const int *devices, urf_comm **out) {
   return 0;
 }
 
+extern "C" int urf_comm_init_loopback(int world, int device, urf_comm **out) {
+  URF_CHECK(out && world >= 1 && world <= 64, "urf_comm_init_loopback: world %d outside [1, 64]", world);
+  int ndev = 0;
+  URF_HIP(hipGetDeviceCount(&ndev));
+  URF_CHECK(device >= 0 && device < ndev, "device %d out of range (%d devices)", device, ndev);
+  URF_HIP(hipSetDevice(device));
+  auto hub = std::make_shared<LoopHub>();
+  hub->world = world; hub->device = device;
+  hub->q.resize(world);
+  hub->ev_in.resize(world); hub->ev_out.resize(world);
+  for (int r = 0; r < world; ++r) {
+    URF_HIP(hipEventCreateWithFlags(&hub->ev_in[r], hipEventDisableTiming));
+    URF_HIP(hipEventCreateWithFlags(&hub->ev_out[r], hipEventDisableTiming));
+  }
+  for (int r = 0; r < world; ++r) {
+    out[r] = new urf_comm();
+    out[r]->world = world; out[r]->rank = r; out[r]->device = device; out[r]->hub = hub;
+  }
+  return 0;
+}
+
+// a rank's call of a loopback collective (kind 0 = all-gather, 1 = gather).  Returns 0, or < 0 with the error text set.
+static int loop_collective(urf_comm *c, int kind, const void *src, void *dst, size_t bytes, int root, hipStream_t st) {
+  LoopHub &h = *c->hub;
+  std::lock_guard<std::mutex> lock(h.mu);
+  h.q[c->rank].push_back({kind, src, dst, bytes, root, st});
+  // (a later record of the same event only makes an earlier collective wait for more of the same stream)
+  URF_HIP(hipEventRecord(h.ev_in[c->rank], st));
+  for (;;) {
+    for (int r = 0; r < h.world; ++r)
+      if (h.q[r].empty()) return 0;
+    std::vector<LoopHub::Arg> set((size_t)h.world);
+    for (int r = 0; r < h.world; ++r) { set[r] = h.q[r].front(); h.q[r].pop_front(); }
+    for (int r = 1; r < h.world; ++r)
+      URF_CHECK(set[r].kind == set[0].kind && set[r].bytes == set[0].bytes && set[r].root == set[0].root,
+                "loopback ranks 0 and %d disagree on a collective (kind %d/%d, %zu/%zu bytes, root %d/%d)", r, set[0].kind,
+                set[r].kind, set[0].bytes, set[r].bytes, set[0].root, set[r].root);
+    const bool gather = set[0].kind == 1;
+    const size_t nb = set[0].bytes;
+    const int rt = set[0].root;
+    // copies on the receivers' streams, behind every sender's event
+    for (int q = 0; q < h.world; ++q) {
+      if (gather && q != rt) continue;
+      URF_CHECK(set[q].dst, "loopback collective: rank %d has no receive buffer", q);
+      for (int r = 0; r < h.world; ++r) URF_HIP(hipStreamWaitEvent(set[q].st, h.ev_in[r], 0));
+      for (int r = 0; r < h.world; ++r) {
+        char *to = (char *)set[q].dst + (size_t)r * nb;
+        if ((const void *)to != set[r].src) URF_HIP(hipMemcpyAsync(to, set[r].src, nb, hipMemcpyDeviceToDevice, set[q].st));
+      }
+      URF_HIP(hipEventRecord(h.ev_out[q], set[q].st));
+    }
+    for (int r = 0; r < h.world; ++r)
+      for (int q = 0; q < h.world; ++q)
+        if ((!gather || q == rt) && q != r) URF_HIP(hipStreamWaitEvent(set[r].st, h.ev_out[q], 0));
+    h.collectives += 1;
+  }
+}
+
 extern "C" void urf_comm_destroy(urf_comm *c) {
   if (!c) return;
   if (c->nccl) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->nccl); }
@@ -136,6 +221,7 @@ extern "C" int urf_comm_allgather_slots(urf_comm *c, const void *d_local, int ns
   URF_CHECK(c && d_local && d_all && nslots >= 1, "urf_comm_allgather_slots: bad argument");
   URF_HIP(hipSetDevice(c->device));
   const size_t bytes = (size_t)nslots * urf_slot_bytes();
+  if (c->hub) return loop_collective(c, 0, d_local, d_all, bytes, -1, (hipStream_t)stream);
   if (!c->nccl) {
     if (d_all != d_local) URF_HIP(hipMemcpyAsync(d_all, d_local, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
@@ -150,6 +236,7 @@ extern "C" int urf_comm_gather(urf_comm *c, const void *d_send, size_t bytes, vo
   URF_CHECK(c->rank != root || d_recv, "urf_comm_gather: the root needs a receive buffer");
   URF_HIP(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  if (c->hub) return loop_collective(c, 1, d_send, d_recv, bytes, root, st);
   if (!c->nccl) {
     if (d_recv != d_send) URF_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
     return 0;

@@ -29,6 +29,18 @@ class Comm:
         buf = None if id_bytes is None else C.create_string_buffer(bytes(id_bytes), 128)
         check(_lib.lib().urf_comm_init(self.world, self.rank, self.device, buf, C.byref(self._h)), "urf_comm_init")
 
+    @classmethod
+    def loopback(cls, world, device=0):
+        """`world` logical ranks of ONE process on one device (urf_comm_init_loopback): a list of Comm, rank order"""
+        hs = (C.c_void_p * world)()
+        check(_lib.lib().urf_comm_init_loopback(int(world), int(device), hs), "urf_comm_init_loopback")
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c.world, c.rank, c.device, c._h = int(world), r, int(device), C.c_void_p(hs[r])
+            out.append(c)
+        return out
+
     @staticmethod
     def unique_id():
         buf = C.create_string_buffer(128)
