@@ -85,9 +85,7 @@ def pmc_traffic(kernel_label, resolution, prec):
     (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py) of this same command.  bench.py cannot collect counters about
     itself: the summary is the newest profiles/r*_pmc_hbm*.json for this resolution whose `source_sha` equals the
     sha of the kernel sources in this tree -- a summary taken on other kernels is refused (traffic = null)."""
-    if prec != 1:
-        return None, "no PMC pass for the exact mode"
-    tag = "" if resolution == "640x480" else "_" + resolution
+    tag = ("" if resolution == "640x480" else "_" + resolution) + ("_exact" if prec == 0 else "")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm{tag}.json")))
     if not files:
         return None, "no committed PMC summary for this resolution"
@@ -95,14 +93,16 @@ def pmc_traffic(kernel_label, resolution, prec):
     if d.get("source_sha") != kernel_source_sha():
         return None, (f"{os.path.basename(files[-1])} was taken on other kernel sources (sha {d.get('source_sha')} != "
                       f"{kernel_source_sha()}): refused")
-    fam = ("h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
+    fam = ("conv_mfma_kernel<9,pool,fuse1a>" if "conv_mfma_kernel<9" in kernel_label else "linear_exact" if "gemm128" in kernel_label
+           else "attn_kernel" if "(attn_kernel)" in kernel_label
+           else "h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
            else "sinkhorn_regs_kernel" if "sinkhorn_regs_kernel" in kernel_label
            else "sinkhorn_resident_kernel" if "sinkhorn_resident_kernel" in kernel_label
            else "sinkhorn_half_kernel" if "inkhorn" in kernel_label else "h2conv_kernel<pool,fuse1a>")
     k = d["kernels"].get(fam)
     if not k:
         return None, f"{os.path.basename(files[-1])} has no {fam}"
-    calls = d["superpoint_calls"] if fam.startswith("h2conv") else d["matcher_calls"]
+    calls = d["superpoint_calls"] if (fam.startswith("h2conv") or fam.startswith("conv_mfma")) else d["matcher_calls"]
     return int(k["bytes_total"] / calls), (f"bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the "
                                            f"{k['launches'] // calls} {fam} launches of a step; L2-miss traffic incl. "
                                            f"Infinity-Cache hits; {os.path.basename(files[-1])}")
@@ -118,8 +118,10 @@ def main():
                     help="frames (and pairs) per GPU per step: 8 = BASELINE configs[2]; 4 with --gpus 8 and --resolution "
                          "1241x376 = configs[3] (batch 32 sharded over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
-                    help="1 = fast (split-f16 MFMA, fp32-equivalent accuracy, default); 0 = exact fp32 (bit-identical to the oracle)")
+    ap.add_argument("--precision", type=int, default=2, choices=[0, 1, 2],
+                    help="2 = guarded fast (default): split-f16 MFMA, and every frame / pair whose discrete decisions sit within "
+                         "the fast mode's error is redone in the exact mode inside the library (the reruns are inside the timed "
+                         "region); 1 = fast without the guard; 0 = exact fp32 (bit-identical to the oracle)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
     ap.add_argument("--resolution", default="640x480", choices=["640x480", "1241x376"],
                     help="frame size WxH: 640x480 (headline, BASELINE configs[2]) or the KITTI-size stream of configs[3]")
@@ -164,6 +166,7 @@ def main():
     spb = synth.pack_sp(synth.sp_weights(0))
     sgb = synth.pack_sg(synth.sg_weights(0))
     PREC = args.precision
+    FAST = PREC >= 1
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
                       device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
@@ -258,7 +261,11 @@ def main():
     gathered_total = pipe.gathered_matches_last      # the last step's matches of ALL ranks, as rank 0 received them
     # per-rank health, gathered to rank 0: a rank that fell back to the streaming Sinkhorn (or redid near-ties) is slower than
     # the others and would otherwise go unreported at N > 1
+    sp_g = sp.near_tie_reruns()
+    pm_g = [m.near_tie_reruns() for m in pms]
     health = {"rank": rank, "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms),
+              "frames_redone_exact": sp_g["redone"], "frames": sp_g["frames"],
+              "pairs_redone_exact": sum(g_["redone"] for g_ in pm_g), "pairs": sum(g_["pairs"] for g_ in pm_g),
               "region_s": [round(time_r, 4) for time_r in region_local],
               "superpoint_ms": round(float(np.mean(sp_ms)), 3) if sp_ms else None,
               "matching_ms": round(float(np.mean(pm_ms)), 3) if pm_ms else None}
@@ -298,15 +305,15 @@ def main():
         Hc_, Wc_ = H // 2, W // 2
         conv1_gb = BATCH * (H * W + Hc_ * Wc_ * 64 * 4) / 1e9   # u8 frame in, pooled 64-channel map out (4 B/element)
         per_step = {   # name: (ms, GFLOP, GB) per step
-            ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if PREC else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
+            ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if FAST else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
                 (np.mean(conv1_ms), GF_CONV1 * BATCH, conv1_gb),
-            ("SuperGlue linear layers (h2gemm_glds_kernel)" if PREC else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
+            ("SuperGlue linear layers (h2gemm_glds_kernel)" if FAST else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
                 (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH,
-                 sg_linear_gbytes(n_avg, n_avg, PREC == 1) * BATCH + SG_WEIGHT_GB),
-            ("SuperGlue attention (attn_h2_kernel)" if PREC else "SuperGlue attention (attn_kernel)"):
+                 sg_linear_gbytes(n_avg, n_avg, FAST) * BATCH + SG_WEIGHT_GB),
+            ("SuperGlue attention (attn_h2_kernel)" if FAST else "SuperGlue attention (attn_kernel)"):
                 (np.mean(attn_ms), sg_attn_gflop(n_avg, n_avg) * BATCH, sg_attn_gbytes(n_avg, n_avg) * BATCH),
         }
-        resident = PREC == 1 and os.environ.get("URF_SINKHORN_RESIDENT", "1") != "0"
+        resident = FAST and os.environ.get("URF_SINKHORN_RESIDENT", "1") != "0"
         if resident:
             # chip-resident Sinkhorn (sinkhorn_resident.hip; plan tile in registers, or in LDS with URF_SINKHORN_REGS=0): the
             # couplings are read from HBM/L2 once per (re)absorption (initially and after iterations 1, 2, 4, ... 64: 8
@@ -323,8 +330,8 @@ def main():
                 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
         # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); the MFMA roof is priced on the
         # ALGORITHMIC flops (counted once), so its fraction is <= 1/3 by construction
-        peak_tf = F16_MFMA_PEAK_TF if PREC == 1 else FP32_MFMA_PEAK_TF
-        issue = 3 if PREC == 1 else 1
+        peak_tf = F16_MFMA_PEAK_TF if FAST else FP32_MFMA_PEAK_TF
+        issue = 3 if FAST else 1
 
         def roofs(ms_, gf_, gb_):
             # (the few VALU flops of Sinkhorn are priced at the MFMA roof too: either way its HBM roof binds)
@@ -363,7 +370,7 @@ def main():
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
         exact = None
-        if world == 1 and PREC == 1 and not args.no_exact_check:
+        if world == 1 and FAST and not args.no_exact_check:
             # reference pass in the exact fp32 mode (bit-identical to the oracle) on the SAME
             # batches: its throughput and how far the fast mode's match lists are from it
             sp2 = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
@@ -434,13 +441,13 @@ def main():
                         "min": round(total_frames / max(region_s), 2), "max": round(total_frames / min(region_s), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
-                      if PREC == 1 else "f32"), "data": "synthetic",
+                      if FAST else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.resolution} grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
                                    f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json "
                                    f"{'configs[3]: batch 32 over 8 GPUs' if (BATCH * world == 32 and args.resolution == '1241x376') else 'configs[2]'})",
                        "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
-                       "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": ("fast" if PREC == 1 else "exact"),
+                       "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": {0: "exact", 1: "fast", 2: "guarded fast"}[PREC],
                        "weights": "seeded synthetic (reference ships none)",
                        "streams": {0: "one in-order stream", 1: "2 streams: SP(b+1) beside Sinkhorn(b)",
                                    2: "3 streams: Sinkhorn(b) beside GNN(b+1) and SP(b+2)"}[OVERLAP],
@@ -453,6 +460,12 @@ def main():
             "matches_per_step": round(float(np.mean(n_matches)), 1),
             "matches_last_step_all_ranks_at_rank0": gathered_total,
             "sinkhorn_fallbacks": sum(h_["sinkhorn_fallbacks"] for h_ in per_rank),   # resident launches redone with the streaming kernels, all ranks
+            # guarded fast mode: frames / pairs redone in the exact mode because a discrete decision sat within the fast mode's
+            # error (all ranks, warm-up and timed regions; the reruns are part of the timed work)
+            "near_tie_reruns": {"frames": sum(h_["frames_redone_exact"] for h_ in per_rank), "of_frames": sum(h_["frames"] for h_ in per_rank),
+                                "pairs": sum(h_["pairs_redone_exact"] for h_ in per_rank), "of_pairs": sum(h_["pairs"] for h_ in per_rank),
+                                "superpoint_causes": {k: sp_g[k] for k in ("cut", "threshold", "nms")},
+                                "matcher_causes": {k: sum(g_[k] for g_ in pm_g) for k in ("threshold", "runner_up")}},
             "per_rank": per_rank,
         }
         print(json.dumps(out))

@@ -44,7 +44,11 @@ typedef struct {
   int device;                 /* HIP device ordinal */
   /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the eight
    * 3x3 convolutions run on the f16 matrix core with split operands
-   * (fp32-equivalent accuracy, not bit-reproducible) */
+   * (fp32-equivalent accuracy, not bit-reproducible);
+   * 2 = guarded fast: as 1, and every discrete decision (NMS maximum, 0.0005 threshold, top-k cut) that sits closer to
+   * its alternative than the fast mode's error is detected on the device; such a frame is redone in the exact mode
+   * inside the library before its slot is handed on (slot header word 1 = 1), so the keypoint SET of every frame is the
+   * exact mode's.  urf_sp_near_tie_reruns() counts them. */
   int precision;
 } urf_sp_config;
 
@@ -86,6 +90,11 @@ int urf_sp_sync(urf_sp *h);
  * producer of the slot must have finished (urf_sp_sync, or a fetched match batch that consumed it). */
 int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K);
 
+/* guarded fast mode (precision 2), counters since build(): out[0] = frames redone in the exact mode, out[1] = frames
+ * processed, out[2..4] = frames flagged by the top-k cut / the threshold band / an NMS near-tie (n <= 8 values are
+ * written; zeros in the other modes).  Waits for the handle's stream. */
+int urf_sp_near_tie_reruns(urf_sp *h, unsigned long long *out, int n);
+
 /* debug / parity taps (tests): dense tensors of the LAST single-frame call.
  * which: 0 = post-NMS scores [Hs][Ws], 1 = pre-NMS heat map [Hs][Ws],
  * 2 = dense descriptors [Hc][Wc][256], 100+i = conv i output (NHWC). */
@@ -107,7 +116,10 @@ typedef struct {
   uint32_t ransac_seed;
   /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the 18 GNN
    * layers run on the f16 matrix core with split operands (fp32-equivalent
-   * accuracy, not bit-reproducible) */
+   * accuracy, not bit-reproducible); 2 = guarded fast: as 1, and a pair in which a row's or
+   * column's best assignment lies within the fast mode's error of the matching threshold or of its runner-up is
+   * redone in the exact mode inside the library before its match list is handed out (urf_pm_fetch, urf_match,
+   * urf_sg_infer), so the match SET of every pair is the exact mode's.  urf_pm_near_tie_reruns() counts them. */
   int precision;
   /* the reference call's own parameters (appended fields; all-zero = the reference's values):
    * ransac_threshold_px: distance to the epipolar line in pixels, findFundamentalMat's 3rd argument.  Used when
@@ -259,6 +271,9 @@ int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d
  * results were handed out (the handle then stays on the streaming kernels).  Normally 0.  Results are the same either way;
  * a caller that shipped the device lists elsewhere before fetching (the gather above) ships them again when this number moved. */
 int urf_pm_sinkhorn_fallbacks(const urf_pm *h);
+/* guarded fast mode (precision 2), counters since build(): out[0] = pairs redone in the exact mode, out[1] = pairs
+ * processed, out[2] = pairs flagged by the threshold margin, out[3] = by the runner-up margin (n <= 8 values written) */
+int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */

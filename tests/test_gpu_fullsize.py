@@ -123,7 +123,7 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-PRECISIONS = [0, 1]
+PRECISIONS = [0, 1, 2]        # exact, fast, guarded fast (the mode bench.py times)
 
 
 @pytest.mark.parametrize("stage", ["ref", "sigma1"])
@@ -234,6 +234,52 @@ def test_bench_stream_keypoints_vs_the_reference_graph(U, F, sp_blob, H, W, prec
         assert len(diff) <= 4 and (not diff or (cut - nxt) <= 4e-6 * cut), (j, diff, cut, nxt)
         common = set(ref) & set(got)
         assert max(abs(ref[k] - got[k]) for k in common) < 1e-5
+
+
+def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp_blob, sg_blob, monkeypatch):
+    """the redo machinery of the guarded fast mode, forced: with an absurd error model every frame and every pair is flagged,
+    so every slot must come out of the exact pass (header word 1 set, features bit-identical to the oracle's) and every
+    match list must be the exact mode's, through the device batch path, the frame API and the pair API; the counters say so.
+    With the product constants the same frames are NOT flagged wholesale (rates: bench line)."""
+    import torch
+    H, W = 480, 640
+    frames, ofeats, olists = bench_stream_oracle(H, W)
+    monkeypatch.setenv("URF_GUARD_SP_ULPS", "1e7")
+    monkeypatch.setenv("URF_GUARD_SG_Z", "50")
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=4, precision=2)
+    assert sp.build(sp_blob)
+    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=3, precision=2)
+    assert pm.build(sg_blob)
+    monkeypatch.delenv("URF_GUARD_SP_ULPS")
+    monkeypatch.delenv("URF_GUARD_SG_Z")
+    d = torch.from_numpy(np.stack(frames[:4])).cuda()
+    slots = torch.zeros((4, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp.infer_device(d.data_ptr(), 4, H, W, slots.data_ptr())
+    sp.sync()
+    hdr = slots[:, :4].cpu().numpy().view(np.int32)
+    assert (hdr[:, 0] == 1000).all() and (hdr[:, 1] == 1).all()
+    for j in range(4):
+        f = F.slot_to_host(slots[j].data_ptr())
+        assert np.array_equal(f[:, :3], ofeats[j][:, :3]) and np.array_equal(f[:, 3:].astype(np.float32), ofeats[j][:, 3:].astype(np.float32))
+    st = sp.near_tie_reruns()
+    assert st["redone"] == 4 and st["frames"] == 4
+    pm.match_device_async([slots[j].data_ptr() for j in range(3)], [slots[j + 1].data_ptr() for j in range(3)], True)
+    got = pm.fetch(3)
+    for j in range(3):
+        assert got[j] == olists["ref"][j + 1], j
+    st = pm.near_tie_reruns()
+    assert st["redone"] == 3 and st["pairs"] == 3
+    # host APIs: one frame, one pair
+    assert np.array_equal(sp.infer(frames[5]), ofeats[5])
+    assert pm.MatchingPoints(ofeats[4], ofeats[5], True) == olists["ref"][5]
+    assert sp.near_tie_reruns()["redone"] == 5 and pm.near_tie_reruns()["redone"] == 4
+    # and an unforced handle leaves (nearly) everything to the fast pass
+    sp2 = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=4, precision=2)
+    assert sp2.build(sp_blob)
+    sp2.infer_device(d.data_ptr(), 4, H, W, slots.data_ptr())
+    sp2.sync()
+    assert sp2.near_tie_reruns()["frames"] == 4 and sp2.near_tie_reruns()["redone"] <= 1
 
 
 # ------------------------------------------------------------------ (d) seeded sweeps (tools/gpu_sweep*.py as tests)
@@ -362,6 +408,37 @@ def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(U, F, sg
     # the handles stay on the streaming kernels: same answers, no further fallback
     assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == [(q, t) for q, t, _ in want]
     assert pm.sinkhorn_fallbacks() == 1
+
+
+def test_resident_sinkhorn_give_up_is_not_sticky(U, F, sg_blob, monkeypatch):
+    """after a give-up the handle stays on the streaming kernels for a bounded number of batches (64, doubling per give-up;
+    2 here through the test knob) and then goes back to the resident kernel: a later fault is seen again -- it would not
+    be if the handle had stayed on the streaming kernels for good"""
+    import os
+    if os.environ.get("URF_SINKHORN_RESIDENT", "1") == "0":
+        pytest.skip("resident Sinkhorn switched off")
+    L = U._lib.lib()
+    rng = np.random.default_rng(78)
+    f0 = make_features(rng, 700)
+    f1 = make_features(rng, 650, planted_from=f0, m=400)
+    monkeypatch.setenv("URF_SINKHORN_BACKOFF", "2")
+    pm = F.PointMatching(F.SuperGlueConfig(), precision=1)
+    assert pm.build(sg_blob)
+    monkeypatch.delenv("URF_SINKHORN_BACKOFF")
+    want = [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)]
+    try:
+        assert L.urf_probe_sinkhorn_fault(1) == 0
+        assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == want and pm.sinkhorn_fallbacks() == 1
+        # two batches on the streaming kernels: a fault armed now is not consumed by this handle's launches ...
+        for _ in range(2):
+            assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == want
+        assert pm.sinkhorn_fallbacks() == 1
+        # ... and the handle is back on the resident kernel: the next fault is seen
+        assert L.urf_probe_sinkhorn_fault(1) == 0
+        assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == want
+        assert pm.sinkhorn_fallbacks() == 2
+    finally:
+        L.urf_probe_sinkhorn_fault(0)
 
 
 @pytest.mark.parametrize("prec", [0, 1])

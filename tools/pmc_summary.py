@@ -42,9 +42,13 @@ def per_kernel(db):
 def family(name):
     if "h2conv_kernel<true, true" in name:
         return "h2conv_kernel<pool,fuse1a>"      # conv1a+conv1b fused: its own line (bench.py's conv1 kernel)
+    if "conv_mfma_kernel<9, true, true" in name:
+        return "conv_mfma_kernel<9,pool,fuse1a>"  # the same in the exact mode
+    if "conv_mfma_kernel<1," in name or "gemm128_kernel" in name:
+        return "linear_exact"                    # the exact mode's linear layers (SuperGlue + the two 1x1 heads of SuperPoint)
     for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "sinkhorn_regs_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
-                "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel"):
+                "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel", "guard_compact_kernel", "nms_tie_kernel"):
         if key in name:
             return key
     return None
@@ -71,7 +75,9 @@ def main():
                   "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
                   "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
     pm_calls = max(fam.get("decode_kernel", {"launches": 0})["launches"], 1)      # one decode_kernel launch per matcher call
-    sp_calls = max(fam.get("topk_kernel", {"launches": 0})["launches"], 1)
+    # one topk_kernel launch per SuperPoint call -- two in the guarded fast mode (the gated redo pass), which also launches
+    # one guard_compact_kernel per call
+    sp_calls = max(fam.get("guard_compact_kernel", fam.get("topk_kernel", {"launches": 0}))["launches"], 1)
     json.dump({"command": cmd, "source_sha": kernel_source_sha(), "matcher_calls": pm_calls, "superpoint_calls": sp_calls, "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide reads tallied at half)",
                "scope": "L2-miss (fabric) traffic incl. Infinity-Cache hits; separate --pmc passes",
                "kernels": res}, open(out, "w"), indent=1)

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
+  if (a.gate && b >= a.gate[0]) return;
   const int cout_base = blockIdx.y * 64;
 
   int y0 = 0, x0 = 0;
@@ -411,14 +412,14 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   grid.y = (a.Cout + 63) / 64;
   grid.z = batch;
   const size_t lds = conv_lds_bytes(taps, fuse1a);
-  static bool attr_done = false;
-  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {  // > 64 KiB of dynamic LDS needs the opt-in
     const int mx = 72 * 1024;
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    attr_done = true;
+    attr_done.mark();
   }
   if (taps == 9 && fuse1a && pool) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, true>), grid, block, lds, st, a);

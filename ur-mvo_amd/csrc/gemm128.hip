@@ -133,10 +133,10 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(ConvArgs a) {
 int launch_gemm128(const ConvArgs &a, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 128) == 0 && (a.Cin % 64) == 0 && a.res == nullptr, "gemm128: unsupported shape");
   const size_t lds = sizeof(float) * (128 * G_IN_STRIDE + 64 * G_W_STRIDE);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {
     URF_HIP(hipFuncSetAttribute((const void *)gemm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    attr_done = true;
+    attr_done.mark();
   }
   dim3 grid((a.W + 127) / 128, a.Cout / 128, batch);
   hipLaunchKernelGGL(gemm128_kernel, grid, dim3(256), lds, st, a);

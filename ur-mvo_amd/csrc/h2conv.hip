@@ -156,11 +156,15 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
       // One batch of six per plane (twelve pieces in flight would not fit the 128-VGPR budget of this kernel, see above).
       // The planes are read through buffer resources: a 32-bit offset per piece instead of a 64-bit address.
       constexpr int PPP = CPH * CPW * 8, NB = (PPP + 255) / 256;      // pieces per plane (1440), loads per thread and plane
-      const unsigned plane_bytes = (unsigned)((size_t)gridDim.z * a.H * a.W * a.Cin * sizeof(_Float16));
-      const unsigned img_off = (unsigned)((size_t)b * a.H * a.W * a.Cin * sizeof(_Float16)) + (unsigned)(ch * 64 * sizeof(_Float16));
+      // one resource per image (base = the image, records = its bytes): offsets stay 32-bit whatever the batch is (a
+      // resource over the whole batch wraps at 4 GiB, i.e. at ~60 frames of 1500 x 1500 with 128 channels)
+      const size_t img_halfs = (size_t)a.H * a.W * a.Cin;
+      const unsigned plane_bytes = (unsigned)(img_halfs * sizeof(_Float16));
+      const unsigned img_off = (unsigned)(ch * 64 * sizeof(_Float16));
 #pragma unroll
       for (int plane = 0; plane < 2; ++plane) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(plane ? a.xl : a.xh), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((plane ? a.xl : a.xh) + (size_t)b * img_halfs), 0,
+                                                                            plane_bytes, 0x00020000);
         u32x4 sv[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -265,14 +269,14 @@ __global__ void __launch_bounds__(256, 4) h2conv_kernel(H2ConvArgs a) {
 int launch_h2conv(const H2ConvArgs &a, bool pool, bool fuse1a, bool outf32, int batch, hipStream_t st) {
   URF_CHECK((a.Cout % 64) == 0 && (fuse1a || (a.Cin % 64) == 0), "h2conv: unsupported shape");
   const size_t lds = sizeof(_Float16) * (2 * 2 * 64 * 64 + 2 * CPH * CPW * 64) + (fuse1a ? 12 * 20 * 4 : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {
     const int mx = 80 * 1024;
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)h2conv_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    attr_done = true;
+    attr_done.mark();
   }
   dim3 grid(((a.W + CTW - 1) / CTW) * ((a.H + CTH - 1) / CTH), a.Cout / 64, batch), block(256);
   if (fuse1a) hipLaunchKernelGGL((h2conv_kernel<true, true, false>), grid, block, lds, st, a);

@@ -373,12 +373,12 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     if (pad < 0) { const char *e = getenv("URF_H2GEMM_LDS_PAD"); pad = e ? atol(e) : 0; if (pad < 0 || pad > 96 * 1024) pad = 0; }
     const size_t lds = sizeof(_Float16) * 2 * 4 * GP + (size_t)pad;
     dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
+      attr_set.mark();
     }
     static int nt = -1;
     if (nt < 0) { const char *e = getenv("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }

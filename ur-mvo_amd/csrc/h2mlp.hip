@@ -209,10 +209,10 @@ __global__ void __launch_bounds__(512, 2) h2mlp_kernel(MlpArgs a) {
 int launch_h2mlp(_Float16 *xh, _Float16 *xl, const _Float16 *oh, const _Float16 *ol, const _Float16 *w1h,
                  const _Float16 *w1l, const _Float16 *w2h, const _Float16 *w2l, const float *b1, const float *b2,
                  const int *counts, int rows, int nimg, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     URF_HIP(hipFuncSetAttribute((const void *)h2mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M_LDS_BYTES));
-    attr_set = true;
+    attr_set.mark();
   }
   MlpArgs a;
   a.xh = xh; a.xl = xl; a.oh = oh; a.ol = ol; a.w1h = w1h; a.w1l = w1l; a.w2h = w2h; a.w2l = w2l;

@@ -647,10 +647,10 @@ extern "C" int urf_solve_pnp_ransac(urf_pose *h, const urf_pnp_config *cfg, int 
   URF_HIP(hipMemcpyAsync(h->d_obj, obj, (size_t)B * cap * 12, hipMemcpyHostToDevice, st));
   URF_HIP(hipMemcpyAsync(h->d_img, img, (size_t)B * cap * 8, hipMemcpyHostToDevice, st));
   const size_t lds = sizeof(double) * (288 + 18) * HT;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     URF_HIP(hipFuncSetAttribute((const void *)pnp_hypothesis_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3((its + HT - 1) / HT, B), dim3(HT), lds, st, cam, cfg->seed, its, h->d_counts,
                      h->d_obj, h->d_img, cap, h->d_hyp, h->d_ok);

@@ -26,12 +26,16 @@ int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u
 size_t sinkhorn_resident_xin_granules(int maxP);
 size_t sinkhorn_resident_xbc_granules(int maxP);
 int sinkhorn_resident_enabled();
+int sinkhorn_resident_supported(int device);
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
-                             void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st);
+                             void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
+                             hipStream_t st);
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
-                  double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int P,
-                  hipStream_t st);
+                  double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
+                  int P, hipStream_t st);
+int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st);
+int launch_guard_merge(const int *gflags, const void *rm, const int *rn, void *fm, int *fn, int P, hipStream_t st);
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
                   float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
                   double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
@@ -43,6 +47,10 @@ enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC
 }  // namespace urf
 using namespace urf;
 static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e) / sqrt(64), folded into the Q projection
+// guarded fast mode, matcher: margin (log domain) within which the fast mode's log-assignment may differ from the exact
+// mode's on entries that can become a match; measured maximum on both bench streams times a safety factor (DESIGN.md
+// "Guarded fast mode", tools/gpu_margins.py)
+static const float kGuardSgZ = 2e-4f;
 
 struct urf_pm {
   urf_sg_config cfg;
@@ -79,7 +87,10 @@ struct urf_pm {
   unsigned rs_salt = 0;
   int *rs_err = nullptr, *h_rs_err = nullptr;
   bool rs_on = false;
+  bool rs_wanted = false;                     // the handle uses the resident kernel unless it is backing off after a give-up
   int rs_fallbacks = 0;                       // launches that gave up and were redone with the streaming kernels
+  int rs_backoff = 0, rs_backoff_next = 64;   // streaming batches left before the resident kernel is tried again / after the next give-up
+  size_t rs_xin_bytes = 0, rs_xbc_bytes = 0;
   int last_P = 0; bool last_Z = false, last_ransac = false;   // what the last pm_pipeline ran (pm_check_resident redoes its tail)
   int *mi0 = nullptr, *mi1 = nullptr, *idx0 = nullptr, *idx1 = nullptr, *nmatch = nullptr, *nfinal = nullptr;
   float *mv0 = nullptr, *mv1 = nullptr;
@@ -99,6 +110,14 @@ struct urf_pm {
   float stage_ms[PT_COUNT + 1];
   bool ev_valid = false;
   int pending_P = 0;     // pairs of the batch enqueued by urf_match_device_async and not fetched yet (0 = none)
+  // guarded fast mode (precision 2): per-pair guard words (device + pinned mirror), the masked counts and the result
+  // buffers of the exact redo, counters ([0] pairs redone, [1] pairs seen (host side), [2] threshold margin, [3] runner-up)
+  bool fast = false, guarded = false;
+  int *g_flags = nullptr, *h_gflags = nullptr, *counts_r = nullptr, *r_nfinal = nullptr;
+  urf_dmatch *r_fmatches = nullptr;
+  unsigned long long *g_stats = nullptr;
+  unsigned long long pairs_seen = 0;
+  float g_z = 0.0f;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -130,7 +149,9 @@ extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
     URF_CHECK(h->r_conf < 1.0, "ransac_confidence must be below 1");
   }
   h->precision = cfg->precision;
-  URF_CHECK(h->precision == 0 || h->precision == 1, "precision must be 0 (exact fp32) or 1 (fast split-f16)");
+  URF_CHECK(h->precision >= 0 && h->precision <= 2, "precision must be 0 (exact fp32), 1 (fast split-f16) or 2 (fast, guarded)");
+  h->fast = h->precision >= 1;
+  h->guarded = h->precision == 2;
   *out = h;
   return 0;
 }
@@ -183,7 +204,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     h->L[l].wm = put(wm, 65536); h->L[l].bm = put(bm, 256);
     h->L[l].w1 = put(w1, 262144); h->L[l].b1 = put(b1, 512);
     h->L[l].w2 = put(w2, 131072); h->L[l].b2 = put(b2, 256);
-    if (h->precision == 1) {
+    if (h->fast) {
       // fast mode folds the merge layer into the first MLP layer (both linear, nothing in between):
       //   W0 [x ; Wm o + bm] + b0 = W0x x + (W0m Wm) o + (b0 + W0m bm)
       // ... and log2(e) / sqrt(64) into the Q projection: the attention kernel then gets its scores already in
@@ -211,7 +232,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_HIP(hipMemcpy(h->d_w, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
 
   const size_t P = h->maxP, NI = 2 * P;
-  if (h->precision == 1) {
+  if (h->fast) {
     // W^T [cout][cin] as (hi, lo) f16 planes for h2gemm
     std::vector<_Float16> wh, wl;
     auto putT = [&](const float *w, int cin, int cout) {  // w: [cin][cout] fp32
@@ -285,7 +306,25 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     if (dalloc(&h->oh, NI * NP * 256) || dalloc(&h->ol, NI * NP * 256)) return -1;
     if (dalloc(&h->hh, NI * NP * 512) || dalloc(&h->hl, NI * NP * 512)) return -1;
     h->rs_on = sinkhorn_resident_enabled() != 0;
+    if (h->rs_on && !sinkhorn_resident_supported(h->device)) {
+      // fewer CUs than the 32 workgroups of a pair (a partitioned or masked device): the streaming kernels, not an error
+      fprintf(stderr, "liburf_front: device %d has fewer than 32 CUs, the chip-resident Sinkhorn is off (streaming kernels)\n", h->device);
+      h->rs_on = false;
+    }
+    h->rs_wanted = h->rs_on;
+    if (const char *e = getenv("URF_SINKHORN_BACKOFF")) { const int v = atoi(e); if (v >= 1) h->rs_backoff_next = v; }   // tests
+    h->rs_xin_bytes = sinkhorn_resident_xin_granules((int)P) * sizeof(unsigned long long);
+    h->rs_xbc_bytes = sinkhorn_resident_xbc_granules((int)P) * sizeof(unsigned long long);
     if (dalloc(&h->rs_xin, sinkhorn_resident_xin_granules((int)P)) || dalloc(&h->rs_xbc, sinkhorn_resident_xbc_granules((int)P))) return -1;
+  }
+  if (h->guarded) {
+    if (dalloc(&h->g_flags, P) || dalloc(&h->counts_r, NI) || dalloc(&h->r_nfinal, P) || dalloc(&h->r_fmatches, P * NP) ||
+        dalloc(&h->g_stats, 8))
+      return -1;
+    URF_HIP(hipHostMalloc((void **)&h->h_gflags, P * sizeof(int), hipHostMallocDefault));
+    memset(h->h_gflags, 0, P * sizeof(int));
+    const char *e = getenv("URF_GUARD_SG_Z");
+    h->g_z = e ? (float)atof(e) : kGuardSgZ;
   }
   if (dalloc(&h->rs_err, 4)) return -1;
   URF_HIP(hipHostMalloc((void **)&h->h_rs_err, 4 * sizeof(int), hipHostMallocDefault));
@@ -361,8 +400,10 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
-                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets};
+                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
+                    h->g_flags, h->counts_r, h->r_nfinal, h->r_fmatches, h->g_stats};
     for (void *p : bufs) (void)hipFree(p);
+    if (h->h_gflags) (void)hipHostFree(h->h_gflags);
     (void)hipHostFree(h->h_matches);
     (void)hipHostFree(h->h_n);
     (void)hipHostFree(h->h_rs_err);
@@ -463,25 +504,20 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
   return 0;
 }
 
-static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof);
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast, bool redo);
 
-// the whole matching pipeline for P pairs whose inputs (counts, kin, kxy, x) are in place
-static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
-  hipStream_t st = h->st;
-  const int NI = 2 * P;
-  const bool prof = urf::g_profiling != 0;
-  auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
-  mark(PT_KENC);
-  // keypoint encoder: 4(3)->32->64->128->256->256, + descriptors
+// keypoint encoder: 4(3)->32->64->128->256->256, + descriptors; fp32 in every mode
+static int pm_kenc(urf_pm *h, int NI) {
   if (sg_linear(h, NI, h->kin, 4, 4, nullptr, 0, 0, h->kw[0], h->kb[0], 32, h->tA, 256, true, nullptr)) return -1;
   if (sg_linear(h, NI, h->tA, 256, 32, nullptr, 0, 0, h->kw[1], h->kb[1], 64, h->tB, 256, true, nullptr)) return -1;
   if (sg_linear(h, NI, h->tB, 256, 64, nullptr, 0, 0, h->kw[2], h->kb[2], 128, h->tA, 256, true, nullptr)) return -1;
   if (sg_linear(h, NI, h->tA, 256, 128, nullptr, 0, 0, h->kw[3], h->kb[3], 256, h->tB, 256, true, nullptr)) return -1;
-  if (sg_linear(h, NI, h->tB, 256, 256, nullptr, 0, 0, h->kw[4], h->kb[4], 256, h->x, 256, false, h->x)) return -1;
-  mark(PT_GNN);
-  if (h->precision == 1) {
-    if (pm_gnn_fast(h, NI, prof)) return -1;
-  } else
+  return sg_linear(h, NI, h->tB, 256, 256, nullptr, 0, 0, h->kw[4], h->kb[4], 256, h->x, 256, false, h->x);
+}
+
+// the 18 GNN layers and the final projection in the exact mode, in place on h->x (-> h->mdesc)
+static int pm_gnn_exact(urf_pm *h, int NI, bool prof) {
+  hipStream_t st = h->st;
   for (int l = 0; l < SG_LAYERS; ++l) {
     if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->L[l].wqkv, h->L[l].bqkv, 768, h->qkv, 768, false, nullptr))
       return -1;
@@ -495,60 +531,127 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
     if (sg_linear(h, NI, h->hid, 512, 512, nullptr, 0, 0, h->L[l].w2, h->L[l].b2, 256, h->x, 256, false, h->x))
       return -1;
   }
+  return 0;
+}
+
+// the whole matching pipeline for P pairs whose inputs (counts, kin, kxy, x) are in place
+static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
+  hipStream_t st = h->st;
+  const int NI = 2 * P;
+  const bool prof = urf::g_profiling != 0;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
+  mark(PT_KENC);
+  if (pm_kenc(h, NI)) return -1;
+  mark(PT_GNN);
+  if (h->fast) {
+    if (pm_gnn_fast(h, NI, prof)) return -1;
+  } else if (pm_gnn_exact(h, NI, prof)) return -1;
   mark(PT_SCORE);
-  if (h->precision == 1) {
+  if (h->fast) {
     if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->hwf, h->bf, 256, h->mdesc, nullptr, nullptr, 256, false,
                   nullptr, false))
       return -1;
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
-  return pm_tail(h, P, want_Z, ransac, prof);
+  h->pairs_seen += (unsigned long long)P;
+  return pm_tail(h, P, want_Z, ransac, prof, h->fast, false);
 }
 
 // scores -> Sinkhorn -> decode -> outlier stage, from the projected descriptors h->mdesc (which stay in place until the next
-// pm_pipeline of this handle: pm_check_resident can run this again)
-static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof) {
+// pm_pipeline of this handle: pm_check_resident can run this again).  fast: the fast mode's Sinkhorn and, when the handle is
+// guarded, the near-tie guard of the decode.  redo: the exact pass of the guarded mode over the flagged pairs -- the final
+// lists go to the redo buffers (the fast lists of the other pairs stay where they are).
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast, bool redo) {
   hipStream_t st = h->st;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
-  (void)hipEventRecord(h->ev_sink, st);
-  if (h->precision == 1 && h->rs_on) {
+  if (!redo) (void)hipEventRecord(h->ev_sink, st);
+  if (fast && h->rs_on) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
-    if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, &h->rs_salt,
-                                 h->rs_err, h->device, st))
+    if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
+                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, st))
       return -1;
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, h->precision == 1, st)) return -1;
+  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, fast, st)) return -1;
   mark(PT_DECODE);
+  const bool guard = fast && h->guarded && !redo;
+  if (guard) URF_HIP(hipMemsetAsync(h->g_flags, 0, P * sizeof(int), st));
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
                     h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,
-                    want_Z ? h->Z : nullptr, P, st))
+                    want_Z ? h->Z : nullptr, guard ? h->g_flags : nullptr, h->g_z, P, st))
     return -1;
+  if (guard) URF_HIP(hipMemcpyAsync(h->h_gflags, h->g_flags, P * sizeof(int), hipMemcpyDeviceToHost, st));
   mark(PT_RANSAC);
   if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
-                    h->cfg.ransac_seed, h->r_iters, h->r_sigma, h->r_conf, nullptr, ransac ? 1 : 0, h->matches, h->fmatches,
-                    h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
+                    h->cfg.ransac_seed, h->r_iters, h->r_sigma, h->r_conf, nullptr, ransac ? 1 : 0, h->matches,
+                    redo ? h->r_fmatches : h->fmatches, redo ? h->r_nfinal : h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
     return -1;
   mark(PT_COUNT);
   return 0;
 }
 
+// Guarded fast mode, after the batch's results have been waited for (and after pm_check_resident): pairs whose guard word is set
+// are redone in the exact mode -- the 18 layers from the encoded keypoints (h->x still holds them: the fast layers work on their
+// own f16 planes), log-domain Sinkhorn, decode, outlier stage -- with the counts of all other pairs masked to zero, so that every
+// kernel skips them.  P == 1 (host API, `in_place`): the exact results simply replace the fast ones, Z and index vectors included.
+// Returns 1 when lists were rewritten (the caller repeats its copies), 0 when no pair was flagged.
+static int pm_guard_redo(urf_pm *h, bool in_place) {
+  if (!h->guarded || h->last_P < 1) return 0;
+  const int P = h->last_P;
+  bool any = false;
+  for (int p = 0; p < P; ++p) any = any || h->h_gflags[p] != 0;
+  if (!any) return 0;
+  hipStream_t st = h->st;
+  if (launch_guard_counts(h->g_flags, h->counts, h->counts_r, P, h->g_stats, st)) return -1;
+  int *full = h->counts;
+  h->counts = h->counts_r;
+  int rc = pm_gnn_exact(h, 2 * P, false);
+  if (!rc) rc = sg_linear(h, 2 * P, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr);
+  if (!rc) rc = pm_tail(h, P, h->last_Z, h->last_ransac, false, false, !in_place);
+  h->counts = full;
+  if (rc) return -1;
+  if (!in_place && launch_guard_merge(h->g_flags, h->r_fmatches, h->r_nfinal, h->fmatches, h->nfinal, P, st)) return -1;
+  URF_HIP(hipStreamSynchronize(st));
+  for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
+  return 1;
+}
+
 // After the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?  (Its workgroups spin on
 // each other, so a launch whose 32 workgroups per pair do not become co-resident within 0.25 s -- another process holding
-// CUs, say -- abandons the exchange.)  Then the handle goes back to the streaming kernels for good and the tail of the
-// batch is redone with them from the projected descriptors, synchronously.  Returns 1 when the device results were
-// rewritten that way (the caller repeats its copies), 0 when there was nothing to do.
+// CUs, say -- abandons the exchange.)  Then the tail of the batch is redone with the streaming kernels from the projected
+// descriptors, synchronously, and the handle stays on them for the next `rs_backoff_next` batches (64, doubling with every
+// further give-up up to 4096) before it tries the resident kernel again: a transient loss of CUs costs seconds, not the
+// rest of the process.  Said once per give-up on stderr.  Returns 1 when the device results were rewritten that way (the
+// caller repeats its copies), 0 when there was nothing to do.
 static int pm_check_resident(urf_pm *h) {
-  if (!(h->h_rs_err && h->h_rs_err[0] != 0)) return 0;
+  if (!(h->h_rs_err && h->h_rs_err[0] != 0)) {
+    if (h->rs_wanted && !h->rs_on && h->rs_backoff > 0 && --h->rs_backoff == 0) h->rs_on = true;   // try again with the next batch
+    return 0;
+  }
   h->h_rs_err[0] = 0;
   URF_HIP(hipMemsetAsync(h->rs_err, 0, sizeof(int), h->st));
   h->rs_on = false;
   h->rs_fallbacks += 1;
+  h->rs_backoff = h->rs_backoff_next;
+  h->rs_backoff_next = h->rs_backoff_next < 4096 ? h->rs_backoff_next * 2 : 4096;
+  fprintf(stderr, "liburf_front: the chip-resident Sinkhorn launch of a %d-pair batch gave up (its workgroups did not become "
+          "co-resident within 0.25 s); batch redone with the streaming kernels, which this handle keeps for the next %d batches "
+          "(give-up %d of this handle)\n", h->last_P, h->rs_backoff, h->rs_fallbacks);
   URF_CHECK(h->last_P >= 1, "resident Sinkhorn gave up and there is no batch to redo");
-  if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false)) return -1;
+  if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast, false)) return -1;
   URF_HIP(hipStreamSynchronize(h->st));
   return 1;
+}
+
+// after a batch's results have been waited for: the resident Sinkhorn's give-up, then the guarded mode's near-ties.
+// > 0: device results were rewritten (the caller repeats its copies); < 0: error
+static int pm_after_wait(urf_pm *h, bool in_place) {
+  const int r1 = pm_check_resident(h);
+  if (r1 < 0) return -1;
+  const int r2 = pm_guard_redo(h, in_place);
+  if (r2 < 0) return -1;
+  return r1 + r2;
 }
 
 static void pm_collect_times(urf_pm *h) {
@@ -618,7 +721,7 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
   if (pm_upload_pair(h, f0, nullptr, n0, f1, nullptr, n1)) return -1;
   if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
   if (pm_pipeline(h, 1, Zout != nullptr, false)) return -1;
-  for (int pass = 0; pass < 2; ++pass) {   // a second pass only after pm_check_resident redid the tail
+  for (int pass = 0; pass < 2; ++pass) {   // a second pass only after a redo (resident Sinkhorn give-up, near-tie guard)
     URF_HIP(hipMemcpyAsync(idx0, h->idx0, n0 * sizeof(int), hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipMemcpyAsync(idx1, h->idx1, n1 * sizeof(int), hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipMemcpyAsync(ms0, h->ms0, n0 * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -628,7 +731,7 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
                                hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipStreamSynchronize(h->st));
     if (pass == 0) pm_collect_times(h);
-    const int redo = pm_check_resident(h);
+    const int redo = pm_after_wait(h, true);
     if (redo < 0) return -3;
     if (redo == 0) break;
   }
@@ -652,7 +755,7 @@ extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, 
     URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipStreamSynchronize(h->st));
     if (pass == 0) pm_collect_times(h);
-    const int redo = pm_check_resident(h);
+    const int redo = pm_after_wait(h, true);
     if (redo < 0) return -3;
     if (redo == 0) break;
   }
@@ -688,6 +791,18 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
 
 extern "C" int urf_pm_sinkhorn_fallbacks(const urf_pm *h) { return h ? h->rs_fallbacks : -1; }
 
+extern "C" int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n) {
+  URF_CHECK(h && h->built && out && n >= 1, "urf_pm_near_tie_reruns: bad argument");
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (h->guarded) {
+    URF_HIP(hipSetDevice(h->device));
+    URF_HIP(hipMemcpy(v, h->g_stats, sizeof(v), hipMemcpyDeviceToHost));   // written by redo passes only, which are synchronous
+  }
+  v[1] = h->pairs_seen;
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 0;
+}
+
 extern "C" int urf_pm_sync(urf_pm *h) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_HIP(hipSetDevice(h->device));
@@ -704,9 +819,9 @@ extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nou
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
   {
-    const int redo = pm_check_resident(h);
+    const int redo = pm_after_wait(h, false);
     if (redo < 0) return -3;
-    if (redo > 0) {   // the tail was redone with the streaming kernels: fetch the rewritten lists
+    if (redo > 0) {   // the tail was redone (streaming Sinkhorn after a give-up, or flagged pairs in the exact mode): fetch the rewritten lists
       URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
       URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
       URF_HIP(hipStreamSynchronize(h->st));

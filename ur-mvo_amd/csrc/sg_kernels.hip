@@ -448,9 +448,13 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
 // Z_ij = ((C_ij + u_i) + v_j) - norm ; row / column argmax over the inner
 // n0 x n1 block with first-max-wins (max_matrix, src/super_glue.cpp:314-343).
 // ROWS: wave per i on C; else wave per j on Ct.  Optionally writes Z rows.
-template <bool ROWS>
+// GUARD (guarded fast mode): also the runner-up of every row / column; a pair is flagged (gflags[p] != 0) when a best
+// entry that can become a match -- at or above the matching threshold minus the margin gz (log domain) -- is closer than
+// gz to the threshold (bit 0) or closer than 2 gz to its runner-up (bit 1): decisions the exact mode could take differently.
+template <bool ROWS, bool GUARD>
 __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const float *M, const float *u, const float *v,
-                                                     int *midx, float *mval, float *Zout) {
+                                                     int *midx, float *mval, float *Zout, int *gflags, float gz,
+                                                     float log_thr) {
   const int p = blockIdx.y;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int R = ROWS ? n0 : n1, Cn = ROWS ? n1 : n0;
@@ -466,21 +470,32 @@ __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const fl
   }
   if (row >= R) return;
   // reference semantics (max_matrix): value starts at -FLT_MAX, index 0, strict '<'
-  float best = -FLT_MAX;
+  float best = -FLT_MAX, second = -FLT_MAX;
   int bi = 0;
   for (int c = lane; c < Cn; c += 64) {
     const float z = ROWS ? (((mr[c] + up[row]) + vp[c]) - norm) : (((mr[c] + up[c]) + vp[row]) - norm);
-    if (best < z) { best = z; bi = c; }
+    if (best < z) { if (GUARD) second = best; best = z; bi = c; }
+    else if (GUARD && second < z) second = z;
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
     const float ob = __shfl_xor(best, s, 64);
     const int oi = __shfl_xor(bi, s, 64);
+    if (GUARD) {
+      const float os = __shfl_xor(second, s, 64);
+      second = fmaxf(fmaxf(second, os), fminf(best, ob));   // the loser of the two bests is a runner-up candidate
+    }
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
   if (lane == 0) {
     midx[(size_t)p * NP + row] = bi;
     mval[(size_t)p * NP + row] = best;
+    if (GUARD && best >= log_thr - gz) {
+      int bits = 0;
+      if (best - log_thr <= gz) bits |= 1;
+      if (best - second <= 2.0f * gz) bits |= 2;
+      if (bits) atomicOr(&gflags[p], bits);
+    }
   }
 }
 
@@ -561,6 +576,39 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
   if (i == 0) nmatch[p] = total;
 }
 
+// ----------------------------------------------------------------- guard redo
+// counts of the pairs to redo in the exact mode (the others get 0: every kernel of the path skips them); stats: [0] pairs
+// redone, [1] pairs seen, [2] flagged by the threshold margin, [3] by the runner-up margin
+__global__ void guard_counts_kernel(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats) {
+  const int i = threadIdx.x;
+  if (i < 2 * P) counts_r[i] = gflags[i >> 1] ? counts[i] : 0;
+  if (i == 0) {
+    int n = 0, a = 0, b = 0;
+    for (int p = 0; p < P; ++p) { n += gflags[p] != 0; a += (gflags[p] & 1) != 0; b += (gflags[p] & 2) != 0; }
+    atomicAdd(&stats[0], (unsigned long long)n);
+    atomicAdd(&stats[2], (unsigned long long)a);
+    atomicAdd(&stats[3], (unsigned long long)b);
+  }
+}
+// the redone pairs' lists replace the fast ones
+__global__ void __launch_bounds__(256) guard_merge_kernel(const int *gflags, const DMatch *rm, const int *rn, DMatch *fm, int *fn) {
+  const int p = blockIdx.x;
+  if (!gflags[p]) return;
+  const int n = rn[p];
+  for (int i = threadIdx.x; i < n; i += 256) fm[(size_t)p * NP + i] = rm[(size_t)p * NP + i];
+  if (threadIdx.x == 0) fn[p] = n;
+}
+int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st) {
+  hipLaunchKernelGGL(guard_counts_kernel, dim3(1), dim3(256), 0, st, gflags, counts, counts_r, P, stats);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_guard_merge(const int *gflags, const void *rm, const int *rn, void *fm, int *fn, int P, hipStream_t st) {
+  hipLaunchKernelGGL(guard_merge_kernel, dim3(P), dim3(256), 0, st, gflags, (const DMatch *)rm, rn, (DMatch *)fm, fn);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ launchers
 int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int height, int *counts, float *kin,
                          float *kxy, float *x, hipStream_t st) {
@@ -609,10 +657,16 @@ int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1,
                   int *idx0, int *idx1, double *ms0, double *ms1, void *matches, float *pts0, float *pts1,
-                  int *nmatch, float *Zout, int P, hipStream_t st) {
+                  int *nmatch, float *Zout, int *gflags, float gz, int P, hipStream_t st) {
   const dim3 grid((NP + 1 + 3) / 4, P), block(256);
-  hipLaunchKernelGGL((argmax_kernel<true>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout);
-  hipLaunchKernelGGL((argmax_kernel<false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr);
+  const float log_thr = thresh > 0.0 ? (float)log(thresh) : -FLT_MAX;
+  if (gflags) {
+    hipLaunchKernelGGL((argmax_kernel<true, true>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr);
+    hipLaunchKernelGGL((argmax_kernel<false, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr);
+  } else {
+    hipLaunchKernelGGL((argmax_kernel<true, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr);
+    hipLaunchKernelGGL((argmax_kernel<false, false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr);
+  }
   hipLaunchKernelGGL(decode_kernel, dim3(P), dim3(1024), 0, st, counts, mi0, mv0, mi1, thresh, kxy, idx0,
                      idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch);
   URF_HIP(hipGetLastError());

@@ -721,8 +721,16 @@ long long *g_rs_stamps = nullptr;   // set by urf_probe_sinkhorn_stamps
 
 static std::atomic<int> g_rs_fault{0};   // urf_probe_sinkhorn_fault: that many launches report a give-up (tests of the recovery)
 
+// can this device hold a pair's 32 workgroups at all?  (no: the handle uses the streaming kernels, sg_api.hip)
+int sinkhorn_resident_supported(int device) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return cus >= RS_WG ? 1 : 0;
+}
+
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
-                             void *xin, void *xbc, unsigned *salt, int *err, int device, hipStream_t st) {
+                             void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
+                             hipStream_t st) {
   URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
   URF_CHECK(iters >= 1 && iters < 4096, "sinkhorn_resident: iterations %d outside [1, 4095]", iters);
   RsDevice &d = g_rs_dev[device];
@@ -757,13 +765,21 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     const int want = knob >= 1 ? knob : (group >= 2 ? group / 2 : group);
     if (want < group) group = want;
   }
-  URF_CHECK(group >= 1, "sinkhorn_resident: the device has %d CUs, a pair needs %d", d.cus, RS_WG);
+  URF_CHECK(group >= 1, "sinkhorn_resident: the device has %d CUs, a pair needs %d (sinkhorn_resident_supported)", d.cus, RS_WG);
   for (int p0 = 0; p0 < P; p0 += group) {
     RsArgs a;
     a.counts = counts; a.C = C; a.u = u; a.v = v; a.alpha = alpha; a.iters = iters;
     a.pair0 = p0; a.npairs = (P - p0 < group) ? (P - p0) : group;
     a.xin = (u64 *)xin; a.xbc = (u64 *)xbc;
-    *salt = (*salt % 0xFFFFFu) + 1;           // tags are (salt << 12 | iteration), never 0
+    if (*salt >= 0xFFFFFu) {
+      // the 20-bit salt wraps: a granule that has not been rewritten since its tag was last current (the regions of pairs the
+      // handle has not used for a million launches) could pass for fresh.  Clear every tag, in stream order, and start over.
+      URF_HIP(hipStreamWaitEvent(st, d.last, 0));
+      URF_HIP(hipMemsetAsync(xin, 0, xin_bytes, st));
+      URF_HIP(hipMemsetAsync(xbc, 0, xbc_bytes, st));
+      *salt = 0;
+    }
+    *salt = *salt + 1;                        // tags are (salt << 12 | iteration), never 0
     a.salt = *salt; a.err = err;
     {
       static int near_knob = -1;

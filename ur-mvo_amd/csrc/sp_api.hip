@@ -7,6 +7,7 @@
 #include "h2.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -25,20 +26,34 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-const char *last_error() { return g_err; }
+// a reader gets a snapshot taken under the lock (its own thread-local copy): never a message another thread is half-way
+// through writing
+const char *last_error() {
+  static thread_local char snap[sizeof(g_err)];
+  std::lock_guard<std::mutex> lock(g_err_mu);
+  memcpy(snap, g_err, sizeof(g_err));
+  snap[sizeof(snap) - 1] = 0;
+  return snap;
+}
 int g_profiling = 0;
+// guarded fast mode, SuperPoint: error model of a fast-mode score, delta * s * (1 - s) + ulps * ulp(s) (sp_kernels.hip);
+// measured maxima on both bench streams times a safety factor (DESIGN.md "Guarded fast mode", tools/gpu_margins.py)
+static const float kGuardSpDelta = 2e-5f, kGuardSpUlps = 4.0f;
 
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
-int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, hipStream_t st);
+int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, const int *gate, hipStream_t st);
 int launch_nms(const float *heat, uint8_t *mask, uint8_t *supp, float *ss, float *out, int H, int W, int B,
-               hipStream_t st);
+               const int *gate, const SpGuard &g, float thr_lo, hipStream_t st);
 int launch_select(const float *scores, int H, int W, double thr, int border, const uint8_t *mask, int *counts,
                   float *cand_score, int *cand_idx, int cand_cap, int *cand_n, int k, float *kp_score, int *kp_idx,
-                  int *kp_n, int B, hipStream_t st);
+                  int *kp_n, int B, const int *gate, const SpGuard &g, hipStream_t st);
 int select_nchunk(int H, int W);
-int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, hipStream_t st);
+int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, const int *gate, int ncell_frame,
+                     hipStream_t st);
 int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, const int *kp_idx, const int *kp_n,
-                  int Ws, double *feat, float *slots, int B, hipStream_t st);
+                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, hipStream_t st);
+int launch_guard_compact(const int *flags, int B, const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs, int *gate,
+                         unsigned long long *stats, hipStream_t st);
 
 struct ConvSpec { int cin, cout, k; };
 static const ConvSpec kSpConv[12] = {{1, 64, 3},    {64, 64, 3},   {64, 64, 3},   {64, 64, 3},
@@ -51,6 +66,15 @@ enum { ST_UPLOAD = 0, ST_CONV1, ST_CONV2A, ST_CONV2B, ST_CONV3A, ST_CONV3B, ST_C
 }  // namespace urf
 
 using namespace urf;
+
+struct SpArena {
+  float *a1 = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
+        *a4b = nullptr, *apd = nullptr, *logits = nullptr, *ddb = nullptr, *desc = nullptr;
+  float *heat = nullptr, *scores = nullptr, *ss = nullptr;
+  uint8_t *mask = nullptr, *supp = nullptr;
+  int *counts = nullptr, *cand_idx = nullptr, *cand_n = nullptr, *kp_idx = nullptr, *kp_n = nullptr;
+  float *cand_score = nullptr, *kp_score = nullptr;
+};
 
 struct urf_sp {
   urf_sp_config cfg;
@@ -70,14 +94,16 @@ struct urf_sp {
   size_t hw_off[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, Pa||Da
   size_t hpb_off = 0, hdb_off = 0;   // fast mode 1x1 heads: convPb [128 (65 used)][256], convDb [256][256] planes
   size_t bpb128_off = 0;             // convPb bias padded to 128
-  // activations
-  float *a1 = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
-        *a4b = nullptr, *apd = nullptr, *logits = nullptr, *ddb = nullptr, *desc = nullptr;
-  float *heat = nullptr, *scores = nullptr, *ss = nullptr;
-  uint8_t *mask = nullptr, *supp = nullptr, *d_img = nullptr, *d_usermask = nullptr;
-  int *counts = nullptr, *cand_idx = nullptr, *cand_n = nullptr, *kp_idx = nullptr, *kp_n = nullptr;
-  float *cand_score = nullptr, *kp_score = nullptr;
+  // activations and selection scratch of a batch: A = the handle's arena; R = the arena of the frames the guarded fast mode
+  // (precision 2) redoes in the exact mode
+  SpArena A, R;
+  uint8_t *d_img = nullptr, *d_usermask = nullptr;
   int cand_cap = 0;
+  // guarded fast mode: guard words, threshold-band scratch, redo list (gate), images of the frames to redo, counters
+  int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr;
+  uint8_t *g_img = nullptr;
+  unsigned long long *g_stats = nullptr;
+  float g_delta = 0.0f, g_ulps = 0.0f;
   double *d_feat = nullptr;
   float *d_slots = nullptr;
   // pinned host staging
@@ -121,7 +147,7 @@ extern "C" int urf_sp_create(const urf_sp_config *cfg, urf_sp **out) {
   h->maxH = cfg->max_height > 0 ? cfg->max_height : 1500;
   h->maxW = cfg->max_width > 0 ? cfg->max_width : 1500;
   h->precision = cfg->precision;
-  URF_CHECK(h->precision == 0 || h->precision == 1, "precision must be 0 (exact fp32) or 1 (fast split-f16)");
+  URF_CHECK(h->precision >= 0 && h->precision <= 2, "precision must be 0 (exact fp32), 1 (fast split-f16) or 2 (fast, guarded)");
   *out = h;
   return 0;
 }
@@ -191,7 +217,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_HIP(hipMalloc((void **)&h->d_wts, host.size() * sizeof(float)));
   URF_HIP(hipMemcpy(h->d_wts, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
 
-  if (h->precision == 1) {
+  if (h->precision >= 1) {
     std::vector<_Float16> wh, wl;
     auto putc = [&](const float *w, int cin, int cout, int coff, int ctot, size_t base) {
       // w: [9][cin][cout] fp32 -> planes [9][ctot][cin] at rows coff..coff+cout
@@ -246,32 +272,47 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   const size_t Hs = H8 * 8, Ws = W8 * 8;
   if (dalloc(&h->d_img, B * H * W)) return -1;
   if (dalloc(&h->d_usermask, H * W)) return -1;
-  if (dalloc(&h->a1, B * H2 * W2 * 64)) return -1;
-  if (dalloc(&h->a2a, B * H2 * W2 * 64)) return -1;
-  if (dalloc(&h->a2b, B * H4 * W4 * 64)) return -1;
-  if (dalloc(&h->a3a, B * H4 * W4 * 128)) return -1;
-  if (dalloc(&h->a3b, B * H8 * W8 * 128)) return -1;
-  if (dalloc(&h->a4a, B * H8 * W8 * 128)) return -1;
-  if (dalloc(&h->a4b, B * H8 * W8 * 128)) return -1;
-  if (dalloc(&h->apd, B * H8 * W8 * 512)) return -1;
-  if (dalloc(&h->logits, B * H8 * W8 * (h->precision == 1 ? 128 : 68))) return -1;
-  if (dalloc(&h->ddb, B * H8 * W8 * 256)) return -1;
-  if (dalloc(&h->desc, B * H8 * W8 * 256)) return -1;
-  if (dalloc(&h->heat, B * Hs * Ws)) return -1;
-  if (dalloc(&h->scores, B * Hs * Ws)) return -1;
-  if (dalloc(&h->ss, B * Hs * Ws)) return -1;
-  if (dalloc(&h->mask, B * Hs * Ws)) return -1;
-  if (dalloc(&h->supp, B * Hs * Ws)) return -1;
-  // every pixel can be a candidate (a tied plateau survives simple_nms whole; the reference keeps every candidate
-  // before top_k_keypoints, src/super_point.cpp:196-251): 2 x 4 B per pixel and frame
+  auto arena = [&](SpArena &A, bool fast) -> int {
+    if (dalloc(&A.a1, B * H2 * W2 * 64)) return -1;
+    if (dalloc(&A.a2a, B * H2 * W2 * 64)) return -1;
+    if (dalloc(&A.a2b, B * H4 * W4 * 64)) return -1;
+    if (dalloc(&A.a3a, B * H4 * W4 * 128)) return -1;
+    if (dalloc(&A.a3b, B * H8 * W8 * 128)) return -1;
+    if (dalloc(&A.a4a, B * H8 * W8 * 128)) return -1;
+    if (dalloc(&A.a4b, B * H8 * W8 * 128)) return -1;
+    if (dalloc(&A.apd, B * H8 * W8 * 512)) return -1;
+    if (dalloc(&A.logits, B * H8 * W8 * (fast ? 128 : 68))) return -1;
+    if (dalloc(&A.ddb, B * H8 * W8 * 256)) return -1;
+    if (dalloc(&A.desc, B * H8 * W8 * 256)) return -1;
+    if (dalloc(&A.heat, B * Hs * Ws)) return -1;
+    if (dalloc(&A.scores, B * Hs * Ws)) return -1;
+    if (dalloc(&A.ss, B * Hs * Ws)) return -1;
+    if (dalloc(&A.mask, B * Hs * Ws)) return -1;
+    if (dalloc(&A.supp, B * Hs * Ws)) return -1;
+    // every pixel can be a candidate (a tied plateau survives simple_nms whole; the reference keeps every candidate
+    // before top_k_keypoints, src/super_point.cpp:196-251): 2 x 4 B per pixel and frame
+    if (dalloc(&A.counts, B * (size_t)select_nchunk((int)Hs, (int)Ws))) return -1;
+    if (dalloc(&A.cand_score, B * (size_t)h->cand_cap)) return -1;
+    if (dalloc(&A.cand_idx, B * (size_t)h->cand_cap)) return -1;
+    if (dalloc(&A.cand_n, B)) return -1;
+    if (dalloc(&A.kp_score, B * (size_t)kCap)) return -1;
+    if (dalloc(&A.kp_idx, B * (size_t)kCap)) return -1;
+    if (dalloc(&A.kp_n, B)) return -1;
+    return 0;
+  };
   h->cand_cap = (int)(Hs * Ws);
-  if (dalloc(&h->counts, B * (size_t)select_nchunk((int)Hs, (int)Ws))) return -1;
-  if (dalloc(&h->cand_score, B * (size_t)h->cand_cap)) return -1;
-  if (dalloc(&h->cand_idx, B * (size_t)h->cand_cap)) return -1;
-  if (dalloc(&h->cand_n, B)) return -1;
-  if (dalloc(&h->kp_score, B * (size_t)kCap)) return -1;
-  if (dalloc(&h->kp_idx, B * (size_t)kCap)) return -1;
-  if (dalloc(&h->kp_n, B)) return -1;
+  if (arena(h->A, h->precision >= 1)) return -1;
+  if (h->precision == 2) {
+    // guarded fast mode: a second arena for the frames redone in the exact mode (every frame of a batch can be), the guard
+    // words and the redo list.  Error model of a fast-mode score (sp_kernels.hip): measured by tools/gpu_margins.py on
+    // both bench streams (DESIGN.md "Guarded fast mode"), overridable for experiments.
+    if (arena(h->R, false)) return -1;
+    if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, B + 1) || dalloc(&h->g_stats, 8)) return -1;
+    if (dalloc(&h->g_img, B * H * W)) return -1;
+    const char *e;
+    h->g_delta = (e = getenv("URF_GUARD_SP_DELTA")) ? (float)atof(e) : kGuardSpDelta;
+    h->g_ulps = (e = getenv("URF_GUARD_SP_ULPS")) ? (float)atof(e) : kGuardSpUlps;
+  }
   if (dalloc(&h->d_feat, B * (size_t)kCap * 259)) return -1;
   if (dalloc(&h->d_slots, B * kSlotFloats)) return -1;
   URF_HIP(hipHostMalloc((void **)&h->h_img, B * H * W, hipHostMallocDefault));
@@ -330,10 +371,14 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
-    void *bufs[] = {h->d_wh, h->d_wl, h->d_wts, h->d_img, h->d_usermask, h->a1, h->a2a, h->a2b, h->a3a, h->a3b, h->a4a, h->a4b, h->apd,
-                    h->logits, h->ddb, h->desc, h->heat, h->scores, h->ss, h->mask, h->supp, h->counts,
-                    h->cand_score, h->cand_idx, h->cand_n, h->kp_score, h->kp_idx, h->kp_n, h->d_feat, h->d_slots};
+    void *bufs[] = {h->d_wh, h->d_wl, h->d_wts, h->d_img, h->d_usermask, h->A.a1, h->A.a2a, h->A.a2b, h->A.a3a, h->A.a3b, h->A.a4a, h->A.a4b, h->A.apd,
+                    h->A.logits, h->A.ddb, h->A.desc, h->A.heat, h->A.scores, h->A.ss, h->A.mask, h->A.supp, h->A.counts,
+                    h->A.cand_score, h->A.cand_idx, h->A.cand_n, h->A.kp_score, h->A.kp_idx, h->A.kp_n, h->d_feat, h->d_slots};
     for (void *p : bufs) (void)hipFree(p);
+    void *rbufs[] = {h->R.a1, h->R.a2a, h->R.a2b, h->R.a3a, h->R.a3b, h->R.a4a, h->R.a4b, h->R.apd, h->R.logits, h->R.ddb, h->R.desc,
+                     h->R.heat, h->R.scores, h->R.ss, h->R.mask, h->R.supp, h->R.counts, h->R.cand_score, h->R.cand_idx, h->R.cand_n,
+                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats};
+    for (void *p : rbufs) (void)hipFree(p);
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
     (void)hipHostFree(h->h_n);
@@ -346,7 +391,7 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
 
 // the eight 3x3 convolutions in the fast precision mode (h2conv.hip).  Each fp32
 // activation buffer of N floats is reused as two f16 planes of N halfs.
-static int sp_convs_fast(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W) {
+static int sp_convs_fast(urf_sp *h, const SpArena &A, int B, const uint8_t *d_imgs, int H, int W) {
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
   hipStream_t st = h->st;
   const float *wt = h->d_wts;
@@ -372,39 +417,43 @@ static int sp_convs_fast(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W) 
     H2ConvArgs a = {};
     a.H = H; a.W = W; a.Cin = 64; a.wh = h->d_wh + h->hw_off[0]; a.wl = h->d_wl + h->hw_off[0];
     a.bias = wt + h->b_off[1]; a.Cout = 64;
-    planes(h->a1, (size_t)B * H2 * W2 * 64, &a.oh, &a.ol);
+    planes(A.a1, (size_t)B * H2 * W2 * 64, &a.oh, &a.ol);
     a.img = d_imgs; a.w1a = wt + h->w_off[0]; a.b1a = wt + h->b_off[0]; a.lut = wt + h->lut_off;
     if (launch_h2conv(a, true, true, false, B, st)) return -1;
   }
   mark(ST_CONV2A);
-  if (conv(h->a1, 64, H2, W2, 1, wt + h->b_off[2], 64, h->a2a, false, false)) return -1;
+  if (conv(A.a1, 64, H2, W2, 1, wt + h->b_off[2], 64, A.a2a, false, false)) return -1;
   mark(ST_CONV2B);
-  if (conv(h->a2a, 64, H2, W2, 2, wt + h->b_off[3], 64, h->a2b, true, false)) return -1;
+  if (conv(A.a2a, 64, H2, W2, 2, wt + h->b_off[3], 64, A.a2b, true, false)) return -1;
   mark(ST_CONV3A);
-  if (conv(h->a2b, 64, H4, W4, 3, wt + h->b_off[4], 128, h->a3a, false, false)) return -1;
+  if (conv(A.a2b, 64, H4, W4, 3, wt + h->b_off[4], 128, A.a3a, false, false)) return -1;
   mark(ST_CONV3B);
-  if (conv(h->a3a, 128, H4, W4, 4, wt + h->b_off[5], 128, h->a3b, true, false)) return -1;
+  if (conv(A.a3a, 128, H4, W4, 4, wt + h->b_off[5], 128, A.a3b, true, false)) return -1;
   mark(ST_CONV4A);
-  if (conv(h->a3b, 128, H8, W8, 5, wt + h->b_off[6], 128, h->a4a, false, false)) return -1;
+  if (conv(A.a3b, 128, H8, W8, 5, wt + h->b_off[6], 128, A.a4a, false, false)) return -1;
   mark(ST_CONV4B);
-  if (conv(h->a4a, 128, H8, W8, 6, wt + h->b_off[7], 128, h->a4b, false, false)) return -1;
+  if (conv(A.a4a, 128, H8, W8, 6, wt + h->b_off[7], 128, A.a4b, false, false)) return -1;
   mark(ST_PADA);
-  if (conv(h->a4b, 128, H8, W8, 7, wt + h->bpd_off, 512, h->apd, false, false)) return -1;   // planes [cells][512]
+  if (conv(A.a4b, 128, H8, W8, 7, wt + h->bpd_off, 512, A.apd, false, false)) return -1;   // planes [cells][512]
   return 0;
 }
 
-// The kernel pipeline for B frames already resident in h->d_img (or d_imgs).
-static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, const uint8_t *d_mask, double *d_feat,
-                       float *d_slots) {
+// The kernel pipeline for B frames already resident in h->d_img (or d_imgs), in arena A.  fast: split-f16 convolutions
+// (else exact fp32).  gate != null: the redo pass of the guarded fast mode -- every kernel skips batch items >= gate[0] and
+// the results of item r go to the caller's item gate[1 + r].  guard.flags != null: the near-tie guard of the fast pass.
+static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const uint8_t *d_imgs, int H, int W,
+                          const uint8_t *d_mask, double *d_feat, float *d_slots, const int *gate, const SpGuard &guard,
+                          int *kp_n_out, bool timed) {
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
   const int Hs = H8 * 8, Ws = W8 * 8;
   hipStream_t st = h->st;
   const float *wt = h->d_wts;
-  const bool prof = urf::g_profiling != 0;
+  const bool prof = urf::g_profiling != 0 && timed;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
   auto conv3 = [&](const float *in, int cin, int hh, int ww, const float *w, const float *b, int cout, float *out,
                    bool pool) {
     ConvArgs a = {};
+    a.gate = gate;
     a.in = in; a.in_ld = cin; a.in_coff = 0; a.in_bstride = (long)hh * ww * cin;
     a.H = hh; a.W = ww; a.Cin = cin; a.w = w; a.bias = b; a.Cout = cout;
     a.out = out; a.out_ld = cout; a.out_coff = 0;
@@ -412,45 +461,46 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
     a.relu = 1;
     return launch_conv(a, 9, pool, false, B, st);
   };
-  if (h->precision == 1) {
-    if (sp_convs_fast(h, B, d_imgs, H, W)) return -1;
+  if (fast) {
+    if (sp_convs_fast(h, A, B, d_imgs, H, W)) return -1;
   } else {
   mark(ST_CONV1);
   {  // conv1a (fused, VALU) + conv1b + relu + pool
     ConvArgs a = {};
+    a.gate = gate;
     a.in = d_imgs; a.in_bstride = (long)H * W; a.H = H; a.W = W; a.Cin = 64;
     a.w = wt + h->w_off[1]; a.bias = wt + h->b_off[1]; a.Cout = 64;
-    a.out = h->a1; a.out_ld = 64; a.out_bstride = (long)H2 * W2 * 64; a.relu = 1;
+    a.out = A.a1; a.out_ld = 64; a.out_bstride = (long)H2 * W2 * 64; a.relu = 1;
     a.w1a = wt + h->w_off[0]; a.b1a = wt + h->b_off[0]; a.lut = wt + h->lut_off;
     if (launch_conv(a, 9, true, true, B, st)) return -1;
   }
   mark(ST_CONV2A);
-  if (conv3(h->a1, 64, H2, W2, wt + h->w_off[2], wt + h->b_off[2], 64, h->a2a, false)) return -1;
+  if (conv3(A.a1, 64, H2, W2, wt + h->w_off[2], wt + h->b_off[2], 64, A.a2a, false)) return -1;
   mark(ST_CONV2B);
-  if (conv3(h->a2a, 64, H2, W2, wt + h->w_off[3], wt + h->b_off[3], 64, h->a2b, true)) return -1;
+  if (conv3(A.a2a, 64, H2, W2, wt + h->w_off[3], wt + h->b_off[3], 64, A.a2b, true)) return -1;
   mark(ST_CONV3A);
-  if (conv3(h->a2b, 64, H4, W4, wt + h->w_off[4], wt + h->b_off[4], 128, h->a3a, false)) return -1;
+  if (conv3(A.a2b, 64, H4, W4, wt + h->w_off[4], wt + h->b_off[4], 128, A.a3a, false)) return -1;
   mark(ST_CONV3B);
-  if (conv3(h->a3a, 128, H4, W4, wt + h->w_off[5], wt + h->b_off[5], 128, h->a3b, true)) return -1;
+  if (conv3(A.a3a, 128, H4, W4, wt + h->w_off[5], wt + h->b_off[5], 128, A.a3b, true)) return -1;
   mark(ST_CONV4A);
-  if (conv3(h->a3b, 128, H8, W8, wt + h->w_off[6], wt + h->b_off[6], 128, h->a4a, false)) return -1;
+  if (conv3(A.a3b, 128, H8, W8, wt + h->w_off[6], wt + h->b_off[6], 128, A.a4a, false)) return -1;
   mark(ST_CONV4B);
-  if (conv3(h->a4a, 128, H8, W8, wt + h->w_off[7], wt + h->b_off[7], 128, h->a4b, false)) return -1;
+  if (conv3(A.a4a, 128, H8, W8, wt + h->w_off[7], wt + h->b_off[7], 128, A.a4b, false)) return -1;
   mark(ST_PADA);
-  if (conv3(h->a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, h->apd, false)) return -1;
+  if (conv3(A.a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, A.apd, false)) return -1;
   }
   const int ncell = H8 * W8;
   int logit_ld = 68;
-  if (h->precision == 1) {
+  if (fast) {
     // the two 1x1 heads as split-f16 GEMMs on the planes of Pa || Da ([cells][512]: hi plane, then lo plane)
-    const _Float16 *ph = (const _Float16 *)h->apd, *pl = ph + (size_t)B * ncell * 512;
+    const _Float16 *ph = (const _Float16 *)A.apd, *pl = ph + (size_t)B * ncell * 512;
     logit_ld = 128;
     mark(ST_PB);
     {
       urf::H2Args a = {};
       a.xh = ph; a.xl = pl; a.ldx = 512; a.x_bstride = (long)ncell * 512; a.rows = ncell; a.Cin = 256;
       a.wh = h->d_wh + h->hpb_off; a.wl = h->d_wl + h->hpb_off; a.bias = wt + h->bpb128_off; a.Cout = 128;
-      a.out = h->logits; a.ld_out = 128; a.out_bstride = (long)ncell * 128;
+      a.out = A.logits; a.ld_out = 128; a.out_bstride = (long)ncell * 128;
       if (urf::launch_h2gemm(a, B, st)) return -1;
     }
     mark(ST_DB);
@@ -458,43 +508,62 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
       urf::H2Args a = {};
       a.xh = ph + 256; a.xl = pl + 256; a.ldx = 512; a.x_bstride = (long)ncell * 512; a.rows = ncell; a.Cin = 256;
       a.wh = h->d_wh + h->hdb_off; a.wl = h->d_wl + h->hdb_off; a.bias = wt + h->b_off[11]; a.Cout = 256;
-      a.out = h->ddb; a.ld_out = 256; a.out_bstride = (long)ncell * 256;
+      a.out = A.ddb; a.ld_out = 256; a.out_bstride = (long)ncell * 256;
       if (urf::launch_h2gemm(a, B, st)) return -1;
     }
   } else {
   mark(ST_PB);
   {  // convPb 1x1 on channels [0,256) of apd -> logits (68-wide rows)
     ConvArgs a = {};
-    a.in = h->apd; a.in_ld = 512; a.in_coff = 0; a.in_bstride = (long)ncell * 512;
+    a.gate = gate;
+    a.in = A.apd; a.in_ld = 512; a.in_coff = 0; a.in_bstride = (long)ncell * 512;
     a.H = 1; a.W = ncell; a.Cin = 256; a.w = wt + h->wpb_off; a.bias = wt + h->bpb_off; a.Cout = 68;
-    a.out = h->logits; a.out_ld = 68; a.out_bstride = (long)ncell * 68; a.relu = 0;
+    a.out = A.logits; a.out_ld = 68; a.out_bstride = (long)ncell * 68; a.relu = 0;
     if (launch_conv(a, 1, false, false, B, st)) return -1;
   }
   mark(ST_DB);
   {  // convDb 1x1 on channels [256,512)
     ConvArgs a = {};
-    a.in = h->apd; a.in_ld = 512; a.in_coff = 256; a.in_bstride = (long)ncell * 512;
+    a.gate = gate;
+    a.in = A.apd; a.in_ld = 512; a.in_coff = 256; a.in_bstride = (long)ncell * 512;
     a.H = 1; a.W = ncell; a.Cin = 256; a.w = wt + h->w_off[11]; a.bias = wt + h->b_off[11]; a.Cout = 256;
-    a.out = h->ddb; a.out_ld = 256; a.out_bstride = (long)ncell * 256; a.relu = 0;
+    a.out = A.ddb; a.out_ld = 256; a.out_bstride = (long)ncell * 256; a.relu = 0;
     if (launch_conv(a, 1, false, false, B, st)) return -1;
   }
   }
   mark(ST_SOFTMAX);
-  if (launch_softmax(h->logits, logit_ld, H8, W8, h->heat, B, st)) return -1;
+  if (launch_softmax(A.logits, logit_ld, H8, W8, A.heat, B, gate, st)) return -1;
   mark(ST_NMS);
-  if (launch_nms(h->heat, h->mask, h->supp, h->ss, h->scores, Hs, Ws, B, st)) return -1;
+  // a maximum below thr_lo can never become a keypoint (nor can anything it suppresses): no near-tie there matters
+  const float thr_lo = (float)(h->cfg.keypoint_threshold * 0.5);
+  if (launch_nms(A.heat, A.mask, A.supp, A.ss, A.scores, Hs, Ws, B, gate, guard, thr_lo, st)) return -1;
   mark(ST_SELECT);
-  if (launch_select(h->scores, Hs, Ws, h->cfg.keypoint_threshold, h->cfg.remove_borders, d_mask, h->counts,
-                    h->cand_score, h->cand_idx, h->cand_cap, h->cand_n, h->cfg.max_keypoints, h->kp_score,
-                    h->kp_idx, h->kp_n, B, st))
+  if (launch_select(A.scores, Hs, Ws, h->cfg.keypoint_threshold, h->cfg.remove_borders, d_mask, A.counts,
+                    A.cand_score, A.cand_idx, h->cand_cap, A.cand_n, h->cfg.max_keypoints, A.kp_score,
+                    A.kp_idx, A.kp_n, B, gate, guard, st))
     return -1;
   mark(ST_DNORM);
-  if (launch_desc_norm(h->ddb, 256, 0, B * ncell, h->desc, st)) return -1;
+  if (launch_desc_norm(A.ddb, 256, 0, B * ncell, A.desc, gate, ncell, st)) return -1;
   mark(ST_SAMPLE);
-  if (launch_sample(h->desc, H8, W8, h->kp_score, h->kp_idx, h->kp_n, Ws, d_feat, d_slots, B, st)) return -1;
+  if (launch_sample(A.desc, H8, W8, A.kp_score, A.kp_idx, A.kp_n, Ws, d_feat, d_slots, B, gate, kp_n_out, st)) return -1;
   mark(ST_DOWNLOAD);
-  h->lastH = H; h->lastW = W; h->lastB = B;
   return 0;
+}
+
+// precision 0 / 1: one pass.  precision 2 (guarded fast): the fast pass with the near-tie guard, then the exact pass over the
+// redo list -- enqueued unconditionally, its kernels exit at once for frames that are not on the list (normally all).
+static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, const uint8_t *d_mask, double *d_feat,
+                       float *d_slots) {
+  SpGuard g = {};
+  h->lastH = H; h->lastW = W; h->lastB = B;
+  if (h->precision != 2) return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true);
+  g.flags = h->g_flags; g.band = h->g_band; g.delta = h->g_delta; g.ulps = h->g_ulps;
+  URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), h->st));
+  URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), h->st));
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true)) return -1;
+  if (launch_guard_compact(h->g_flags, B, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, h->st)) return -1;
+  SpGuard off = {};
+  return sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false);
 }
 
 static int sp_check_dims(urf_sp *h, int B, int rows, int cols) {
@@ -526,7 +595,7 @@ extern "C" int urf_sp_infer_batch(urf_sp *h, int B, const uint8_t *const *imgs, 
   if (prof) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   URF_HIP(hipMemcpyAsync(h->d_img, h->h_img, B * fsz, hipMemcpyHostToDevice, h->st));
   if (sp_pipeline(h, B, h->d_img, rows, cols, nullptr, h->d_feat, h->d_slots)) return -1;
-  URF_HIP(hipMemcpyAsync(h->h_n, h->kp_n, B * sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, B * sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)B * kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->st));
   if (prof) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
   URF_HIP(hipStreamSynchronize(h->st));
@@ -557,7 +626,7 @@ extern "C" int urf_sp_infer(urf_sp *h, const uint8_t *img, int rows, int cols, s
   sp_flip_events(h);
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   if (sp_pipeline(h, 1, h->d_img, rows, cols, h->d_usermask, h->d_feat, h->d_slots)) return -1;
-  URF_HIP(hipMemcpyAsync(h->h_n, h->kp_n, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->st));
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
   URF_HIP(hipStreamSynchronize(h->st));
@@ -587,6 +656,18 @@ extern "C" int urf_sp_sync(urf_sp *h) {
   return 0;
 }
 
+extern "C" int urf_sp_near_tie_reruns(urf_sp *h, unsigned long long *out, int n) {
+  URF_CHECK(h && h->built && out && n >= 1, "urf_sp_near_tie_reruns: bad argument");
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (h->precision == 2) {
+    URF_HIP(hipSetDevice(h->device));
+    URF_HIP(hipStreamSynchronize(h->st));
+    URF_HIP(hipMemcpy(v, h->g_stats, sizeof(v), hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 0;
+}
+
 extern "C" int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K) {
   URF_CHECK(d_slot && feat && K, "urf_slot_to_host: null pointer");
   std::vector<float> s(kSlotFloats);
@@ -609,19 +690,19 @@ extern "C" int urf_sp_debug_tensor(urf_sp *h, int which, float *out, size_t n) {
   URF_HIP(hipSetDevice(h->device));
   const float *src = nullptr;
   switch (which) {
-    case 0: src = h->scores; break;
-    case 1: src = h->heat; break;
-    case 2: src = h->desc; break;
-    case 101: src = h->a1; break;
-    case 102: src = h->a2a; break;
-    case 103: src = h->a2b; break;
-    case 104: src = h->a3a; break;
-    case 105: src = h->a3b; break;
-    case 106: src = h->a4a; break;
-    case 107: src = h->a4b; break;
-    case 108: src = h->apd; break;     /* [cells][512]: Pa | Da */
-    case 109: src = h->logits; break;  /* [cells][68] */
-    case 111: src = h->ddb; break;
+    case 0: src = h->A.scores; break;
+    case 1: src = h->A.heat; break;
+    case 2: src = h->A.desc; break;
+    case 101: src = h->A.a1; break;
+    case 102: src = h->A.a2a; break;
+    case 103: src = h->A.a2b; break;
+    case 104: src = h->A.a3a; break;
+    case 105: src = h->A.a3b; break;
+    case 106: src = h->A.a4a; break;
+    case 107: src = h->A.a4b; break;
+    case 108: src = h->A.apd; break;     /* [cells][512]: Pa | Da */
+    case 109: src = h->A.logits; break;  /* [cells][68] */
+    case 111: src = h->A.ddb; break;
     default: URF_CHECK(false, "unknown debug tensor %d", which);
   }
   URF_HIP(hipStreamSynchronize(h->st));

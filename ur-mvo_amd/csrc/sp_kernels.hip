@@ -13,13 +13,34 @@ namespace urf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------- near-tie guard
+// Guarded fast mode (DESIGN.md "Guarded fast mode"): the fast precision mode computes every score within
+//   err(s) = delta * s * (1 - s) + ulps * ulp(s)
+// of the exact mode's (softmax of logits that carry ~1e-6 of rounding noise: the error of s = 1 / (1 + R) is s (1 - s)
+// times the relative error of R; constants measured by tools/gpu_margins.py, with a safety factor).  Every discrete
+// decision of the SuperPoint tail that two scores closer than err(a) + err(b) could flip sets a bit in flags[frame]; the
+// frame is then redone in the exact mode by kernels that are already enqueued behind the fast ones and exit at once
+// when their frame is not in the redo list (`gate`: gate[0] = frames to redo, gate[1 + r] = frame index of redo slot r).
+// (struct SpGuard: urf_common.h)
+__device__ __forceinline__ float guard_err(float s, float delta, float ulps) {
+  const float a = s < 0.0f ? -s : s;
+  const float one_m = a < 1.0f ? 1.0f - a : 0.0f;
+  return delta * a * one_m + ulps * 1.1920929e-7f * a;
+}
+__device__ __forceinline__ bool guard_near(float a, float b, const SpGuard &g) {
+  const float d = a > b ? a - b : b - a;
+  return d <= guard_err(a, g.delta, g.ulps) + guard_err(b, g.delta, g.ulps);
+}
+#define URF_GATE(idx) if (gate && (int)(idx) >= gate[0]) return
+
 // ------------------------------------------------------------------ softmax
 // logits [B][Hc*Wc][ld] (65 used) -> heat [B][Hs][Ws].  One lane per cell:
 // m = max; e_k = exp_c(l_k - m); sum sequential k=0..64; p_k = e_k / sum.
 __global__ void __launch_bounds__(256) softmax_d2s_kernel(const float *logits, int ld, int Hc, int Wc,
-                                                          float *heat) {
+                                                          float *heat, const int *gate) {
   const int cell = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
+  URF_GATE(b);
   if (cell >= Hc * Wc) return;
   const float *l = logits + ((size_t)b * Hc * Wc + cell) * ld;
   float v[65];
@@ -51,10 +72,13 @@ __global__ void __launch_bounds__(256) softmax_d2s_kernel(const float *logits, i
 constexpr int NR = 32, NC = 64;
 template <int MODE, bool LAST>
 __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *mask, uint8_t *supp, float *ss,
-                                                       float *out, int H, int W) {
+                                                       float *out, int H, int W, const int *gate, SpGuard g,
+                                                       float thr_lo) {
   __shared__ float tin[(NR + 8)][(NC + 8)];
   __shared__ float hm[(NR + 8)][NC];
   const int b = blockIdx.z;
+  URF_GATE(b);
+  bool near_tie = false;
   const size_t boff = (size_t)b * H * W;
   const int y0 = blockIdx.y * NR, x0 = blockIdx.x * NC;
   const int tid = threadIdx.x;
@@ -88,6 +112,9 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
     for (int d = 1; d < 9; ++d) m = fmaxf(m, hm[r + d][c]);
     const size_t p = boff + (size_t)y * W + x;
     const float center = tin[r + 4][c + 4];
+    // guard: a pixel that loses against its window's maximum by less than the two scores' error could win in the exact
+    // mode (only where the maximum can become a keypoint at all)
+    if (MODE != 1 && g.flags && center != m && m > thr_lo && guard_near(center, m, g)) near_tie = true;
     if (MODE == 0) {
       mask[p] = (center == m) ? 1 : 0;
     } else if (MODE == 1) {
@@ -101,6 +128,30 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
       else mask[p] = mk;
     }
   }
+  if (MODE != 1 && g.flags && near_tie) atomicOr(&g.flags[b], 4);
+}
+
+// guard: two surviving pixels within 4 px of each other (Chebyshev) can only be an exact tie of the fast scores (each is the
+// maximum of a window that holds the other); the exact mode may separate them.  Sparse: only survivors look around.
+__global__ void __launch_bounds__(256) nms_tie_kernel(const float *out, int H, int W, float thr_lo, SpGuard g) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const float *o = out + (size_t)b * H * W;
+  const float c = o[i];
+  if (!(c > thr_lo)) return;
+  const int y = i / W, x = i % W;
+  bool tie = false;
+  for (int dy = -4; dy <= 4; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = -4; dx <= 4; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
+      tie = tie || o[(size_t)yy * W + xx] > 0.0f;
+    }
+  }
+  if (tie) atomicOr(&g.flags[b], 4);
 }
 
 // ---------------------------------------------------------------- selection
@@ -138,17 +189,28 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
 }
 
 __global__ void __launch_bounds__(256) sel_count_kernel(const float *scores, int H, int W, double thr, int border,
-                                                        const uint8_t *mask, int *counts, int nchunk) {
+                                                        const uint8_t *mask, int *counts, int nchunk, const int *gate,
+                                                        SpGuard g) {
   __shared__ int wsum[16];
   const int b = blockIdx.y, chunk = blockIdx.x;
+  URF_GATE(b);
   const size_t boff = (size_t)b * H * W;
   const int base = chunk * SEL_PIX + threadIdx.x * 8;
   int c = 0;
+  bool in_band = false;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int i = base + j;
-    if (i < H * W) c += sel_flag(scores[boff + i], i / W, i % W, H, W, thr, border, mask, boff) ? 1 : 0;
+    if (i < H * W) {
+      const float sc = scores[boff + i];
+      c += sel_flag(sc, i / W, i % W, H, W, thr, border, mask, boff) ? 1 : 0;
+      // guard: a surviving pixel (scores are 0 where the NMS suppressed) whose score is within its error of the threshold,
+      // on either side, inside the border / mask
+      if (g.flags && sc > 0.0f && guard_near(sc, (float)thr, g) && sel_flag(sc, i / W, i % W, H, W, -1.0, border, mask, boff))
+        in_band = true;
+    }
   }
+  if (g.flags && in_band) atomicOr(&g.band[b], 1);
   int total;
   block_excl_scan(c, wsum, total);
   if (threadIdx.x == 0) counts[b * nchunk + chunk] = total;
@@ -157,10 +219,11 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const float *scores, int
 __global__ void __launch_bounds__(256) sel_scatter_kernel(const float *scores, int H, int W, double thr, int border,
                                                           const uint8_t *mask, const int *counts, int nchunk,
                                                           float *cand_score, int *cand_idx, int cand_cap,
-                                                          int *cand_n) {
+                                                          int *cand_n, const int *gate) {
   __shared__ int wsum[16];
   __shared__ int s_off;
   const int b = blockIdx.y, chunk = blockIdx.x;
+  URF_GATE(b);
   const size_t boff = (size_t)b * H * W;
   // offset of this chunk = sum of the counts of earlier chunks (integers: exact)
   int part = 0;
@@ -214,13 +277,16 @@ __global__ void __launch_bounds__(256) sel_scatter_kernel(const float *scores, i
 // Otherwise the k best by (score desc, raster index asc): 4-pass radix select
 // on the score bits, first-come tie completion, bitonic sort of <=1024 keys.
 __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, const int *cand_idx, const int *cand_n,
-                                                    int cand_cap, int k, float *kp_score, int *kp_idx, int *kp_n) {
+                                                    int cand_cap, int k, float *kp_score, int *kp_idx, int *kp_n,
+                                                    const int *gate, SpGuard g, float thr) {
   __shared__ int hist[256];
   __shared__ int wsum[16];
   __shared__ unsigned long long keys[kCap];
   __shared__ unsigned s_prefix, s_mask;
   __shared__ int s_rank, s_cnt;
+  __shared__ unsigned s_next[16];
   const int b = blockIdx.x, tid = threadIdx.x;
+  URF_GATE(b);
   const int n = cand_n[b];
   const float *cs = cand_score + (size_t)b * cand_cap;
   const int *ci = cand_idx + (size_t)b * cand_cap;
@@ -229,7 +295,11 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
   const int kk = (k < 0 || k > kCap) ? kCap : k;
   if (n <= kk) {  // includes the k == -1 case up to the slot capacity
     for (int i = tid; i < n; i += 1024) { os[i] = cs[i]; oi[i] = ci[i]; }
-    if (tid == 0) kp_n[b] = n;
+    if (tid == 0) {
+      kp_n[b] = n;
+      // guard: every candidate is kept, so a pixel within its error of the threshold changes the result
+      if (g.flags && g.band[b]) atomicOr(&g.flags[b], 2);
+    }
     return;
   }
   // ---- radix select: find T = kk-th largest score bit pattern
@@ -258,6 +328,38 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
   }
   const unsigned T = s_prefix;
   const int need_eq = s_rank;  // how many candidates with bits == T to take (first in raster order)
+  if (g.flags) {
+    // guard: the best candidate that does NOT make the cut (scores are positive floats: their bit patterns order like the
+    // values).  More candidates with the cut's own bits than are taken = an exact tie across the cut.
+    unsigned nx = 0;
+    int eq_total = 0;
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned u = __float_as_uint(cs[i]);
+      if (u < T && u > nx) nx = u;
+      eq_total += (u == T) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)nx, d, 64);
+      nx = o > nx ? o : nx;
+      eq_total += __shfl_xor(eq_total, d, 64);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_next[tid >> 6] = nx; wsum[tid >> 6] = eq_total; }
+    __syncthreads();
+    if (tid == 0) {
+      int eq = 0;
+      for (int w = 0; w < 16; ++w) { nx = s_next[w] > nx ? s_next[w] : nx; eq += wsum[w]; }
+      const float cut = __uint_as_float(T);
+      const float nxt = eq > need_eq ? cut : __uint_as_float(nx);
+      int bits = 0;
+      if (guard_near(cut, nxt, g)) bits |= 1;
+      // a pixel within its error of the threshold matters only if it could enter the top k
+      if (g.band[b] && guard_near(cut, thr, g)) bits |= 2;
+      if (bits) atomicOr(&g.flags[b], bits);
+    }
+    __syncthreads();
+  }
   if (tid == 0) s_cnt = 0;
   for (int i = tid; i < kCap; i += 1024) keys[i] = 0ull;
   __syncthreads();
@@ -301,10 +403,12 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
 // ------------------------------------------------------- descriptor normalise
 // F.normalize(p=2, dim=1) (model.py:83).  One wave per cell; lane l owns
 // channels 4l..4l+3 (fma chain from x0*x0), 64-lane butterfly, x / max(norm,1e-12)
-__global__ void __launch_bounds__(256) desc_norm_kernel(float *desc, int ld, int coff, int ncell, float *out) {
+__global__ void __launch_bounds__(256) desc_norm_kernel(float *desc, int ld, int coff, int ncell, float *out,
+                                                        const int *gate, int ncell_frame) {
   const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (cell >= ncell) return;
+  if (gate && cell >= gate[0] * ncell_frame) return;
   const f32x4 v = *(const f32x4 *)(desc + (size_t)cell * ld + coff + 4 * lane);
   float a = v[0] * v[0];
   a = __builtin_fmaf(v[1], v[1], a);
@@ -328,16 +432,23 @@ __device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : (v < mx
 __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*Wc][256]*/, int Hc, int Wc,
                                                      const float *kp_score, const int *kp_idx, const int *kp_n,
                                                      int Ws, double *feat /*[B][kCap][259] or null*/,
-                                                     float *slots /*[B][kSlotFloats] or null*/) {
+                                                     float *slots /*[B][kSlotFloats] or null*/, const int *gate,
+                                                     int *kp_n_out) {
   __shared__ double vals[4][256];
   __shared__ double s_inv[4];
   const int b = blockIdx.y;
+  URF_GATE(b);
+  // redo of a flagged frame in the exact mode: arena item b goes to the caller's item gate[1 + b]; hdr[1] = 1 marks the slot
+  const int ob = gate ? gate[1 + b] : b;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + wv;
   const int n = kp_n[b];
-  if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
-    int *hdr = (int *)(slots + (size_t)b * kSlotFloats);
-    hdr[0] = n; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (slots) {
+      int *hdr = (int *)(slots + (size_t)ob * kSlotFloats);
+      hdr[0] = n; hdr[1] = gate ? 1 : 0; hdr[2] = 0; hdr[3] = 0;
+    }
+    if (kp_n_out) kp_n_out[ob] = n;
   }
   const bool active = j < n;
   double v[4] = {0, 0, 0, 0};
@@ -384,13 +495,13 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
   if (!active) return;
   const double inv = s_inv[wv];
   if (feat) {
-    double *col = feat + ((size_t)b * kCap + j) * 259;
+    double *col = feat + ((size_t)ob * kCap + j) * 259;
     if (lane == 0) { col[0] = (double)sc; col[1] = (double)kx; col[2] = (double)ky; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) col[3 + 4 * lane + r] = v[r] * inv;
   }
   if (slots) {
-    float *sl = slots + (size_t)b * kSlotFloats;
+    float *sl = slots + (size_t)ob * kSlotFloats;
     if (lane == 0) {
       f32x4 m = {sc, (float)kx, (float)ky, 0.0f};
       *(f32x4 *)(sl + kSlotHeader + 4 * (size_t)j) = m;
@@ -402,51 +513,100 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
   }
 }
 
+// ----------------------------------------------------------------- guard redo
+// After the fast pipeline of a batch: frames whose guard word is set go to the redo list, their u8 images to the redo arena.
+// One workgroup per frame.  gate[0] = count, gate[1 + r] = frame of redo slot r.  stats: [0] frames redone, [1] frames seen,
+// [2..4] frames flagged by the top-k cut / the threshold band / the NMS.
+__global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, int B, const uint8_t *imgs, size_t img_bytes,
+                                                            uint8_t *redo_imgs, int *gate, unsigned long long *stats) {
+  const int b = blockIdx.x;
+  int r = 0, total = 0;
+  for (int i = 0; i < B; ++i) {
+    const int f = flags[i] != 0;
+    r += (i < b) ? f : 0;
+    total += f;
+  }
+  const int mine = flags[b];
+  if (threadIdx.x == 0) {
+    if (b == 0) {
+      gate[0] = total;
+      atomicAdd(&stats[0], (unsigned long long)total);
+      atomicAdd(&stats[1], (unsigned long long)B);
+    }
+    if (mine) {
+      gate[1 + r] = b;
+      if (mine & 1) atomicAdd(&stats[2], 1ull);
+      if (mine & 2) atomicAdd(&stats[3], 1ull);
+      if (mine & 4) atomicAdd(&stats[4], 1ull);
+    }
+  }
+  if (!mine) return;
+  const uint8_t *src = imgs + (size_t)b * img_bytes;
+  uint8_t *dst = redo_imgs + (size_t)r * img_bytes;
+  if ((((size_t)src | (size_t)dst | img_bytes) & 15) == 0) {
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)dst;
+    for (size_t i = threadIdx.x; i < img_bytes / 16; i += 256) d4[i] = s4[i];
+  } else {
+    for (size_t i = threadIdx.x; i < img_bytes; i += 256) dst[i] = src[i];
+  }
+}
+
 // ------------------------------------------------------------------ launchers
-int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, hipStream_t st) {
+int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, const int *gate, hipStream_t st) {
   dim3 grid((Hc * Wc + 255) / 256, B);
-  hipLaunchKernelGGL(softmax_d2s_kernel, grid, dim3(256), 0, st, logits, ld, Hc, Wc, heat);
+  hipLaunchKernelGGL(softmax_d2s_kernel, grid, dim3(256), 0, st, logits, ld, Hc, Wc, heat, gate);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_nms(const float *heat, uint8_t *mask, uint8_t *supp, float *ss, float *out, int H, int W, int B,
-               hipStream_t st) {
+               const int *gate, const SpGuard &g, float thr_lo, hipStream_t st) {
   dim3 grid((W + NC - 1) / NC, (H + NR - 1) / NR, B), block(256);
-  hipLaunchKernelGGL((nms_pass_kernel<0, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
-  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
-  hipLaunchKernelGGL((nms_pass_kernel<2, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
-  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
-  hipLaunchKernelGGL((nms_pass_kernel<2, true>), grid, block, 0, st, heat, mask, supp, ss, out, H, W);
+  hipLaunchKernelGGL((nms_pass_kernel<0, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W, gate, g, thr_lo);
+  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W, gate, g, thr_lo);
+  hipLaunchKernelGGL((nms_pass_kernel<2, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W, gate, g, thr_lo);
+  hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, block, 0, st, heat, mask, supp, ss, out, H, W, gate, g, thr_lo);
+  hipLaunchKernelGGL((nms_pass_kernel<2, true>), grid, block, 0, st, heat, mask, supp, ss, out, H, W, gate, g, thr_lo);
+  if (g.flags) hipLaunchKernelGGL(nms_tie_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, out, H, W, thr_lo, g);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_select(const float *scores, int H, int W, double thr, int border, const uint8_t *mask, int *counts,
                   float *cand_score, int *cand_idx, int cand_cap, int *cand_n, int k, float *kp_score, int *kp_idx,
-                  int *kp_n, int B, hipStream_t st) {
+                  int *kp_n, int B, const int *gate, const SpGuard &g, hipStream_t st) {
   const int nchunk = (H * W + SEL_PIX - 1) / SEL_PIX;
   dim3 grid(nchunk, B);
-  hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), 0, st, scores, H, W, thr, border, mask, counts, nchunk);
+  hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), 0, st, scores, H, W, thr, border, mask, counts, nchunk, gate, g);
   hipLaunchKernelGGL(sel_scatter_kernel, grid, dim3(256), 0, st, scores, H, W, thr, border, mask, counts, nchunk,
-                     cand_score, cand_idx, cand_cap, cand_n);
+                     cand_score, cand_idx, cand_cap, cand_n, gate);
   hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, st, cand_score, cand_idx, cand_n, cand_cap, k, kp_score,
-                     kp_idx, kp_n);
+                     kp_idx, kp_n, gate, g, (float)thr);
   URF_HIP(hipGetLastError());
   return 0;
 }
 int select_nchunk(int H, int W) { return (H * W + SEL_PIX - 1) / SEL_PIX; }
 
-int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, hipStream_t st) {
-  hipLaunchKernelGGL(desc_norm_kernel, dim3((ncell_total + 3) / 4), dim3(256), 0, st, desc, ld, coff, ncell_total, out);
+int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, const int *gate, int ncell_frame,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(desc_norm_kernel, dim3((ncell_total + 3) / 4), dim3(256), 0, st, desc, ld, coff, ncell_total, out,
+                     gate, ncell_frame);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, const int *kp_idx, const int *kp_n,
-                  int Ws, double *feat, float *slots, int B, hipStream_t st) {
+                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, hipStream_t st) {
   hipLaunchKernelGGL(sample_kernel, dim3(kCap / 4, B), dim3(256), 0, st, desc, Hc, Wc, kp_score, kp_idx, kp_n, Ws,
-                     feat, slots);
+                     feat, slots, gate, kp_n_out);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_guard_compact(const int *flags, int B, const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs, int *gate,
+                         unsigned long long *stats, hipStream_t st) {
+  hipLaunchKernelGGL(guard_compact_kernel, dim3(B), dim3(256), 0, st, flags, B, imgs, img_bytes, redo_imgs, gate, stats);
   URF_HIP(hipGetLastError());
   return 0;
 }

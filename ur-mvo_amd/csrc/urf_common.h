@@ -3,11 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 namespace urf {
 
 void set_error(const char *fmt, ...);
+
+// "once per device" guard for hipFuncSetAttribute: the attribute belongs to the (kernel, device) pair, and the library may
+// drive several devices from several host threads.  Doing the work twice is harmless (idempotent), skipping it is not.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  static int cur() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d & 63; }
+  bool need() { return ((done.load(std::memory_order_acquire) >> cur()) & 1ull) == 0; }
+  void mark() { done.fetch_or(1ull << cur(), std::memory_order_release); }
+};
 
 #define URF_HIP(call)                                                              \
   do {                                                                             \
@@ -54,6 +64,14 @@ struct ConvArgs {
   const float *w1a;      // [9][64]
   const float *b1a;      // [64]
   const float *lut;      // [256] u8 -> f32 ( float(u8)/255.0 )
+  const int *gate;       // optional: batch items >= gate[0] are skipped (redo pipeline of the guarded fast mode)
+};
+
+// near-tie guard of the fast precision mode, SuperPoint tail (sp_kernels.hip)
+struct SpGuard {
+  int *flags;        // [B] bit 0: top-k cut, bit 1: threshold band, bit 2: NMS near-tie; null = guard off
+  int *band;         // [B] scratch: some candidate lies in the threshold band
+  float delta, ulps; // error model of a fast-mode score: delta * s * (1 - s) + ulps * ulp(s)
 };
 
 // feature slot (device): header + meta[cap][4] + desc[cap][256], all 4-byte units

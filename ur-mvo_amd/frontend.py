@@ -112,6 +112,12 @@ class SuperPoint:
     def sync(self):
         check(_lib.lib().urf_sp_sync(self._h), "urf_sp_sync")
 
+    def near_tie_reruns(self):
+        """guarded fast mode: dict(redone, frames, cut, threshold, nms) since build()"""
+        v = (C.c_ulonglong * 8)()
+        check(_lib.lib().urf_sp_near_tie_reruns(self._h, v, 8), "urf_sp_near_tie_reruns")
+        return dict(redone=int(v[0]), frames=int(v[1]), cut=int(v[2]), threshold=int(v[3]), nms=int(v[4]))
+
     def debug_tensor(self, which, shape):
         out = np.zeros(shape, np.float32)
         check(_lib.lib().urf_sp_debug_tensor(self._h, which, _p(out), C.c_size_t(out.size)), "debug_tensor")
@@ -171,6 +177,12 @@ class _PM:
     def sinkhorn_fallbacks(self):
         """how often the resident Sinkhorn launch of this handle gave up and the batch was redone with the streaming kernels"""
         return int(_lib.lib().urf_pm_sinkhorn_fallbacks(self._h))
+
+    def near_tie_reruns(self):
+        """guarded fast mode: dict(redone, pairs, threshold, runner_up) since build()"""
+        v = (C.c_ulonglong * 8)()
+        check(_lib.lib().urf_pm_near_tie_reruns(self._h, v, 8), "urf_pm_near_tie_reruns")
+        return dict(redone=int(v[0]), pairs=int(v[1]), threshold=int(v[2]), runner_up=int(v[3]))
 
     def stage_ms(self):
         ms = (C.c_float * 16)()
