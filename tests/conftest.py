@@ -237,33 +237,53 @@ SG_CFG = (640, 512, 0.5, 100)
 _BENCH_ORACLE = {}
 
 
-def _bench_oracle_worker(args):
-    """one oracle job in a worker process (the C oracle uses <= 32 OpenMP threads; a GPU box has many more cores)"""
-    kind, payload = args
-    U = load_pkg()
-    from oracle import oracle as O
-    O.build()
-    if kind == "sp":
-        img, max_kp = payload if isinstance(payload, tuple) else (payload, 1000)
-        return O.sp_infer(U.synth.pack_sp(U.synth.sp_weights(0)), O.SPConfig(max_kp, 0.0005, 4), img)
-    f0, f1, ransac = payload
-    rc = O.ref_ransac() if ransac == "ref" else O.RansacConfig(200, 1.0, 0)
-    return O.match_points(U.synth.pack_sg(U.synth.sg_weights(0)), O.SGConfig(*SG_CFG), rc, f0, f1, True)
-
-
-def oracle_pool():
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
+def run_oracle_jobs(kind, jobs, timeout=900):
+    """CPU-oracle jobs spread over worker PROCESSES (tests/oracle_worker.py, plain subprocesses with .npz files in between:
+    no pickled callables, no fork of a process that holds a GPU).  kind "sp": jobs = [(img, max_kp)] -> [features];
+    kind "pm": jobs = [(f0, f1, "ref" | "sigma1")] -> [match list of (queryIdx, trainIdx, distance)]"""
+    import subprocess
+    import tempfile
+    if not jobs:
+        return []
     ncpu = len(os.sched_getaffinity(0))
-    return ProcessPoolExecutor(max(1, min(6, ncpu // 32)), mp_context=mp.get_context("spawn"))
+    W = max(1, min(6, ncpu // 32, len(jobs)))
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for w in range(W):
+            mine = list(range(w, len(jobs), W))
+            d = {"kind": np.array(kind), "n": np.array(len(mine))}
+            for i, j in enumerate(mine):
+                if kind == "sp":
+                    d[f"img_{i}"], d[f"max_kp_{i}"] = np.ascontiguousarray(jobs[j][0], np.uint8), np.array(jobs[j][1])
+                else:
+                    d[f"f0_{i}"], d[f"f1_{i}"], d[f"ransac_{i}"] = jobs[j][0], jobs[j][1], np.array(jobs[j][2])
+            src, dst = os.path.join(tmp, f"in{w}.npz"), os.path.join(tmp, f"out{w}.npz")
+            np.savez(src, **d)
+            procs.append((mine, dst, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_worker.py"), src, dst],
+                                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+        out = [None] * len(jobs)
+        for mine, dst, p in procs:
+            try:
+                _, err = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                for _, _, q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, err.decode()[-2000:]
+            r = np.load(dst)
+            for i, j in enumerate(mine):
+                if kind == "sp":
+                    out[j] = r[f"feat_{i}"]
+                else:
+                    out[j] = [(int(q), int(t), float(np.float32(dd))) for q, t, dd in r[f"m_{i}"]]
+        return out
 
 
 def oracle_frames_and_pairs(frames, pairs, max_kp=1000):
     """O.sp_infer on every frame and O.match_points (default outlier stage, outlier rejection on) on every (first, second)
     index pair, spread over worker processes: (features, match lists)"""
-    with oracle_pool() as ex:
-        feats = list(ex.map(_bench_oracle_worker, [("sp", (f, max_kp)) for f in frames]))
-        lists = list(ex.map(_bench_oracle_worker, [("pm", (feats[a], feats[b], "ref")) for a, b in pairs]))
+    feats = run_oracle_jobs("sp", [(f, max_kp) for f in frames])
+    lists = run_oracle_jobs("pm", [(feats[a], feats[b], "ref") for a, b in pairs])
     return feats, lists
 
 
@@ -278,11 +298,10 @@ def bench_stream_oracle(H, W, n_sigma1=8):
     U = load_pkg()
     frames = U.synth.shift_stream(100, BENCH_STREAM_FRAMES, H, W)
     n = BENCH_STREAM_FRAMES
-    with oracle_pool() as ex:
-        feats = list(ex.map(_bench_oracle_worker, [("sp", f) for f in frames]))
-        jobs = [("pm", (feats[(j - 1) % n], feats[j], "ref")) for j in range(n)]
-        jobs += [("pm", (feats[j], feats[j + 1], "sigma1")) for j in range(n_sigma1)]
-        res = list(ex.map(_bench_oracle_worker, jobs))
+    feats = run_oracle_jobs("sp", [(f, 1000) for f in frames])
+    jobs = [(feats[(j - 1) % n], feats[j], "ref") for j in range(n)]
+    jobs += [(feats[j], feats[j + 1], "sigma1") for j in range(n_sigma1)]
+    res = run_oracle_jobs("pm", jobs)
     out = (frames, feats, {"ref": res[:n], "sigma1": res[n:]})
     _BENCH_ORACLE[(H, W)] = out
     return out

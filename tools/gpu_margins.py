@@ -105,6 +105,36 @@ for (H, W) in ((480, 640), (376, 1241)):
         big = Z0 > np.log(0.1)
         prec_rec["Z_abs_err_max_where_p_gt_0.1"].append(float(np.abs(Z1 - Z0)[big].max()) if big.any() else 0.0)
         prec_rec["Z_abs_err_max_all"].append(float(np.abs(Z1 - Z0).max()))
+        eb = np.abs(Z1 - Z0)[big]
+        prec_rec.setdefault("Z_abs_err_rms_where_p_gt_0.1", []).append(float(np.sqrt((eb ** 2).mean())))
+        prec_rec.setdefault("Z_abs_err_p99_where_p_gt_0.1", []).append(float(np.quantile(eb, 0.99)))
+        # couplings (the input of the Sinkhorn iterations): the GNN's own error, without the two Sinkhorn forms
+        import ctypes as C_
+        n0_, n1_ = nf0.shape[0], nf1.shape[0]
+        Cs = []
+        for p_ in (0, 1):
+            sgs[p_].infer(nf0, nf1)
+            Cm = np.zeros((n0_ + 1, n1_ + 1), np.float32)
+            assert U._lib.lib().urf_sg_debug_couplings(sgs[p_]._h, n0_, n1_, Cm.ctypes.data_as(C_.c_void_p)) == 0
+            Cs.append(Cm)
+        prec_rec.setdefault("C_abs_err_max", []).append(float(np.abs(Cs[1] - Cs[0]).max()))
+        prec_rec.setdefault("C_abs_err_max_where_p_gt_0.1", []).append(float(np.abs(Cs[1] - Cs[0])[big].max()) if big.any() else 0.0)
+        prec_rec.setdefault("C_abs_max", []).append(float(np.abs(Cs[0]).max()))
+        # input-induced: the EXACT matcher on the fast mode's features (descriptors differ at the 1e-6 level) vs on the exact ones,
+        # rows / columns aligned by keypoint coordinates
+        g0, g1 = feats[1][t - 1], feats[1][t]
+        if g0.shape == feats[0][t - 1].shape and g1.shape == feats[0][t].shape:
+            def perm(a, b):      # index of each keypoint of a in b, or None when the sets differ
+                m_ = {(r[1], r[2]): i for i, r in enumerate(b)}
+                idx = [m_.get((r[1], r[2]), -1) for r in a]
+                return None if min(idx) < 0 else np.array(idx)
+            p0_, p1_ = perm(feats[0][t - 1], g0), perm(feats[0][t], g1)
+            if p0_ is not None and p1_ is not None:
+                Zi = sgs[0].infer(pm.NormalizeKeypoints(g0, 640, 512), pm.NormalizeKeypoints(g1, 640, 512), want_scores=True)[4]
+                Zi = Zi[:-1, :-1][np.ix_(p0_, p1_)]
+                di = np.abs(Zi - Z0[:-1, :-1])[big[:-1, :-1]]
+                prec_rec.setdefault("Z_input_induced_err_max_where_p_gt_0.1", []).append(float(di.max()) if di.size else 0.0)
+                prec_rec.setdefault("Z_input_induced_err_rms_where_p_gt_0.1", []).append(float(np.sqrt((di ** 2).mean())) if di.size else 0.0)
         prec_rec["mscore_abs_err_max"].append(float(max(np.abs(r[0][2] - r[1][2]).max(), np.abs(r[0][3] - r[1][3]).max())))
         prec_rec["idx_diff"].append(int((r[0][0] != r[1][0]).sum() + (r[0][1] != r[1][1]).sum()))
         prec_rec["matches"].append(int((r[0][0] >= 0).sum()))

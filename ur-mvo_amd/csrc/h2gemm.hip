@@ -25,7 +25,8 @@ constexpr int BK = 32;  // K chunk = one 32-deep MFMA step: small LDS/VGPR footp
 constexpr int HS = 48;  // LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
 
 // accumulators -> outputs.  acc[m][r]: cout tile m (16) x token tile r (16) of wave (wc, wr)
-template <bool TOUT>
+// R = token tiles (of 16) per wave: 2 for the 128-row workgroup tile, 1 for the 64-row one
+template <bool TOUT, int R = 2>
 __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2], int b, int cout_base, int row0, int wc,
                                             int wr, int px, int g) {
   if (a.xflags & 2) {   // timing diagnostics only: keep the accumulators alive without the store burst
@@ -33,7 +34,7 @@ __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2],
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t += acc[m][0][q] + acc[m][1][q];
+      for (int q = 0; q < 4; ++q) t += acc[m][0][q] + acc[m][R - 1][q];
     if (t == 123.456f && a.out) a.out[0] = t;
     return;
   }
@@ -41,8 +42,8 @@ __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2],
   if (TOUT) {
     // lane owns tokens 4g..4g+3 of r-tile for cout px of m-tile -> 8-byte stores along the token axis
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int tok = row0 + wr * 32 + r * 16 + 4 * g;
+    for (int r = 0; r < R; ++r) {
+      const int tok = row0 + wr * (16 * R) + r * 16 + 4 * g;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int co = cout_base + wc * 64 + m * 16 + px;
@@ -62,8 +63,8 @@ __device__ __forceinline__ void h2_epilogue(const H2Args &a, f32x4 (&acc)[4][2],
   }
   // epilogue: lane owns couts 4g..4g+3 of m-tile for row (token) px of r-tile
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = row0 + wr * 32 + r * 16 + px;
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + wr * (16 * R) + r * 16 + px;
     if (row >= a.rows) continue;
     const size_t ro = (size_t)b * a.out_bstride + (size_t)row * a.ld_out + cout_base + wc * 64 + 4 * g;
 #pragma unroll
@@ -132,13 +133,13 @@ __device__ long long g_gemm_stamps[2][8];
 #define GM_NOW() 0ll
 #endif
 
-template <bool TOUT>
-__device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
+// One workgroup tile: 128 couts x (64 R) rows of batch item b.  R = 2: wave (wc, wr) = 64 couts x 32 rows, 24 MFMAs per
+// chunk; R = 1 (64-row tile): 64 couts x 16 rows, 12 MFMAs -- the half tiles that balance a launch whose tile count is not a
+// multiple of the resident workgroups (below).  `first` = false: a previous tile of this workgroup has used the LDS stages.
+template <bool TOUT, int R>
+__device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm, int b, int cout_base, int row0, bool first) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z;
-  const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * 128;
-  if (a.counts && row0 >= a.counts[b]) return;
   const int wc = wave >> 2, wr = wave & 3;
   GM_STAMP(0);
   f32x4 acc[4][2];
@@ -147,7 +148,7 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
   // DMA role of this lane: instruction u (= plane), row block `wave`, row/slot from the lane id
   const int drow = wave * 16 + (lane >> 2);
   const int dkg = (lane & 3) ^ ((-(drow >> 2)) & 3);
-  const bool brow_ok = row0 + drow < a.rows;   // rows past the end are never stored: their LDS bytes may be stale
+  const bool brow_ok = drow < 64 * R && row0 + drow < a.rows;   // rows past the end are never stored: their LDS bytes may be stale
   const _Float16 *srcA_h = a.wh + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
   const _Float16 *srcA_l = a.wl + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
   const size_t xoff = (size_t)b * a.x_bstride + (size_t)(row0 + drow) * a.ldx + 8 * dkg;
@@ -168,9 +169,10 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
 
   // fragment read offsets (halfs) inside a plane: row r -> r*32 + 8*(g ^ sw(r)); sw depends on (r>>2)&3 = (px>>2)
   const int swz = 8 * (g ^ ((-(px >> 2)) & 3));
-  const int aoff = (wc * 64 + px) * BK + swz;   // + m*16*BK
-  const int boff = (wr * 32 + px) * BK + swz;   // + r*16*BK
+  const int aoff = (wc * 64 + px) * BK + swz;       // + m*16*BK
+  const int boff = (wr * 16 * R + px) * BK + swz;   // + r*16*BK
   const int nchunks = (a.xflags & 4) ? 1 : a.Cin / BK;
+  if (!first) __syncthreads();     // every wave is done with the fragments of the previous tile's last chunks
   issue(0, 0);
   [[maybe_unused]] long long t_wait = 0, t_sync = 0;   // diagnostic build: cycles spent waiting for the DMA / at the barrier
   GM_STAMP(1);
@@ -184,23 +186,23 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
     if (ch == 0) GM_STAMP(2);
     if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
     const _Float16 *st = hsm + (ch & 1) * 4 * GP;
-    f16x8 ah[4], al[4], bh[2], bl[2];
+    f16x8 ah[4], al[4], bh[R], bl[R];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       ah[m] = *(const f16x8 *)(st + aoff + m * 16 * BK);
       al[m] = *(const f16x8 *)(st + GP + aoff + m * 16 * BK);
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < R; ++r) {
       bh[r] = *(const f16x8 *)(st + 2 * GP + boff + r * 16 * BK);
       bl[r] = *(const f16x8 *)(st + 3 * GP + boff + r * 16 * BK);
     }
-    // all twelve fragment reads before the first MFMA: left alone, the scheduler re-reads the second token tile's two
+    // all fragment reads before the first MFMA: left alone, the scheduler re-reads the second token tile's two
     // fragments into the registers of the first after its twelve MFMAs, an LDS round trip in the middle of every chunk
     // (measured: +0.5 % in the pipeline, nothing serialised)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (TOUT) {  // D[row = token][col = cout]
@@ -218,8 +220,16 @@ __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm)
 #ifdef URF_GEMM_STAMPS
   if (blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 5)) { g_gemm_stamps[wave != 0][5] = t_wait; g_gemm_stamps[wave != 0][6] = t_sync; }
 #endif
-  h2_epilogue<TOUT>(a, acc, b, cout_base, row0, wc, wr, px, g);
+  h2_epilogue<TOUT, R>(a, acc, b, cout_base, row0, wc, wr, px, g);
   GM_STAMP(4);
+}
+
+template <bool TOUT>
+__device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
+  const int b = blockIdx.z;
+  const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * 128;
+  if (a.counts && row0 >= a.counts[b]) return;
+  h2gemm_glds_tile<TOUT, 2>(a, hsm, b, cout_base, row0, true);
 }
 
 // MODE 0: token-major outputs, 1: transposed outputs, 2: both in one launch (uniform branch per workgroup)
@@ -230,6 +240,29 @@ __global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
   else if (MODE == 1) h2gemm_glds_body<true>(a, hsm);
   else if ((int)blockIdx.y * 128 >= a.t_from) h2gemm_glds_body<true>(a, hsm);
   else h2gemm_glds_body<false>(a, hsm);
+}
+
+// MODE 3: the fused Q | K | V^T projection of a GNN layer (768 couts = 6 cout tiles, t_from = 512) on a grid of FOUR cout
+// slots per row tile: workgroup (x, j) computes the full Q|K tile j and then the 64-row half (j & 1) of the V^T tile 4 + (j >> 1).
+// 1.5 tiles per workgroup, 4 x rows/128 workgroups per image: 512 workgroups for 16 images = the resident set of the chip,
+// instead of 768 tiles in one and a half rounds (the second round half empty).
+__global__ void __launch_bounds__(512, 4) h2gemm_glds_qkv_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];
+  const int b = blockIdx.z, row0 = blockIdx.x * 128, j = blockIdx.y;
+  if (a.counts && row0 >= a.counts[b]) return;
+  h2gemm_glds_tile<false, 2>(a, hsm, b, j * 128, row0, true);
+  const int hrow0 = row0 + 64 * (j & 1);
+  if (a.counts && hrow0 >= a.counts[b]) return;     // workgroup-uniform
+  h2gemm_glds_tile<true, 1>(a, hsm, b, 512 + (j >> 1) * 128, hrow0, false);
+}
+
+// MODE 4: 64-row tiles (token-major outputs): launches with few cout tiles (Cout = 256: 2) fill the chip's resident set with
+// twice the workgroups of half the size
+__global__ void __launch_bounds__(512, 4) h2gemm_glds_half_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];
+  const int b = blockIdx.z, row0 = blockIdx.x * 64;
+  if (a.counts && row0 >= a.counts[b]) return;
+  h2gemm_glds_tile<false, 1>(a, hsm, b, blockIdx.y * 128, row0, true);
 }
 
 template <bool TOUT, int WC, int WR>
@@ -378,13 +411,22 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set.mark();
     }
+    // URF_H2GEMM_BALANCE (default 3): bit 0 = the 1.5-tile Q|K|V^T kernel, bit 1 = 64-row tiles for launches of <= 2 cout tiles
+    static int balance = -1;
+    if (balance < 0) { const char *e = getenv("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 3; }
     static int nt = -1;
     if (nt < 0) { const char *e = getenv("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;
     b.xflags = g_h2gemm_xflags | nt;
-    if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, b);
+    if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768)
+      hipLaunchKernelGGL(h2gemm_glds_qkv_kernel, dim3((a.rows + 127) / 128, 4, batch), dim3(512), lds, st, b);
+    else if ((balance & 2) && !a.ohT && a.Cout <= 256)
+      hipLaunchKernelGGL(h2gemm_glds_half_kernel, dim3((a.rows + 63) / 64, a.Cout / 128, batch), dim3(512), lds, st, b);
+    else if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, b);
     else if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<1>), grid, dim3(512), lds, st, b);
     else hipLaunchKernelGGL((h2gemm_glds_kernel<0>), grid, dim3(512), lds, st, b);
     URF_HIP(hipGetLastError());
