@@ -46,9 +46,12 @@ typedef struct {
    * 3x3 convolutions run on the f16 matrix core with split operands
    * (fp32-equivalent accuracy, not bit-reproducible);
    * 2 = guarded fast: as 1, and every discrete decision (NMS maximum, 0.0005 threshold, top-k cut) that sits closer to
-   * its alternative than the fast mode's error is detected on the device; such a frame is redone in the exact mode
-   * inside the library before its slot is handed on (slot header word 1 = 1), so the keypoint SET of every frame is the
-   * exact mode's.  urf_sp_near_tie_reruns() counts them. */
+   * its alternative than the fast mode's error is detected on the device.  A top-k cut with up to 8 candidates inside
+   * the error band is resolved per candidate: the exact mode's convolution stack is run on just the receptive fields
+   * of their cells and the band's members are ranked by their exact scores.  Any other near-tie: the frame is redone
+   * in the exact mode inside the library before its slot is handed on.  Slot header word 1 says which: 1 = redone
+   * whole, 2 = cut resolved per candidate, 0 = the fast pass stands.  Either way the
+   * keypoint SET of every frame is the exact mode's.  urf_sp_near_tie_reruns() counts both. */
   int precision;
 } urf_sp_config;
 
@@ -90,9 +93,10 @@ int urf_sp_sync(urf_sp *h);
  * producer of the slot must have finished (urf_sp_sync, or a fetched match batch that consumed it). */
 int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K);
 
-/* guarded fast mode (precision 2), counters since build(): out[0] = frames redone in the exact mode, out[1] = frames
- * processed, out[2..4] = frames flagged by the top-k cut / the threshold band / an NMS near-tie (n <= 8 values are
- * written; zeros in the other modes).  Waits for the handle's stream. */
+/* guarded fast mode (precision 2), counters since build(): out[0] = frames redone whole in the exact mode, out[1] =
+ * frames processed, out[2] = frames whose top-k cut was resolved per candidate, out[3..5] = frames flagged by the
+ * threshold band / an NMS near-tie / more than 8 candidates at the cut (these are the frames of out[0]), out[6] =
+ * candidates resolved (n <= 8 values are written; zeros in the other modes).  Waits for the handle's stream. */
 int urf_sp_near_tie_reruns(urf_sp *h, unsigned long long *out, int n);
 
 /* debug / parity taps (tests): dense tensors of the LAST single-frame call.

@@ -228,3 +228,29 @@ def test_register_and_lds_budgets_keep_the_pipeline_coresident(tmp_path):
     assert attn[0][1] == 0
     conv_lds = 2 * (2 * 2 * 64 * 64 + 2 * 10 * 18 * 64) + 12 * 20 * 4   # launch_h2conv's dynamic LDS, fused variant
     assert attn[0][2] + conv_lds <= 160 * 1024
+
+
+def test_integration_patches_apply_to_the_reference(tmp_path):
+    """integration/*.patch (the batched caller in Tracking and the pybind engine) apply cleanly to the
+    reference tree they were diffed against; and every urf_* call they add is a symbol of the C ABI"""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    patches = [os.path.join(ROOT, "integration", n) for n in ("tracking.patch", "main_py.patch")]
+    text = "".join(open(p).read() for p in patches)
+    added = set(re.findall(r"^\+.*?\b(urf_[a-z_]+)\(", text, re.M))
+    assert {"urf_fe_create", "urf_fe_build_files", "urf_fe_submit", "urf_fe_collect", "urf_fe_destroy"} <= added
+    from conftest import load_pkg
+    assert added - {"urf_shim_precision"} <= set(load_pkg()._lib.SYMBOLS)
+    assert "usleep(30000)" in text and "-        usleep(30000);" in text
+    if not os.path.isdir(ref) or not shutil.which("patch"):
+        pytest.skip("reference tree (or patch) not available here")
+    for rel in ("src/tracking.cc", "include/tracking.h", "main_py.cpp"):
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        shutil.copy(os.path.join(ref, rel), tmp_path / rel)
+    for p in patches:
+        subprocess.run(["patch", "-p1", "--dry-run", "-i", p], cwd=tmp_path, check=True, capture_output=True)
+        subprocess.run(["patch", "-p1", "-i", p], cwd=tmp_path, check=True, capture_output=True)
+    out = open(tmp_path / "src" / "tracking.cc").read()
+    assert "ExtractFeatureBatch" in out and "std::thread point_ectraction_thread" not in out
+    assert "usleep(30000);" not in open(tmp_path / "main_py.cpp").read()

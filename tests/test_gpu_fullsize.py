@@ -237,7 +237,8 @@ def test_bench_stream_keypoints_vs_the_reference_graph(U, F, sp_blob, H, W, prec
 
 
 def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp_blob, sg_blob, monkeypatch):
-    """the redo machinery of the guarded fast mode, forced: with an absurd error model every frame and every pair is flagged,
+    """the redo machinery of the guarded fast mode, forced: with an absurd error model every frame and every pair is flagged
+    (the band around the top-k cut holds every candidate: too many to resolve one by one, so the frames are redone whole),
     so every slot must come out of the exact pass (header word 1 set, features bit-identical to the oracle's) and every
     match list must be the exact mode's, through the device batch path, the frame API and the pair API; the counters say so.
     With the product constants the same frames are NOT flagged wholesale (rates: bench line)."""
@@ -280,6 +281,38 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
     sp2.infer_device(d.data_ptr(), 4, H, W, slots.data_ptr())
     sp2.sync()
     assert sp2.near_tie_reruns()["frames"] == 4 and sp2.near_tie_reruns()["redone"] <= 1
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (376, 1241)])
+def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H, W, monkeypatch):
+    """the per-candidate resolution of the top-k cut: with a widened error band (about six candidates at the cut of every
+    frame) the exact mode's convolution stack runs on just the receptive fields of their cells; the resolved candidates
+    carry the EXACT mode's scores bit for bit (checked on the keypoint at the cut, which is always one of them) and the
+    keypoint set is the oracle's.  With the product constants the same machinery runs on roughly every second frame of the
+    bench streams (the bench line counts them)."""
+    import torch
+    frames, ofeats, _ = bench_stream_oracle(H, W)
+    monkeypatch.setenv("URF_GUARD_SP_ULPS", "300")
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=2)
+    assert sp.build(sp_blob)
+    monkeypatch.delenv("URF_GUARD_SP_ULPS")
+    d = torch.from_numpy(np.stack(frames[:16])).cuda()
+    slots = torch.zeros((16, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for b0 in (0, 8):
+        sp.infer_device(d[b0].data_ptr(), 8, H, W, slots[b0].data_ptr())
+    sp.sync()
+    hdr = slots[:, :4].cpu().numpy().view(np.int32)
+    st = sp.near_tie_reruns()
+    assert st["frames"] == 16 and st["cut_resolved"] >= 8 and st["cut_resolved"] + st["redone"] == int((hdr[:, 1] != 0).sum())
+    assert st["candidates"] >= 2 * st["cut_resolved"]
+    for j in range(16):
+        f = F.slot_to_host(slots[j].data_ptr())
+        assert {(r[1], r[2]) for r in f} == {(r[1], r[2]) for r in ofeats[j]}, j
+        if hdr[j, 1] == 2:      # resolved per candidate: the keypoint at the cut carries the exact mode's score
+            assert np.float32(f[:, 0].min()) == np.float32(ofeats[j][:, 0].min()), j
+        elif hdr[j, 1] == 1:    # redone whole: the oracle's features
+            assert np.array_equal(f[:, :3], ofeats[j][:, :3]), j
 
 
 # ------------------------------------------------------------------ (d) seeded sweeps (tools/gpu_sweep*.py as tests)

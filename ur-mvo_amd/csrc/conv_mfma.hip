@@ -50,6 +50,24 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     x0 = blockIdx.x * (TH * TW);
     if (a.counts && x0 >= a.counts[b]) return;  // rows beyond this item's count
   }
+  if (a.gate && a.t_scale != 0) {
+    // a redo slot that only needs the scores of a few cells: is this tile within reach of one of them?  (workgroup-uniform)
+    const int nt = a.gate[kGateMode + b];
+    if (nt >= 0) {
+      if (a.t_scale < 0) return;
+      bool needed = false;
+      for (int t = 0; t < nt; ++t) {
+        const int cell = a.gate[kGateTargets + kAmbMax * b + t];
+        if (TAPS == 9) {
+          const int fy = (cell / a.t_wc) * a.t_scale, fx = (cell % a.t_wc) * a.t_scale;
+          needed = needed || (y0 + TH > fy - a.t_rad && y0 < fy + a.t_scale + a.t_rad && x0 + TW > fx - a.t_rad && x0 < fx + a.t_scale + a.t_rad);
+        } else {
+          needed = needed || (cell >= x0 && cell < x0 + TH * TW);
+        }
+      }
+      if (!needed || cout_base >= 256) return;   // (the score head is channels 0..255 of the fused Pa || Da layer)
+    }
+  }
 
   f32x4 acc[4][2];
 #pragma unroll

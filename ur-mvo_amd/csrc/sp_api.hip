@@ -38,7 +38,7 @@ const char *last_error() {
 int g_profiling = 0;
 // guarded fast mode, SuperPoint: error model of a fast-mode score, delta * s * (1 - s) + ulps * ulp(s) (sp_kernels.hip);
 // measured maxima on both bench streams times a safety factor (DESIGN.md "Guarded fast mode", tools/gpu_margins.py)
-static const float kGuardSpDelta = 2e-5f, kGuardSpUlps = 4.0f;
+static const float kGuardSpDelta = 2e-4f, kGuardSpUlps = 32.0f;
 
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
 int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, const int *gate, hipStream_t st);
@@ -51,9 +51,12 @@ int select_nchunk(int H, int W);
 int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out, const int *gate, int ncell_frame,
                      hipStream_t st);
 int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, const int *kp_idx, const int *kp_n,
-                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, hipStream_t st);
-int launch_guard_compact(const int *flags, int B, const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs, int *gate,
-                         unsigned long long *stats, hipStream_t st);
+                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, const int *guard_flags,
+                  hipStream_t st);
+int launch_guard_compact(const int *flags, const int *amb, int B, int Ws, int Wc, const uint8_t *imgs, size_t img_bytes,
+                         uint8_t *redo_imgs, int *gate, unsigned long long *stats, hipStream_t st);
+int launch_guard_resolve(const int *gate, const int *amb, const float *heat_x, int HsWs, float *kp_score, int *kp_idx,
+                         const int *kp_n, int B, hipStream_t st);
 
 struct ConvSpec { int cin, cout, k; };
 static const ConvSpec kSpConv[12] = {{1, 64, 3},    {64, 64, 3},   {64, 64, 3},   {64, 64, 3},
@@ -100,7 +103,7 @@ struct urf_sp {
   uint8_t *d_img = nullptr, *d_usermask = nullptr;
   int cand_cap = 0;
   // guarded fast mode: guard words, threshold-band scratch, redo list (gate), images of the frames to redo, counters
-  int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr;
+  int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr, *g_amb = nullptr;
   uint8_t *g_img = nullptr;
   unsigned long long *g_stats = nullptr;
   float g_delta = 0.0f, g_ulps = 0.0f;
@@ -307,7 +310,10 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     // words and the redo list.  Error model of a fast-mode score (sp_kernels.hip): measured by tools/gpu_margins.py on
     // both bench streams (DESIGN.md "Guarded fast mode"), overridable for experiments.
     if (arena(h->R, false)) return -1;
-    if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, B + 1) || dalloc(&h->g_stats, 8)) return -1;
+    URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
+    if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) ||
+        dalloc(&h->g_amb, B * (1 + kAmbMax)))
+      return -1;
     if (dalloc(&h->g_img, B * H * W)) return -1;
     const char *e;
     h->g_delta = (e = getenv("URF_GUARD_SP_DELTA")) ? (float)atof(e) : kGuardSpDelta;
@@ -377,7 +383,7 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     for (void *p : bufs) (void)hipFree(p);
     void *rbufs[] = {h->R.a1, h->R.a2a, h->R.a2b, h->R.a3a, h->R.a3b, h->R.a4a, h->R.a4b, h->R.apd, h->R.logits, h->R.ddb, h->R.desc,
                      h->R.heat, h->R.scores, h->R.ss, h->R.mask, h->R.supp, h->R.counts, h->R.cand_score, h->R.cand_idx, h->R.cand_n,
-                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats};
+                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb};
     for (void *p : rbufs) (void)hipFree(p);
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
@@ -441,19 +447,24 @@ static int sp_convs_fast(urf_sp *h, const SpArena &A, int B, const uint8_t *d_im
 // The kernel pipeline for B frames already resident in h->d_img (or d_imgs), in arena A.  fast: split-f16 convolutions
 // (else exact fp32).  gate != null: the redo pass of the guarded fast mode -- every kernel skips batch items >= gate[0] and
 // the results of item r go to the caller's item gate[1 + r].  guard.flags != null: the near-tie guard of the fast pass.
+// part: 1 = up to the softmax, 2 = NMS and selection, 4 = descriptor normalisation and sampling (bit mask; 7 = everything).
 static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const uint8_t *d_imgs, int H, int W,
                           const uint8_t *d_mask, double *d_feat, float *d_slots, const int *gate, const SpGuard &guard,
-                          int *kp_n_out, bool timed) {
+                          int *kp_n_out, bool timed, int part = 7) {
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
   const int Hs = H8 * 8, Ws = W8 * 8;
   hipStream_t st = h->st;
   const float *wt = h->d_wts;
   const bool prof = urf::g_profiling != 0 && timed;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
+  // target gating of the redo pass (urf_common.h): pixels per cell at the layer's resolution and the reach, in that
+  // layer's pixels, within which a cell's logits depend on the layer's output
+  const int W8c = W8;
+  const int ncell = H8 * W8;
   auto conv3 = [&](const float *in, int cin, int hh, int ww, const float *w, const float *b, int cout, float *out,
-                   bool pool) {
+                   bool pool, int t_scale, int t_rad) {
     ConvArgs a = {};
-    a.gate = gate;
+    a.gate = gate; a.t_scale = t_scale; a.t_rad = t_rad; a.t_wc = W8c;
     a.in = in; a.in_ld = cin; a.in_coff = 0; a.in_bstride = (long)hh * ww * cin;
     a.H = hh; a.W = ww; a.Cin = cin; a.w = w; a.bias = b; a.Cout = cout;
     a.out = out; a.out_ld = cout; a.out_coff = 0;
@@ -461,13 +472,14 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
     a.relu = 1;
     return launch_conv(a, 9, pool, false, B, st);
   };
+  if (part & 1) {
   if (fast) {
     if (sp_convs_fast(h, A, B, d_imgs, H, W)) return -1;
   } else {
   mark(ST_CONV1);
   {  // conv1a (fused, VALU) + conv1b + relu + pool
     ConvArgs a = {};
-    a.gate = gate;
+    a.gate = gate; a.t_scale = 8; a.t_rad = 36; a.t_wc = W8c;
     a.in = d_imgs; a.in_bstride = (long)H * W; a.H = H; a.W = W; a.Cin = 64;
     a.w = wt + h->w_off[1]; a.bias = wt + h->b_off[1]; a.Cout = 64;
     a.out = A.a1; a.out_ld = 64; a.out_bstride = (long)H2 * W2 * 64; a.relu = 1;
@@ -475,21 +487,20 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
     if (launch_conv(a, 9, true, true, B, st)) return -1;
   }
   mark(ST_CONV2A);
-  if (conv3(A.a1, 64, H2, W2, wt + h->w_off[2], wt + h->b_off[2], 64, A.a2a, false)) return -1;
+  if (conv3(A.a1, 64, H2, W2, wt + h->w_off[2], wt + h->b_off[2], 64, A.a2a, false, 4, 17)) return -1;
   mark(ST_CONV2B);
-  if (conv3(A.a2a, 64, H2, W2, wt + h->w_off[3], wt + h->b_off[3], 64, A.a2b, true)) return -1;
+  if (conv3(A.a2a, 64, H2, W2, wt + h->w_off[3], wt + h->b_off[3], 64, A.a2b, true, 4, 16)) return -1;
   mark(ST_CONV3A);
-  if (conv3(A.a2b, 64, H4, W4, wt + h->w_off[4], wt + h->b_off[4], 128, A.a3a, false)) return -1;
+  if (conv3(A.a2b, 64, H4, W4, wt + h->w_off[4], wt + h->b_off[4], 128, A.a3a, false, 2, 7)) return -1;
   mark(ST_CONV3B);
-  if (conv3(A.a3a, 128, H4, W4, wt + h->w_off[5], wt + h->b_off[5], 128, A.a3b, true)) return -1;
+  if (conv3(A.a3a, 128, H4, W4, wt + h->w_off[5], wt + h->b_off[5], 128, A.a3b, true, 2, 6)) return -1;
   mark(ST_CONV4A);
-  if (conv3(A.a3b, 128, H8, W8, wt + h->w_off[6], wt + h->b_off[6], 128, A.a4a, false)) return -1;
+  if (conv3(A.a3b, 128, H8, W8, wt + h->w_off[6], wt + h->b_off[6], 128, A.a4a, false, 1, 2)) return -1;
   mark(ST_CONV4B);
-  if (conv3(A.a4a, 128, H8, W8, wt + h->w_off[7], wt + h->b_off[7], 128, A.a4b, false)) return -1;
+  if (conv3(A.a4a, 128, H8, W8, wt + h->w_off[7], wt + h->b_off[7], 128, A.a4b, false, 1, 1)) return -1;
   mark(ST_PADA);
-  if (conv3(A.a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, A.apd, false)) return -1;
+  if (conv3(A.a4b, 128, H8, W8, wt + h->wpd_off, wt + h->bpd_off, 512, A.apd, false, 1, 0)) return -1;   // (of a target-gated slot only the score head's 256 channels)
   }
-  const int ncell = H8 * W8;
   int logit_ld = 68;
   if (fast) {
     // the two 1x1 heads as split-f16 GEMMs on the planes of Pa || Da ([cells][512]: hi plane, then lo plane)
@@ -515,7 +526,7 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
   mark(ST_PB);
   {  // convPb 1x1 on channels [0,256) of apd -> logits (68-wide rows)
     ConvArgs a = {};
-    a.gate = gate;
+    a.gate = gate; a.t_scale = 1; a.t_rad = 0; a.t_wc = W8c;
     a.in = A.apd; a.in_ld = 512; a.in_coff = 0; a.in_bstride = (long)ncell * 512;
     a.H = 1; a.W = ncell; a.Cin = 256; a.w = wt + h->wpb_off; a.bias = wt + h->bpb_off; a.Cout = 68;
     a.out = A.logits; a.out_ld = 68; a.out_bstride = (long)ncell * 68; a.relu = 0;
@@ -524,7 +535,7 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
   mark(ST_DB);
   {  // convDb 1x1 on channels [256,512)
     ConvArgs a = {};
-    a.gate = gate;
+    a.gate = gate; a.t_scale = -1;     // not needed for scores: target-gated slots skip it
     a.in = A.apd; a.in_ld = 512; a.in_coff = 256; a.in_bstride = (long)ncell * 512;
     a.H = 1; a.W = ncell; a.Cin = 256; a.w = wt + h->w_off[11]; a.bias = wt + h->b_off[11]; a.Cout = 256;
     a.out = A.ddb; a.out_ld = 256; a.out_bstride = (long)ncell * 256; a.relu = 0;
@@ -533,6 +544,8 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
   }
   mark(ST_SOFTMAX);
   if (launch_softmax(A.logits, logit_ld, H8, W8, A.heat, B, gate, st)) return -1;
+  }   // part & 1
+  if (part & 2) {
   mark(ST_NMS);
   // a maximum below thr_lo can never become a keypoint (nor can anything it suppresses): no near-tie there matters
   const float thr_lo = (float)(h->cfg.keypoint_threshold * 0.5);
@@ -542,28 +555,39 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
                     A.cand_score, A.cand_idx, h->cand_cap, A.cand_n, h->cfg.max_keypoints, A.kp_score,
                     A.kp_idx, A.kp_n, B, gate, guard, st))
     return -1;
+  }   // part & 2
+  if (!(part & 4)) return 0;
   mark(ST_DNORM);
   if (launch_desc_norm(A.ddb, 256, 0, B * ncell, A.desc, gate, ncell, st)) return -1;
   mark(ST_SAMPLE);
-  if (launch_sample(A.desc, H8, W8, A.kp_score, A.kp_idx, A.kp_n, Ws, d_feat, d_slots, B, gate, kp_n_out, st)) return -1;
+  if (launch_sample(A.desc, H8, W8, A.kp_score, A.kp_idx, A.kp_n, Ws, d_feat, d_slots, B, gate, kp_n_out,
+                    (h->precision == 2 && !gate) ? h->g_flags : nullptr, st))
+    return -1;
   mark(ST_DOWNLOAD);
   return 0;
 }
 
-// precision 0 / 1: one pass.  precision 2 (guarded fast): the fast pass with the near-tie guard, then the exact pass over the
-// redo list -- enqueued unconditionally, its kernels exit at once for frames that are not on the list (normally all).
+// precision 0 / 1: one pass.  precision 2 (guarded fast): the fast pass up to the top-k selection with the near-tie guard;
+// the redo list; the exact pass over it -- enqueued unconditionally, its kernels exit at once for frames that are not on the
+// list and compute only the tiles that reach a target cell for frames whose sole ambiguity is the top-k cut; the
+// per-candidate resolution of those cuts; then the descriptor tail of the fast pass, and of the exact pass for the frames
+// redone whole.
 static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, const uint8_t *d_mask, double *d_feat,
                        float *d_slots) {
   SpGuard g = {};
   h->lastH = H; h->lastW = W; h->lastB = B;
   if (h->precision != 2) return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true);
-  g.flags = h->g_flags; g.band = h->g_band; g.delta = h->g_delta; g.ulps = h->g_ulps;
+  const int Hs = H / 8 * 8, Ws = W / 8 * 8;
+  g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.delta = h->g_delta; g.ulps = h->g_ulps;
+  SpGuard off = {};
   URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), h->st));
   URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), h->st));
-  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true)) return -1;
-  if (launch_guard_compact(h->g_flags, B, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, h->st)) return -1;
-  SpGuard off = {};
-  return sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false);
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3)) return -1;
+  if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, h->st)) return -1;
+  if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, nullptr, false, 3)) return -1;
+  if (launch_guard_resolve(h->g_gate, h->g_amb, h->R.heat, Hs * Ws, h->A.kp_score, h->A.kp_idx, h->A.kp_n, B, h->st)) return -1;
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, off, nullptr, true, 4)) return -1;
+  return sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false, 4);
 }
 
 static int sp_check_dims(urf_sp *h, int B, int rows, int cols) {

@@ -32,6 +32,8 @@ __device__ __forceinline__ bool guard_near(float a, float b, const SpGuard &g) {
   return d <= guard_err(a, g.delta, g.ulps) + guard_err(b, g.delta, g.ulps);
 }
 #define URF_GATE(idx) if (gate && (int)(idx) >= gate[0]) return
+// the exact tail (NMS, selection, descriptors) only runs for slots whose whole frame is redone
+#define URF_GATE_FULL(idx) if (gate && ((int)(idx) >= gate[0] || gate[kGateMode + (int)(idx)] >= 0)) return
 
 // ------------------------------------------------------------------ softmax
 // logits [B][Hc*Wc][ld] (65 used) -> heat [B][Hs][Ws].  One lane per cell:
@@ -42,6 +44,11 @@ __global__ void __launch_bounds__(256) softmax_d2s_kernel(const float *logits, i
   const int b = blockIdx.y;
   URF_GATE(b);
   if (cell >= Hc * Wc) return;
+  if (gate && gate[kGateMode + b] >= 0) {   // a slot that only needs the scores of its target cells
+    bool needed = false;
+    for (int t = 0; t < gate[kGateMode + b]; ++t) needed = needed || gate[kGateTargets + kAmbMax * b + t] == cell;
+    if (!needed) return;
+  }
   const float *l = logits + ((size_t)b * Hc * Wc + cell) * ld;
   float v[65];
   float m = l[0];
@@ -77,7 +84,7 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
   __shared__ float tin[(NR + 8)][(NC + 8)];
   __shared__ float hm[(NR + 8)][NC];
   const int b = blockIdx.z;
-  URF_GATE(b);
+  URF_GATE_FULL(b);
   bool near_tie = false;
   const size_t boff = (size_t)b * H * W;
   const int y0 = blockIdx.y * NR, x0 = blockIdx.x * NC;
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const float *scores, int
                                                         SpGuard g) {
   __shared__ int wsum[16];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  URF_GATE(b);
+  URF_GATE_FULL(b);
   const size_t boff = (size_t)b * H * W;
   const int base = chunk * SEL_PIX + threadIdx.x * 8;
   int c = 0;
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(256) sel_scatter_kernel(const float *scores, i
   __shared__ int wsum[16];
   __shared__ int s_off;
   const int b = blockIdx.y, chunk = blockIdx.x;
-  URF_GATE(b);
+  URF_GATE_FULL(b);
   const size_t boff = (size_t)b * H * W;
   // offset of this chunk = sum of the counts of earlier chunks (integers: exact)
   int part = 0;
@@ -286,7 +293,7 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
   __shared__ int s_rank, s_cnt;
   __shared__ unsigned s_next[16];
   const int b = blockIdx.x, tid = threadIdx.x;
-  URF_GATE(b);
+  URF_GATE_FULL(b);
   const int n = cand_n[b];
   const float *cs = cand_score + (size_t)b * cand_cap;
   const int *ci = cand_idx + (size_t)b * cand_cap;
@@ -347,15 +354,35 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
     __syncthreads();
     if ((tid & 63) == 0) { s_next[tid >> 6] = nx; wsum[tid >> 6] = eq_total; }
     __syncthreads();
+    const float cut = __uint_as_float(T);
     if (tid == 0) {
       int eq = 0;
       for (int w = 0; w < 16; ++w) { nx = s_next[w] > nx ? s_next[w] : nx; eq += wsum[w]; }
-      const float cut = __uint_as_float(T);
       const float nxt = eq > need_eq ? cut : __uint_as_float(nx);
       int bits = 0;
       if (guard_near(cut, nxt, g)) bits |= 1;
       // a pixel within its error of the threshold matters only if it could enter the top k
       if (g.band[b] && guard_near(cut, thr, g)) bits |= 2;
+      s_cnt = bits;
+      g.amb[(size_t)b * (1 + kAmbMax)] = 0;
+    }
+    __syncthreads();
+    if (s_cnt & 1) {
+      // the candidates within the error of the cut, on either side: their exact scores decide who is in (guard_resolve_kernel).
+      // One uniform error for the band (the scores in it differ by 1e-5 at most): 2 x 1.25 x err(cut)
+      const float band = 2.5f * guard_err(cut, g.delta, g.ulps);
+      for (int i = tid; i < n; i += 1024) {
+        const float d = cs[i] > cut ? cs[i] - cut : cut - cs[i];
+        if (d <= band) {
+          const int p = atomicAdd(&g.amb[(size_t)b * (1 + kAmbMax)], 1);
+          if (p < kAmbMax) g.amb[(size_t)b * (1 + kAmbMax) + 1 + p] = ci[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int bits = s_cnt;
+      if ((bits & 1) && g.amb[(size_t)b * (1 + kAmbMax)] > kAmbMax) bits |= 8;   // too many to resolve one by one: the whole frame
       if (bits) atomicOr(&g.flags[b], bits);
     }
     __syncthreads();
@@ -408,7 +435,7 @@ __global__ void __launch_bounds__(256) desc_norm_kernel(float *desc, int ld, int
   const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (cell >= ncell) return;
-  if (gate && cell >= gate[0] * ncell_frame) return;
+  if (gate && (cell >= gate[0] * ncell_frame || gate[kGateMode + cell / ncell_frame] >= 0)) return;
   const f32x4 v = *(const f32x4 *)(desc + (size_t)cell * ld + coff + 4 * lane);
   float a = v[0] * v[0];
   a = __builtin_fmaf(v[1], v[1], a);
@@ -433,11 +460,11 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
                                                      const float *kp_score, const int *kp_idx, const int *kp_n,
                                                      int Ws, double *feat /*[B][kCap][259] or null*/,
                                                      float *slots /*[B][kSlotFloats] or null*/, const int *gate,
-                                                     int *kp_n_out) {
+                                                     int *kp_n_out, const int *guard_flags) {
   __shared__ double vals[4][256];
   __shared__ double s_inv[4];
   const int b = blockIdx.y;
-  URF_GATE(b);
+  URF_GATE_FULL(b);
   // redo of a flagged frame in the exact mode: arena item b goes to the caller's item gate[1 + b]; hdr[1] = 1 marks the slot
   const int ob = gate ? gate[1 + b] : b;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -446,7 +473,8 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (slots) {
       int *hdr = (int *)(slots + (size_t)ob * kSlotFloats);
-      hdr[0] = n; hdr[1] = gate ? 1 : 0; hdr[2] = 0; hdr[3] = 0;
+      // word 1: 1 = the frame was redone whole in the exact mode, 2 = its top-k cut was resolved per candidate (guarded fast mode)
+      hdr[0] = n; hdr[1] = gate ? 1 : ((guard_flags && guard_flags[b] == 1) ? 2 : 0); hdr[2] = 0; hdr[3] = 0;
     }
     if (kp_n_out) kp_n_out[ob] = n;
   }
@@ -514,11 +542,14 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
 }
 
 // ----------------------------------------------------------------- guard redo
-// After the fast pipeline of a batch: frames whose guard word is set go to the redo list, their u8 images to the redo arena.
-// One workgroup per frame.  gate[0] = count, gate[1 + r] = frame of redo slot r.  stats: [0] frames redone, [1] frames seen,
-// [2..4] frames flagged by the top-k cut / the threshold band / the NMS.
-__global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, int B, const uint8_t *imgs, size_t img_bytes,
-                                                            uint8_t *redo_imgs, int *gate, unsigned long long *stats) {
+// After the fast pass of a batch (up to the top-k selection): frames whose guard word is set go to the redo list (layout:
+// urf_common.h), their u8 images to the redo arena.  A frame whose only ambiguity is the top-k cut needs nothing but the exact
+// scores of the cells of a few candidates (mode = their number, targets = their cells); any other bit: the whole frame.
+// One workgroup per frame.  stats: [0] frames redone whole, [1] frames seen, [2] frames with a cut resolved per candidate,
+// [3] threshold band, [4] NMS near-tie, [5] too many candidates at the cut, [6] candidates resolved.
+__global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, const int *amb, int B, int Ws, int Wc,
+                                                            const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs,
+                                                            int *gate, unsigned long long *stats) {
   const int b = blockIdx.x;
   int r = 0, total = 0;
   for (int i = 0; i < B; ++i) {
@@ -530,14 +561,23 @@ __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, in
   if (threadIdx.x == 0) {
     if (b == 0) {
       gate[0] = total;
-      atomicAdd(&stats[0], (unsigned long long)total);
       atomicAdd(&stats[1], (unsigned long long)B);
     }
     if (mine) {
       gate[1 + r] = b;
-      if (mine & 1) atomicAdd(&stats[2], 1ull);
+      const bool whole = (mine & ~1) != 0;
+      const int na = amb[(size_t)b * (1 + kAmbMax)];
+      gate[kGateMode + r] = whole ? -1 : na;
+      if (!whole)
+        for (int t = 0; t < na; ++t) {
+          const int pix = amb[(size_t)b * (1 + kAmbMax) + 1 + t];
+          gate[kGateTargets + kAmbMax * r + t] = ((pix / Ws) >> 3) * Wc + ((pix % Ws) >> 3);
+        }
+      if (whole) atomicAdd(&stats[0], 1ull);
+      else { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[6], (unsigned long long)na); }
       if (mine & 2) atomicAdd(&stats[3], 1ull);
       if (mine & 4) atomicAdd(&stats[4], 1ull);
+      if (mine & 8) atomicAdd(&stats[5], 1ull);
     }
   }
   if (!mine) return;
@@ -549,6 +589,75 @@ __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, in
     for (size_t i = threadIdx.x; i < img_bytes / 16; i += 256) d4[i] = s4[i];
   } else {
     for (size_t i = threadIdx.x; i < img_bytes; i += 256) dst[i] = src[i];
+  }
+}
+
+// Per-candidate resolution of the top-k cut.  Slot r (mode >= 0) of the redo list: the candidates of frame b within the fast
+// mode's error of the cut (amb) now have exact scores (heat_x = the exact mode's heat map of the slot, valid at their cells).
+// Everything above the band is in the exact mode's top k, everything below it is out (the band is wider than twice the error);
+// the places the band's members held in the fast top k go to the band's best by (exact score descending, raster index
+// ascending) -- the exact mode's own rule.  The frame's keypoint list is rewritten in place, in score order, the band's members
+// carrying their exact scores.  One 1024-thread workgroup per redo slot.
+__global__ void __launch_bounds__(1024) guard_resolve_kernel(const int *gate, const int *amb, const float *heat_x, int HsWs,
+                                                             float *kp_score, int *kp_idx, const int *kp_n) {
+  __shared__ unsigned long long keys[kCap];
+  __shared__ unsigned long long akey[kAmbMax];
+  __shared__ int s_in;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (r >= gate[0] || gate[kGateMode + r] < 0) return;
+  const int b = gate[1 + r];
+  const int na = amb[(size_t)b * (1 + kAmbMax)];
+  const int *ai = amb + (size_t)b * (1 + kAmbMax) + 1;
+  const int n = kp_n[b];
+  float *os = kp_score + (size_t)b * kCap;
+  int *oi = kp_idx + (size_t)b * kCap;
+  if (tid == 0) s_in = 0;
+  if (tid < kAmbMax) {
+    akey[tid] = 0ull;
+    if (tid < na) {
+      const float sx = heat_x[(size_t)r * HsWs + ai[tid]];
+      akey[tid] = ((unsigned long long)__float_as_uint(sx) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ai[tid]);
+    }
+  }
+  __syncthreads();
+  // the list without the band's members; count the places they held
+  unsigned long long key = 0ull;
+  if (tid < n) {
+    const int idx = oi[tid];
+    bool member = false;
+    for (int t = 0; t < na; ++t) member = member || ai[t] == idx;
+    if (member) atomicAdd(&s_in, 1);
+    else key = ((unsigned long long)__float_as_uint(os[tid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+  }
+  keys[tid] = key;
+  __syncthreads();
+  // the band's best by exact score (na <= 8: one thread sorts them), into the freed places (zeros sort last)
+  if (tid == 0) {
+    for (int i = 1; i < na; ++i) {
+      const unsigned long long k = akey[i];
+      int j = i - 1;
+      while (j >= 0 && akey[j] < k) { akey[j + 1] = akey[j]; --j; }
+      akey[j + 1] = k;
+    }
+    int t = 0;
+    for (int i = 0; i < n && t < s_in; ++i)
+      if (keys[i] == 0ull) keys[i] = akey[t++];
+  }
+  __syncthreads();
+  for (int size = 2; size <= kCap; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int i = tid, j = i ^ stride;
+      if (j > i) {
+        const unsigned long long a = keys[i], c = keys[j];
+        const bool desc = ((i & size) == 0);
+        if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < n) {
+    os[tid] = __uint_as_float((unsigned)(keys[tid] >> 32));
+    oi[tid] = (int)(0xFFFFFFFFu - (unsigned)(keys[tid] & 0xFFFFFFFFu));
   }
 }
 
@@ -597,16 +706,24 @@ int launch_desc_norm(float *desc, int ld, int coff, int ncell_total, float *out,
 }
 
 int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, const int *kp_idx, const int *kp_n,
-                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, hipStream_t st) {
+                  int Ws, double *feat, float *slots, int B, const int *gate, int *kp_n_out, const int *guard_flags,
+                  hipStream_t st) {
   hipLaunchKernelGGL(sample_kernel, dim3(kCap / 4, B), dim3(256), 0, st, desc, Hc, Wc, kp_score, kp_idx, kp_n, Ws,
-                     feat, slots, gate, kp_n_out);
+                     feat, slots, gate, kp_n_out, guard_flags);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_guard_compact(const int *flags, int B, const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs, int *gate,
-                         unsigned long long *stats, hipStream_t st) {
-  hipLaunchKernelGGL(guard_compact_kernel, dim3(B), dim3(256), 0, st, flags, B, imgs, img_bytes, redo_imgs, gate, stats);
+int launch_guard_compact(const int *flags, const int *amb, int B, int Ws, int Wc, const uint8_t *imgs, size_t img_bytes,
+                         uint8_t *redo_imgs, int *gate, unsigned long long *stats, hipStream_t st) {
+  hipLaunchKernelGGL(guard_compact_kernel, dim3(B), dim3(256), 0, st, flags, amb, B, Ws, Wc, imgs, img_bytes, redo_imgs, gate,
+                     stats);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+int launch_guard_resolve(const int *gate, const int *amb, const float *heat_x, int HsWs, float *kp_score, int *kp_idx,
+                         const int *kp_n, int B, hipStream_t st) {
+  hipLaunchKernelGGL(guard_resolve_kernel, dim3(B), dim3(1024), 0, st, gate, amb, heat_x, HsWs, kp_score, kp_idx, kp_n);
   URF_HIP(hipGetLastError());
   return 0;
 }

@@ -65,12 +65,24 @@ struct ConvArgs {
   const float *b1a;      // [64]
   const float *lut;      // [256] u8 -> f32 ( float(u8)/255.0 )
   const int *gate;       // optional: batch items >= gate[0] are skipped (redo pipeline of the guarded fast mode)
+  // redo slots that only need the scores of a few cells (gate layout below): a tile is computed only if it lies within
+  // t_rad pixels (at this layer's resolution, t_scale pixels per cell) of a target cell; t_scale 0 = no such gating,
+  // -1 = the layer is skipped for those slots altogether (descriptor head); t_wc = cells per row
+  int t_scale, t_rad, t_wc;
 };
+
+// Redo list of the guarded fast mode ("gate", device ints): [0] = slots; [1 + r] = frame of slot r;
+// [kGateMode + r] = -1: the whole frame is redone in the exact mode, n >= 0: only the scores of n target cells are needed
+// (the top-k cut is the only ambiguous decision); [kGateTargets + 8 r + t] = target cell t (cy * Wc + cx)
+constexpr int kGateMax = 64, kGateMode = 1 + kGateMax, kGateTargets = 1 + 2 * kGateMax, kGateInts = kGateTargets + 8 * kGateMax;
+constexpr int kAmbMax = 8;     // candidates within the error of the top-k cut that are resolved one by one; more = whole frame
 
 // near-tie guard of the fast precision mode, SuperPoint tail (sp_kernels.hip)
 struct SpGuard {
-  int *flags;        // [B] bit 0: top-k cut, bit 1: threshold band, bit 2: NMS near-tie; null = guard off
+  int *flags;        // [B] bit 0: top-k cut (resolved per candidate), bit 1: threshold band, bit 2: NMS near-tie, bit 3: too many
+                     // candidates at the cut (bits 1-3: the whole frame is redone); null = guard off
   int *band;         // [B] scratch: some candidate lies in the threshold band
+  int *amb;          // [B][1 + kAmbMax]: count and pixel indices of the candidates within the error of the cut
   float delta, ulps; // error model of a fast-mode score: delta * s * (1 - s) + ulps * ulp(s)
 };
 

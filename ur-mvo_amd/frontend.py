@@ -113,10 +113,13 @@ class SuperPoint:
         check(_lib.lib().urf_sp_sync(self._h), "urf_sp_sync")
 
     def near_tie_reruns(self):
-        """guarded fast mode: dict(redone, frames, cut, threshold, nms) since build()"""
+        """guarded fast mode, since build(): frames redone whole in the exact mode, frames processed, frames whose top-k cut was
+        resolved per candidate (and how many candidates), frames flagged by the threshold band / an NMS near-tie / too many
+        candidates at the cut (those are the ones redone whole)"""
         v = (C.c_ulonglong * 8)()
         check(_lib.lib().urf_sp_near_tie_reruns(self._h, v, 8), "urf_sp_near_tie_reruns")
-        return dict(redone=int(v[0]), frames=int(v[1]), cut=int(v[2]), threshold=int(v[3]), nms=int(v[4]))
+        return dict(redone=int(v[0]), frames=int(v[1]), cut_resolved=int(v[2]), threshold=int(v[3]), nms=int(v[4]),
+                    cut_overflow=int(v[5]), candidates=int(v[6]))
 
     def debug_tensor(self, which, shape):
         out = np.zeros(shape, np.float32)
