@@ -415,9 +415,11 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set.mark();
     }
-    // URF_H2GEMM_BALANCE (default 3): bit 0 = the 1.5-tile Q|K|V^T kernel, bit 1 = 64-row tiles for launches of <= 2 cout tiles
+    // URF_H2GEMM_BALANCE (default 2): bit 1 = 64-row tiles for launches of <= 2 cout tiles (measured: linear layers 1.775 -> 1.757 ms per
+    // 8 pairs, pipeline +1.5 %); bit 0 = the 1.5-tile Q|K|V^T kernel (measured and NOT the default: 1.775 -> 1.890 ms, its 64-row
+    // transposed half tile is slower than the half-empty second round it removes)
     static int balance = -1;
-    if (balance < 0) { const char *e = getenv("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 3; }
+    if (balance < 0) { const char *e = getenv("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 2; }
     static int nt = -1;
     if (nt < 0) { const char *e = getenv("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;

@@ -63,9 +63,12 @@ struct RsArgs {
   long long *stamps;   // diagnostic runs only (urf_probe_sinkhorn_stamps): s_memtime at 8 points of every iteration
 };
 
-// Granule store.  `near` = every workgroup of the pair runs on ONE XCD (verified at run time, below): the store
-// only has to reach that XCD's L2 (sc0: the line stays there) where the readers' L1-bypassing loads find it
-// ~0.1 us later; otherwise the agent-scope form (sc1: written through to the memory side, ~1 us per hop).
+// Granule store.  Default: the agent-scope form (sc1: written through to the memory side, ~1 us per hop) -- what the HIP memory
+// model asks for between workgroups.  `near` (opt-in, URF_SINKHORN_NEAR=1): when every workgroup of the pair runs on ONE XCD
+// (verified at run time, below) a workgroup-scope store only has to reach that XCD's L2 (the L1 is write-through on gfx950),
+// where the readers' L1-bypassing agent-scope loads find it ~0.1 us later.  That is below the scope the memory model requires
+// between workgroups and relies on this chip's cache hierarchy: measured 0.48 vs 0.60 ms per 8-pair launch, 0.8 % of the
+// pipeline's throughput -- not worth leaving the model for, hence off by default.
 __device__ __forceinline__ void rs_store(u64 *p, unsigned tag, float v, bool near) {
   const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
   if (near) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -783,7 +786,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     a.salt = *salt; a.err = err;
     {
       static int near_knob = -1;
-      if (near_knob < 0) { const char *e = getenv("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 1; }
+      if (near_knob < 0) { const char *e = getenv("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 0; }
       a.allow_near = near_knob;
     }
     a.stamps = g_rs_stamps;
