@@ -245,8 +245,9 @@ def run_oracle_jobs(kind, jobs, timeout=900):
     import tempfile
     if not jobs:
         return []
-    ncpu = len(os.sched_getaffinity(0))
-    W = max(1, min(6, ncpu // 32, len(jobs)))
+    # URF_ORACLE_WORKERS: worker processes (default 1: the GPU boxes show 256 cores but deliver far fewer -- six workers of 32
+    # OpenMP threads each took twenty times longer than one, tools/cpu_probe.py)
+    W = max(1, min(int(os.environ.get("URF_ORACLE_WORKERS", "1")), len(jobs)))
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
         for w in range(W):
