@@ -53,11 +53,18 @@ _lib = None
 
 
 def threads():
-    """OpenMP threads the oracle uses: the cores this process may run on, <= 32."""
+    """OpenMP threads the oracle uses: the cores this process may run on -- its affinity mask capped by the cgroup's CPU
+    quota (a container can see 256 cores and own 16 of them) --, <= 32."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     return max(1, min(n, 32))
 
 

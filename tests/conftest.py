@@ -245,8 +245,8 @@ def run_oracle_jobs(kind, jobs, timeout=900):
     import tempfile
     if not jobs:
         return []
-    # URF_ORACLE_WORKERS: worker processes (default 1: the GPU boxes show 256 cores but deliver far fewer -- six workers of 32
-    # OpenMP threads each took twenty times longer than one, tools/cpu_probe.py)
+    # URF_ORACLE_WORKERS: worker processes (default 1: the GPU boxes show 256 cores behind a cgroup quota of 16 -- six workers of
+    # 32 OpenMP threads each took twenty times longer than one, tools/cpu_probe.py; oracle.threads() honours the quota)
     W = max(1, min(int(os.environ.get("URF_ORACLE_WORKERS", "1")), len(jobs)))
     with tempfile.TemporaryDirectory() as tmp:
         procs = []

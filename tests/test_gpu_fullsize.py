@@ -285,14 +285,14 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
 
 @pytest.mark.parametrize("H,W", [(480, 640), (376, 1241)])
 def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H, W, monkeypatch):
-    """the per-candidate resolution of the top-k cut: with a widened error band (about six candidates at the cut of every
-    frame) the exact mode's convolution stack runs on just the receptive fields of their cells; the resolved candidates
+    """the per-candidate resolution of the top-k cut: with a widened error band (about five candidates at the cut of every
+    frame; more than eight would send the frame to the whole-frame redo) the exact mode's convolution stack runs on just the receptive fields of their cells; the resolved candidates
     carry the EXACT mode's scores bit for bit (checked on the keypoint at the cut, which is always one of them) and the
     keypoint set is the oracle's.  With the product constants the same machinery runs on roughly every second frame of the
     bench streams (the bench line counts them)."""
     import torch
     frames, ofeats, _ = bench_stream_oracle(H, W)
-    monkeypatch.setenv("URF_GUARD_SP_ULPS", "300")
+    monkeypatch.setenv("URF_GUARD_SP_ULPS", "100")
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=2)
     assert sp.build(sp_blob)
     monkeypatch.delenv("URF_GUARD_SP_ULPS")
@@ -304,7 +304,7 @@ def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H,
     sp.sync()
     hdr = slots[:, :4].cpu().numpy().view(np.int32)
     st = sp.near_tie_reruns()
-    assert st["frames"] == 16 and st["cut_resolved"] >= 8 and st["cut_resolved"] + st["redone"] == int((hdr[:, 1] != 0).sum())
+    assert st["frames"] == 16 and st["cut_resolved"] >= 6 and st["cut_resolved"] + st["redone"] == int((hdr[:, 1] != 0).sum()), (st, hdr[:, 1])
     assert st["candidates"] >= 2 * st["cut_resolved"]
     for j in range(16):
         f = F.slot_to_host(slots[j].data_ptr())

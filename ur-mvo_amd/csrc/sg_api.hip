@@ -50,7 +50,7 @@ static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e
 // guarded fast mode, matcher: margin (log domain) within which the fast mode's log-assignment may differ from the exact
 // mode's on entries that can become a match; measured maximum on both bench streams times a safety factor (DESIGN.md
 // "Guarded fast mode", tools/gpu_margins.py)
-static const float kGuardSgZ = 2e-4f;
+static const float kGuardSgZ = 1e-4f;
 
 struct urf_pm {
   urf_sg_config cfg;
