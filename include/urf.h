@@ -390,6 +390,20 @@ typedef struct {
 int urf_frame_optimization(urf_pose *h, const urf_poseopt_config *cfg, int B, const int *n, const double *Xw,
                            const double *obs, int cap, double *q_wc, double *p_wc, uint8_t *inlier, int *n_inliers);
 
+/* FrameOptimization with the stereo edges of a rectified pair as well (EdgeStereoSE3ProjectXYZOnlyPose,
+ * src/g2o_optimization.cc:235-260, 291-306): frame f holds n_mono[f] mono observations followed by n_stereo[f] stereo ones in
+ * the same rows -- Xw[f][cap][3], obs[f][cap][3] = (u, v, u_right), u_right ignored for the mono rows; inlier[f][cap] in that
+ * order.  The third residual is u_right - (u - bf / z); Huber deltas sqrt(chi2_mono) / sqrt(chi2_stereo). */
+typedef struct {
+  double fx, fy, cx, cy;
+  double bf;                   /* Camera::BF(): baseline times fx */
+  double chi2_mono;            /* 0 -> 5.991 (OptimizationConfig::mono_point) */
+  double chi2_stereo;          /* 0 -> 7.815 (OptimizationConfig::stereo_point) */
+} urf_poseopt_stereo_config;
+int urf_frame_optimization_stereo(urf_pose *h, const urf_poseopt_stereo_config *cfg, int B, const int *n_mono, const int *n_stereo,
+                                  const double *Xw, const double *obs, int cap, double *q_wc, double *p_wc, uint8_t *inlier,
+                                  int *n_inliers);
+
 /* ------------------------------------------------ map-point projection search -- */
 /* Mapping::SearchByProjection(frame, mappoints, thr, good_projections), src/mapping.cc:667-735
  * (SURVEY.md section 8 f4): projection (include/camera.h:48-68), window search

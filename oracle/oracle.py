@@ -388,3 +388,24 @@ def frame_optimization(cam, Xw, obs, q_wc, p_wc, inlier=None, chi2_threshold=5.9
     inl = np.ones(max(n, 1), np.uint8) if inlier is None else np.ascontiguousarray(inlier, np.uint8).copy()
     k = lib().oframe_optimization(C.byref(cfg), _p(Xw), _p(obs), n, _p(q), _p(p), _p(inl))
     return int(k), q, p, inl[:n]
+
+
+class PoseOptStereoConfig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double)]
+
+
+def frame_optimization_stereo(cam, bf, Xw, obs, n_mono, q_wc, p_wc, chi2_mono=5.991, chi2_stereo=7.815):
+    """FrameOptimization with stereo edges (src/g2o_optimization.cc:179-321): rows [0, n_mono) of obs [n, 3] are mono
+    observations (u, v, unused), the rest stereo (u, v, u_right) -> (n - outliers, q_wc, p_wc, inlier flags)"""
+    cfg = PoseOptStereoConfig(*[float(v) for v in cam], float(bf), chi2_mono, chi2_stereo)
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    n = Xw.shape[0]
+    assert obs.shape == (n, 3) and 0 <= n_mono <= n
+    q = np.ascontiguousarray(q_wc, np.float64).copy()
+    p = np.ascontiguousarray(p_wc, np.float64).copy()
+    inl = np.ones(max(n, 1), np.uint8)
+    lib().oframe_optimization_stereo.restype = C.c_int
+    k = lib().oframe_optimization_stereo(C.byref(cfg), _p(Xw), _p(obs), int(n_mono), int(n - n_mono), _p(q), _p(p), _p(inl))
+    return int(k), q, p, inl[:n]

@@ -138,134 +138,190 @@ static void se3_apply_update(const double dx[6], double q[4], double t[3]) {
   memcpy(t, tn, sizeof(tn));
 }
 
-/* (H + lambda I) x = b for the symmetric positive definite 6x6 H: Cholesky, row by row */
+/* (H + lambda I) x = b, H symmetric positive definite 6x6.  Cholesky by columns (Crout): every entry of L is the same
+   left-to-right inner product as in the row-by-row form, so the factor and the solution are the same numbers */
 static int solve6(const double H[36], double lambda, const double b[6], double x[6]) {
-  double L[36];
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = H[i * 6 + j] + (i == j ? lambda : 0.0);
-      for (int k = 0; k < j; ++k) s = s - L[i * 6 + k] * L[j * 6 + k];
-      if (i == j) {
-        if (!(s > 0.0)) return 0;
-        L[i * 6 + i] = sqrt(s);
-      } else {
-        L[i * 6 + j] = s / L[j * 6 + j];
-      }
+  double L[6][6];
+  for (int col = 0; col < 6; ++col) {
+    double d = H[col * 6 + col] + lambda;
+    for (int k = 0; k < col; ++k) d = d - L[col][k] * L[col][k];
+    if (!(d > 0.0)) return 0;
+    L[col][col] = sqrt(d);
+    for (int row = col + 1; row < 6; ++row) {
+      double v = H[row * 6 + col] + 0.0;
+      for (int k = 0; k < col; ++k) v = v - L[row][k] * L[col][k];
+      L[row][col] = v / L[col][col];
     }
-  double y[6];
+  }
+  double fwd[6];
   for (int i = 0; i < 6; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s = s - L[i * 6 + k] * y[k];
-    y[i] = s / L[i * 6 + i];
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v = v - L[i][k] * fwd[k];
+    fwd[i] = v / L[i][i];
   }
   for (int i = 5; i >= 0; --i) {
-    double s = y[i];
-    for (int k = i + 1; k < 6; ++k) s = s - L[k * 6 + i] * x[k];
-    x[i] = s / L[i * 6 + i];
+    double v = fwd[i];
+    for (int k = i + 1; k < 6; ++k) v = v - L[k][i] * x[k];
+    x[i] = v / L[i][i];
   }
   return 1;
 }
 
 typedef struct { double fx, fy, cx, cy; } cam4;
 
-/* error = obs - project(R X + t) and, optionally, its Jacobian (EdgeSE3ProjectXYZOnlyPose::linearizeOplus) */
-static void edge_eval(const cam4 *cam, const double R[9], const double t[3], const double *X, const double *obs,
-                      double e[2], double J[12]) {
-  const double x = ((R[0] * X[0] + R[1] * X[1]) + R[2] * X[2]) + t[0];
-  const double y = ((R[3] * X[0] + R[4] * X[1]) + R[5] * X[2]) + t[1];
-  const double z = ((R[6] * X[0] + R[7] * X[1]) + R[8] * X[2]) + t[2];
-  const double iz = 1.0 / z;
-  e[0] = obs[0] - (x * iz * cam->fx + cam->cx);
-  e[1] = obs[1] - (y * iz * cam->fy + cam->cy);
-  if (J) {
-    const double iz2 = iz * iz;
-    J[0] = x * y * iz2 * cam->fx;           J[1] = -(1.0 + x * x * iz2) * cam->fx; J[2] = y * iz * cam->fx;
-    J[3] = -iz * cam->fx;                   J[4] = 0.0;                            J[5] = x * iz2 * cam->fx;
-    J[6] = (1.0 + y * y * iz2) * cam->fy;   J[7] = -x * y * iz2 * cam->fy;         J[8] = -x * iz * cam->fy;
-    J[9] = 0.0;                             J[10] = -iz * cam->fy;                 J[11] = y * iz2 * cam->fy;
+/* The edges of one frame, in the order FrameOptimization adds them (src/g2o_optimization.cc:213-258): n_mono mono edges
+   (EdgeSE3ProjectXYZOnlyPose, measurement u v), then n - n_mono stereo edges (EdgeStereoSE3ProjectXYZOnlyPose, u v u_right). */
+typedef struct {
+  cam4 cam;
+  double bf;
+  const double *pts;       /* [n][3] */
+  const double *meas;      /* [n][stride] */
+  int n, n_mono, stride;
+  double gate_mono, gate_stereo;
+} edge_set;
+
+typedef struct { int rows; double res[3]; double jac[3][6]; } edge_value;
+
+/* residual = measurement - projection of (R X + t), and (want_jac) its derivative with respect to the left increment
+   (omega, upsilon): linearizeOplus of the two g2o edges.  The stereo edge's third row is the column in the right image,
+   u - bf / z. */
+static void evaluate_edge(const edge_set *E, int j, const double R[9], const double t[3], int want_jac, edge_value *out) {
+  const double *P = E->pts + 3 * (size_t)j, *m = E->meas + (size_t)E->stride * j;
+  const double xc = ((R[0] * P[0] + R[1] * P[1]) + R[2] * P[2]) + t[0];
+  const double yc = ((R[3] * P[0] + R[4] * P[1]) + R[5] * P[2]) + t[1];
+  const double zc = ((R[6] * P[0] + R[7] * P[1]) + R[8] * P[2]) + t[2];
+  const double inv = 1.0 / zc;
+  const int stereo = j >= E->n_mono;
+  const double fx = E->cam.fx, fy = E->cam.fy;
+  const double u_left = xc * inv * fx + E->cam.cx;
+  out->rows = stereo ? 3 : 2;
+  out->res[0] = m[0] - u_left;
+  out->res[1] = m[1] - (yc * inv * fy + E->cam.cy);
+  out->res[2] = stereo ? m[2] - (u_left - E->bf * inv) : 0.0;
+  if (!want_jac) return;
+  const double inv2 = inv * inv;
+  double *du = out->jac[0], *dv = out->jac[1], *dr = out->jac[2];
+  du[0] = xc * yc * inv2 * fx;
+  du[1] = -(1.0 + xc * xc * inv2) * fx;
+  du[2] = yc * inv * fx;
+  du[3] = -inv * fx;
+  du[4] = 0.0;
+  du[5] = xc * inv2 * fx;
+  dv[0] = (1.0 + yc * yc * inv2) * fy;
+  dv[1] = -xc * yc * inv2 * fy;
+  dv[2] = -xc * inv * fy;
+  dv[3] = 0.0;
+  dv[4] = -inv * fy;
+  dv[5] = yc * inv2 * fy;
+  if (stereo) {
+    dr[0] = du[0] - E->bf * yc * inv2;
+    dr[1] = du[1] + E->bf * xc * inv2;
+    dr[2] = du[2];
+    dr[3] = du[3];
+    dr[4] = 0.0;
+    dr[5] = du[5] - E->bf * inv2;
   }
 }
 
-/* robust chi2 over the active observations, and optionally H = sum w J^T J, b = -sum w J^T e (w = Huber weight) */
-static double build_system(const cam4 *cam, const double q[4], const double t[3], const double *Xw, const double *obs, int n,
-                           const uint8_t *active, double delta, double *H, double *b) {
+static double squared_norm(const edge_value *v) {
+  const double s = v->res[0] * v->res[0] + v->res[1] * v->res[1];
+  return v->rows == 3 ? s + v->res[2] * v->res[2] : s;
+}
+
+/* robust cost over the active edges; with H != NULL also the Gauss-Newton system H = sum w J^T J, g = -sum w J^T r.
+   Lane l of the canonical wave order takes the edges l, l + 64, ...; the 28 sums are closed by the butterfly. */
+static double accumulate(const edge_set *E, const double q[4], const double t[3], const uint8_t *active, int robust,
+                         double *H, double *g) {
   double R[9];
   q_to_R(q, R);
-  double part[28][64];
-  for (int l = 0; l < 64; ++l) {
-    double acc[28];
-    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int j = l; j < n; j += 64) {
+  const double huber_mono = robust ? sqrt(E->gate_mono) : 0.0, huber_stereo = robust ? sqrt(E->gate_stereo) : 0.0;
+  double lanes[28][64];
+  for (int lane = 0; lane < 64; ++lane) {
+    double sum[28];
+    for (int k = 0; k < 28; ++k) sum[k] = 0.0;
+    for (int j = lane; j < E->n; j += 64) {
       if (!active[j]) continue;
-      double e[2], J[12];
-      edge_eval(cam, R, t, Xw + 3 * j, obs + 2 * j, e, H ? J : NULL);
-      const double e2 = e[0] * e[0] + e[1] * e[1];
-      double rho = e2, w = 1.0;
-      if (delta > 0.0) {
-        const double en = sqrt(e2);
-        if (en > delta) { rho = 2.0 * en * delta - delta * delta; w = delta / en; }
+      edge_value v;
+      evaluate_edge(E, j, R, t, H != NULL, &v);
+      const double r2 = squared_norm(&v);
+      const double huber = v.rows == 3 ? huber_stereo : huber_mono;
+      double cost = r2, weight = 1.0;
+      if (huber > 0.0) {
+        const double r = sqrt(r2);
+        if (r > huber) { cost = 2.0 * r * huber - huber * huber; weight = huber / r; }
       }
-      acc[27] = acc[27] + rho;
-      if (H) {
-        int k = 0;
-        for (int r = 0; r < 6; ++r)
-          for (int c = r; c < 6; ++c) { acc[k] = acc[k] + w * (J[r] * J[c] + J[6 + r] * J[6 + c]); ++k; }
-        for (int r = 0; r < 6; ++r) acc[21 + r] = acc[21 + r] - w * (J[r] * e[0] + J[6 + r] * e[1]);
+      sum[27] = sum[27] + cost;
+      if (H == NULL) continue;
+      int k = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c, ++k) {
+          double jj = v.jac[0][a] * v.jac[0][c] + v.jac[1][a] * v.jac[1][c];
+          if (v.rows == 3) jj = jj + v.jac[2][a] * v.jac[2][c];
+          sum[k] = sum[k] + weight * jj;
+        }
+      for (int a = 0; a < 6; ++a) {
+        double jr = v.jac[0][a] * v.res[0] + v.jac[1][a] * v.res[1];
+        if (v.rows == 3) jr = jr + v.jac[2][a] * v.res[2];
+        sum[21 + a] = sum[21 + a] - weight * jr;
       }
     }
-    for (int k = 0; k < 28; ++k) part[k][l] = acc[k];
+    for (int k = 0; k < 28; ++k) lanes[k][lane] = sum[k];
   }
-  if (H) {
+  if (H != NULL) {
     int k = 0;
-    for (int r = 0; r < 6; ++r)
-      for (int c = r; c < 6; ++c) { const double v = d_bfly64(part[k]); H[r * 6 + c] = v; H[c * 6 + r] = v; ++k; }
-    for (int r = 0; r < 6; ++r) b[r] = d_bfly64(part[21 + r]);
+    for (int a = 0; a < 6; ++a)
+      for (int c = a; c < 6; ++c, ++k) H[a * 6 + c] = H[c * 6 + a] = d_bfly64(lanes[k]);
+    for (int a = 0; a < 6; ++a) g[a] = d_bfly64(lanes[21 + a]);
   }
-  return d_bfly64(part[27]);
+  return d_bfly64(lanes[27]);
 }
 
-/* `iterations` Levenberg-Marquardt iterations on T = (q, t) (camera-from-world), g2o's damping policy */
-static void lm_pose(const cam4 *cam, const double *Xw, const double *obs, int n, const uint8_t *active, double delta,
-                    int iterations, double q[4], double t[3]) {
-  double lambda = 0.0, ni = 2.0;
+/* `iterations` Levenberg-Marquardt iterations on the camera-from-world pose (q, t) with the damping policy of g2o's
+   OptimizationAlgorithmLevenberg: lambda0 = 1e-5 max diag H; a step is kept when the gain ratio is positive, and then
+   lambda *= max(1/3, min(2/3, 1 - (2 rho - 1)^3)); otherwise lambda *= nu, nu *= 2 and the step is retried, ten times at most */
+static void lm_pose(const edge_set *E, const uint8_t *active, int robust, int iterations, double q[4], double t[3]) {
+  double damping = 0.0, growth = 2.0;
   for (int it = 0; it < iterations; ++it) {
-    double H[36], b[6];
-    double current = build_system(cam, q, t, Xw, obs, n, active, delta, H, b);
+    double H[36], g[6];
+    double cost = accumulate(E, q, t, active, robust, H, g);
     if (it == 0) {
-      double md = 0.0;
-      for (int k = 0; k < 6; ++k) md = fmax(md, fabs(H[k * 6 + k]));
-      lambda = 1e-5 * md;
-      ni = 2.0;
+      double top = 0.0;
+      for (int k = 0; k < 6; ++k) top = fmax(top, fabs(H[k * 7]));
+      damping = 1e-5 * top;
+      growth = 2.0;
     }
-    double rho = 0.0;
-    int qmax = 0;
-    do {
-      double qb[4], tb[3], dx[6];
-      memcpy(qb, q, sizeof(qb)); memcpy(tb, t, sizeof(tb));
-      const int ok = solve6(H, lambda, b, dx);
-      double temp = 1.7976931348623157e308;
-      if (ok) {
-        se3_apply_update(dx, q, t);
-        temp = build_system(cam, q, t, Xw, obs, n, active, delta, NULL, NULL);
+    double ratio = 0.0;
+    int tries = 0;
+    for (;;) {
+      double keep_q[4], keep_t[3], step[6];
+      memcpy(keep_q, q, sizeof(keep_q));
+      memcpy(keep_t, t, sizeof(keep_t));
+      const int solved = solve6(H, damping, g, step);
+      double cost_new = 1.7976931348623157e308, predicted = 1e-3;
+      if (solved) {
+        se3_apply_update(step, q, t);
+        cost_new = accumulate(E, q, t, active, robust, NULL, NULL);
+        for (int k = 0; k < 6; ++k) predicted = predicted + step[k] * (damping * step[k] + g[k]);
       }
-      double scale = 1e-3;
-      if (ok) for (int k = 0; k < 6; ++k) scale = scale + dx[k] * (lambda * dx[k] + b[k]);
-      rho = (current - temp) / scale;
-      if (ok && rho > 0.0 && isfinite(temp)) {
-        double alpha = 1.0 - ((2.0 * rho - 1.0) * (2.0 * rho - 1.0)) * (2.0 * rho - 1.0);
-        if (alpha > 2.0 / 3.0) alpha = 2.0 / 3.0;
-        lambda = lambda * fmax(1.0 / 3.0, alpha);
-        ni = 2.0;
-        current = temp;
+      ratio = (cost - cost_new) / predicted;
+      if (solved && ratio > 0.0 && isfinite(cost_new)) {
+        const double d = 2.0 * ratio - 1.0;
+        double shrink = 1.0 - (d * d) * d;
+        if (shrink > 2.0 / 3.0) shrink = 2.0 / 3.0;
+        damping = damping * fmax(1.0 / 3.0, shrink);
+        growth = 2.0;
+        cost = cost_new;
       } else {
-        lambda = lambda * ni;
-        ni = ni * 2.0;
-        memcpy(q, qb, sizeof(qb)); memcpy(t, tb, sizeof(tb));
-        if (!isfinite(lambda)) break;
+        damping = damping * growth;
+        growth = growth * 2.0;
+        memcpy(q, keep_q, sizeof(keep_q));
+        memcpy(t, keep_t, sizeof(keep_t));
+        if (!isfinite(damping)) break;
       }
-      ++qmax;
-    } while (rho < 0.0 && qmax < 10);
-    if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) break;
+      ++tries;
+      if (!(ratio < 0.0 && tries < 10)) break;
+    }
+    if (tries == 10 || ratio == 0.0 || !isfinite(damping)) break;
   }
 }
 
@@ -277,41 +333,55 @@ static void invert_pose(const double q[4], const double p[3], double qi[4], doub
   for (int i = 0; i < 3; ++i) ti[i] = -((R[i * 3] * p[0] + R[i * 3 + 1] * p[1]) + R[i * 3 + 2] * p[2]);
 }
 
-/* FrameOptimization, src/g2o_optimization.cc:179-321 (mono edges).  q_wc (w,x,y,z), p_wc: in = prior, out = optimised.
-   inlier[n]: in = the caller's flags (MonoPointConstraint::inlier), out = re-classified.  Returns n - outliers. */
-int oframe_optimization(const oposeopt_config *cfg, const double *Xw, const double *obs, int n, double *q_wc, double *p_wc,
-                        uint8_t *inlier) {
-  const cam4 cam = {cfg->fx, cfg->fy, cfg->cx, cfg->cy};
-  const double delta = sqrt(cfg->chi2_threshold);
-  double q0[4], t0[3], q[4], t[3];
-  double qn[4] = {q_wc[0], q_wc[1], q_wc[2], q_wc[3]};
-  q_normalize(qn);
-  invert_pose(qn, p_wc, q0, t0);
-  memcpy(q, q0, sizeof(q)); memcpy(t, t0, sizeof(t));
-  uint8_t *level0 = (uint8_t *)malloc(n > 0 ? n : 1);       /* edges on optimisation level 0 (all of them at first) */
-  for (int j = 0; j < n; ++j) level0[j] = 1;
+/* FrameOptimization, src/g2o_optimization.cc:179-321, over an edge set.  q_wc (w,x,y,z), p_wc: in = prior, out = optimised.
+   inlier[n]: out = the re-classified *PointConstraint::inlier flags.  Returns n - outliers. */
+static int optimise_frame(const edge_set *E, double *q_wc, double *p_wc, uint8_t *inlier) {
+  const int n = E->n;
+  double q_prior[4], t_prior[3], q[4], t[3];
+  double q_in[4] = {q_wc[0], q_wc[1], q_wc[2], q_wc[3]};
+  q_normalize(q_in);
+  invert_pose(q_in, p_wc, q_prior, t_prior);
+  memcpy(q, q_prior, sizeof(q)); memcpy(t, t_prior, sizeof(t));
+  uint8_t *on_level0 = (uint8_t *)malloc(n > 0 ? n : 1);    /* edges on optimisation level 0 (all of them at first) */
+  memset(on_level0, 1, n > 0 ? n : 1);
   int outliers = 0;
   for (int round = 0; round < 4; ++round) {
-    memcpy(q, q0, sizeof(q)); memcpy(t, t0, sizeof(t));     /* :266-267 every round restarts from the prior */
-    lm_pose(&cam, Xw, obs, n, level0, round < 3 ? delta : 0.0, 10, q, t);
+    memcpy(q, q_prior, sizeof(q)); memcpy(t, t_prior, sizeof(t));       /* :266-267 every round restarts from the prior */
+    lm_pose(E, on_level0, round < 3, 10, q, t);                           /* :289-290, :304-305 */
     double R[9];
     q_to_R(q, R);
     outliers = 0;
     for (int j = 0; j < n; ++j) {
-      double e[2];
-      edge_eval(&cam, R, t, Xw + 3 * j, obs + 2 * j, e, NULL);
-      const float chi2 = (float)(e[0] * e[0] + e[1] * e[1]);           /* :279 const float chi2 */
-      if (chi2 > cfg->chi2_threshold) { inlier[j] = 0; level0[j] = 0; ++outliers; }
-      else { inlier[j] = 1; level0[j] = 1; }
+      edge_value v;
+      evaluate_edge(E, j, R, t, 0, &v);
+      const float chi2 = (float)squared_norm(&v);                         /* :279, :295 const float chi2 */
+      const double gate = v.rows == 3 ? E->gate_stereo : E->gate_mono;
+      const int bad = chi2 > gate;
+      inlier[j] = !bad; on_level0[j] = !bad;
+      outliers += bad;
     }
-    if (n < 10) break;
+    if (n < 10) break;                                                    /* :309-310 */
   }
-  free(level0);
-  double qo[4], po[3];
-  invert_pose(q, t, qo, po);
-  q_normalize(qo);
-  memcpy(q_wc, qo, sizeof(qo)); memcpy(p_wc, po, sizeof(po));
+  free(on_level0);
+  double q_out[4], p_out[3];
+  invert_pose(q, t, q_out, p_out);
+  q_normalize(q_out);
+  memcpy(q_wc, q_out, sizeof(q_out)); memcpy(p_wc, p_out, sizeof(p_out));
   return n - outliers;
+}
+
+int oframe_optimization(const oposeopt_config *cfg, const double *Xw, const double *obs, int n, double *q_wc, double *p_wc,
+                        uint8_t *inlier) {
+  edge_set E = {{cfg->fx, cfg->fy, cfg->cx, cfg->cy}, 0.0, Xw, obs, n, n, 2, cfg->chi2_threshold, 0.0};
+  return optimise_frame(&E, q_wc, p_wc, inlier);
+}
+
+/* the same with stereo edges: n_mono rows (u, v, unused) followed by n_stereo rows (u, v, u_right) */
+int oframe_optimization_stereo(const oposeopt_stereo_config *cfg, const double *Xw, const double *obs, int n_mono, int n_stereo,
+                               double *q_wc, double *p_wc, uint8_t *inlier) {
+  edge_set E = {{cfg->fx, cfg->fy, cfg->cx, cfg->cy}, cfg->bf, Xw, obs, n_mono + n_stereo, n_mono, 3, cfg->chi2_mono,
+                cfg->chi2_stereo};
+  return optimise_frame(&E, q_wc, p_wc, inlier);
 }
 
 /* ------------------------------------------------------------------ PnP-RANSAC */
@@ -442,6 +512,7 @@ int opnp_solve_ransac(const opnp_config *cfg, const float *obj, const float *img
     uv[2 * j] = (double)img[2 * j]; uv[2 * j + 1] = (double)img[2 * j + 1];
     xn[2 * j] = (uv[2 * j] - cam.cx) / cam.fx; xn[2 * j + 1] = (uv[2 * j + 1] - cam.cy) / cam.fy;
   }
+  const edge_set all = {cam, 0.0, X, uv, n, n, 2, 0.0, 0.0};      /* every correspondence as a mono edge */
   double *Rs = (double *)malloc(sizeof(double) * 12 * (size_t)its);
   int *cnt = (int *)malloc(sizeof(int) * (size_t)its);
 #pragma omp parallel for schedule(static)
@@ -458,10 +529,10 @@ int opnp_solve_ransac(const opnp_config *cfg, const float *obj, const float *img
     if (!dlt6(X6, x6, R, t)) continue;
     int c = 0;
     for (int j = 0; j < n; ++j) {
-      double e[2];
-      edge_eval(&cam, R, t, X + 3 * j, uv + 2 * j, e, NULL);
+      edge_value v;
+      evaluate_edge(&all, j, R, t, 0, &v);
       const double z = ((R[6] * X[3 * j] + R[7] * X[3 * j + 1]) + R[8] * X[3 * j + 2]) + t[2];
-      if (z > 0.0 && e[0] * e[0] + e[1] * e[1] <= gate2) ++c;
+      if (z > 0.0 && squared_norm(&v) <= gate2) ++c;
     }
     cnt[it] = c;
   }
@@ -483,16 +554,16 @@ int opnp_solve_ransac(const opnp_config *cfg, const float *obj, const float *img
   if (best >= 0 && best_cnt >= 6) {
     double *R = Rs + 12 * (size_t)best, *t = R + 9;
     for (int j = 0; j < n; ++j) {
-      double e[2];
-      edge_eval(&cam, R, t, X + 3 * j, uv + 2 * j, e, NULL);
+      edge_value v;
+      evaluate_edge(&all, j, R, t, 0, &v);
       const double z = ((R[6] * X[3 * j] + R[7] * X[3 * j + 1]) + R[8] * X[3 * j + 2]) + t[2];
-      inliers[j] = (z > 0.0 && e[0] * e[0] + e[1] * e[1] <= gate2) ? 1 : 0;
+      inliers[j] = (z > 0.0 && squared_norm(&v) <= gate2) ? 1 : 0;
       ninl += inliers[j];
     }
     /* refinement on the inliers (OpenCV: SOLVEPNP_ITERATIVE on the inlier set) */
     double q[4], tt[3] = {t[0], t[1], t[2]};
     R_to_q(R, q);
-    lm_pose(&cam, X, uv, n, inliers, 0.0, 10, q, tt);
+    lm_pose(&all, inliers, 0, 10, q, tt);
     double Rr[9];
     q_to_R(q, Rr);
     /* Twc = [Rcw^T, -Rcw^T tcw] :363-367 */

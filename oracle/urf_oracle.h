@@ -150,6 +150,15 @@ typedef struct {
 int oframe_optimization(const oposeopt_config *cfg, const double *Xw, const double *obs, int n, double *q_wc, double *p_wc,
                         uint8_t *inlier);
 
+/* FrameOptimization with stereo edges as well (EdgeStereoSE3ProjectXYZOnlyPose, src/g2o_optimization.cc:235-260,291-306):
+   n_mono rows (u, v, unused) followed by n_stereo rows (u, v, u_right); Xw and obs have 3 numbers per row */
+typedef struct {
+  double fx, fy, cx, cy, bf;
+  double chi2_mono, chi2_stereo;   /* cfg.mono_point, cfg.stereo_point */
+} oposeopt_stereo_config;
+int oframe_optimization_stereo(const oposeopt_stereo_config *cfg, const double *Xw, const double *obs, int n_mono, int n_stereo,
+                               double *q_wc, double *p_wc, uint8_t *inlier);
+
 /* ---------------- camera ---------------- */
 typedef struct {
   int width, height;       /* image_width / image_height, src/camera.cc:16-17 */

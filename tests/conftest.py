@@ -306,3 +306,25 @@ def bench_stream_oracle(H, W, n_sigma1=8):
     out = (frames, feats, {"ref": res[:n], "sigma1": res[n:]})
     _BENCH_ORACLE[(H, W)] = out
     return out
+
+
+POSE_GOLDEN = ["pose_mono_a.npz", "pose_mono_b.npz", "pose_mono_few.npz", "pose_stereo_a.npz", "pose_stereo_b.npz"]
+
+
+def check_pose_golden(g, frame_opt, pnp=None):
+    """a FrameOptimization result (n - outliers, q_wc, p_wc, inlier flags) -- and, for the mono fixtures, a SolvePnPWithCV result
+    (n_inliers, Twc, inlier flags) -- against tests/golden/pose_*.npz: the independent numpy restatement of the written
+    specification (tests/golden/make_pose_golden.py: numpy.linalg.solve / svd, scipy rotations, numpy sums).  Poses to 1e-6,
+    flags equal except for observations within 1e-6 of their gate."""
+    k, q, p, inl = frame_opt
+    assert abs(np.linalg.norm(q) - 1) < 1e-12
+    dq = min(np.abs(q - g["q"]).max(), np.abs(q + g["q"]).max())
+    assert dq < 1e-6 and np.abs(p - g["p"]).max() < 1e-6, (dq, np.abs(p - g["p"]).max())
+    diff = inl.astype(bool) != g["inlier"].astype(bool)
+    assert not (diff & (np.abs(g["margin"]) > 1e-6)).any()
+    assert k == int(inl.sum())
+    if pnp is not None:
+        n_in, T, pinl = pnp
+        d = pinl.astype(bool) != g["pnp_inlier"].astype(bool)
+        assert not (d & (np.abs(g["pnp_margin"]) > 1e-6)).any() and n_in == int(pinl.sum())
+        assert np.abs(T - g["pnp_pose"]).max() < 1e-6, np.abs(T - g["pnp_pose"]).max()

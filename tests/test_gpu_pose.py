@@ -68,6 +68,39 @@ def test_frame_optimization_batch_bit_exact_vs_oracle(F, O):
     assert g2[0][0] == k and np.array_equal(g2[0][1], q) and np.array_equal(g2[0][3], inl)
 
 
+@pytest.mark.parametrize("name", __import__("conftest").POSE_GOLDEN)
+def test_pose_stage_vs_the_independent_numpy_restatement(F, O, name):
+    """the HIP pose stage against the numpy restatement's fixtures (tests/golden/make_pose_golden.py) and, for the stereo edges
+    (EdgeStereoSE3ProjectXYZOnlyPose, src/g2o_optimization.cc:235-260), against the oracle bit for bit"""
+    from conftest import check_pose_golden, golden
+    g = golden(name)
+    cam, n_mono, n = tuple(g["cam"]), int(g["n_mono"]), len(g["Xw"])
+    gate = [float(v) for v in g["gate"]]
+    ps = F.PoseStage(cam, max_batch=2, capacity=512)
+    fs = ps.FrameOptimizationStereo(float(g["bf"]), [g["Xw"]], [g["obs"]], [n_mono], [g["q0"]], [g["p0"]], *gate)[0]
+    of = O.frame_optimization_stereo(cam, float(g["bf"]), g["Xw"], g["obs"], n_mono, g["q0"], g["p0"], *gate)
+    assert fs[0] == of[0] and np.array_equal(fs[1], of[1]) and np.array_equal(fs[2], of[2]) and np.array_equal(fs[3], of[3])
+    pnp = None
+    if n_mono == n:
+        fm = ps.FrameOptimization([g["Xw"]], [g["obs"][:, :2]], [g["q0"]], [g["p0"]], chi2_threshold=gate[0])[0]
+        assert fm[0] == fs[0] and np.array_equal(fm[1], fs[1]) and np.array_equal(fm[3], fs[3])      # the mono entry point is the same computation
+        pnp = ps.SolvePnPWithCV([g["Xw"]], [g["obs"][:, :2]], seed=int(g["pnp_seed"]))[0]
+    check_pose_golden(g, fs, pnp)
+
+
+def test_frame_optimization_stereo_batch_of_ragged_frames_vs_oracle(F, O):
+    """two frames of different mono / stereo mixes in one call (the kernel's row bookkeeping), bit-exact vs the oracle"""
+    from conftest import golden
+    a, b = golden("pose_stereo_a.npz"), golden("pose_stereo_b.npz")
+    cam = tuple(a["cam"])
+    ps = F.PoseStage(cam, max_batch=2, capacity=300)
+    got = ps.FrameOptimizationStereo(float(a["bf"]), [a["Xw"], b["Xw"]], [a["obs"], b["obs"]], [int(a["n_mono"]), int(b["n_mono"])],
+                                     [a["q0"], b["q0"]], [a["p0"], b["p0"]], 10.0, 75.0)       # configs/configs_aqua.yaml:42-43
+    for f, g in enumerate((a, b)):
+        of = O.frame_optimization_stereo(cam, float(g["bf"]), g["Xw"], g["obs"], int(g["n_mono"]), g["q0"], g["p0"], 10.0, 75.0)
+        assert got[f][0] == of[0] and np.array_equal(got[f][1], of[1]) and np.array_equal(got[f][2], of[2]) and np.array_equal(got[f][3], of[3]), f
+
+
 def test_pose_stage_argument_errors(F):
     ps = F.PoseStage((400.0, 400.0, 320.0, 240.0), max_batch=2, capacity=64)
     with pytest.raises(RuntimeError):

@@ -540,3 +540,26 @@ def test_frame_optimization_minimises_the_reprojection_error(O, seed, noise, out
     # fewer than 10 observations: one round only, still a valid result
     n9, q9, p9, inl9 = O.frame_optimization(cam, Xw[~bad][:9], uv[~bad][:9], quat_wxyz(R0), p0)
     assert n9 == inl9.sum() and np.abs(_quat_to_R(q9) - Rwc).max() < 2e-2
+
+
+@pytest.mark.parametrize("name", __import__("conftest").POSE_GOLDEN)
+def test_pose_stage_vs_the_independent_numpy_restatement(O, name):
+    """FrameOptimization (mono and stereo edges, src/g2o_optimization.cc:179-321) and SolvePnPWithCV (:323-377) of the oracle
+    against fixtures made by an independent numpy restatement of the same written specification
+    (tests/golden/make_pose_golden.py): different linear algebra, different summation order, different rotation code"""
+    from conftest import check_pose_golden
+    g = golden(name)
+    cam, n_mono = tuple(g["cam"]), int(g["n_mono"])
+    n = len(g["Xw"])
+    if n_mono == n:
+        fo = O.frame_optimization(cam, g["Xw"], g["obs"][:, :2], g["q0"], g["p0"], chi2_threshold=float(g["gate"][0]))
+        # ... and the stereo entry point with no stereo rows is the same computation
+        fs = O.frame_optimization_stereo(cam, float(g["bf"]), g["Xw"], g["obs"], n, g["q0"], g["p0"], *[float(v) for v in g["gate"]])
+        assert fo[0] == fs[0] and np.array_equal(fo[1], fs[1]) and np.array_equal(fo[2], fs[2]) and np.array_equal(fo[3], fs[3])
+        pnp = O.solve_pnp_ransac(cam, g["Xw"], g["obs"][:, :2], seed=int(g["pnp_seed"]))
+        check_pose_golden(g, fo, pnp)
+    else:
+        fs = O.frame_optimization_stereo(cam, float(g["bf"]), g["Xw"], g["obs"], n_mono, g["q0"], g["p0"], *[float(v) for v in g["gate"]])
+        check_pose_golden(g, fs)
+        R = _quat_to_R(fs[1])
+        assert np.abs(R - g["R_true"]).max() < 2e-3 and np.abs(fs[2] - g["p_true"]).max() < 3e-2

@@ -168,6 +168,39 @@ __device__ bool damped_solve(const double (&H)[36], double lambda, const double 
   return true;
 }
 
+// The observations of one frame: mono edges first (2 numbers each: u, v), then stereo edges (3 numbers: u, v, u_right) in
+// the same arrays with row stride `os` -- the order FrameOptimization adds them to the graph (src/g2o_optimization.cc:213-258).
+struct Obs {
+  const double *X, *o;     // map points [n][3], measurements [n][os]
+  int n, n_mono, os;
+  double bf;               // Camera::BF() of the stereo edges
+  double gate_m, gate_s;   // chi-square gates cfg.mono_point / cfg.stereo_point; the Huber deltas are their square roots
+};
+
+// EdgeStereoSE3ProjectXYZOnlyPose (src/g2o_optimization.cc:235-260): the mono edge plus a third row, the column of the point in
+// the right image u - bf / z; measurement (u, v, u_right)
+template <bool JAC>
+__device__ __forceinline__ void reprojection_stereo(const Cam &cam, double bf, const double (&R)[9], const double (&t)[3],
+                                                    const double *X, const double *obs, double (&e)[3], double (&J)[18]) {
+  const double x = ((R[0] * X[0] + R[1] * X[1]) + R[2] * X[2]) + t[0];
+  const double y = ((R[3] * X[0] + R[4] * X[1]) + R[5] * X[2]) + t[1];
+  const double z = ((R[6] * X[0] + R[7] * X[1]) + R[8] * X[2]) + t[2];
+  const double iz = 1.0 / z;
+  const double u = x * iz * cam.fx + cam.cx;
+  e[0] = obs[0] - u;
+  e[1] = obs[1] - (y * iz * cam.fy + cam.cy);
+  e[2] = obs[2] - (u - bf * iz);
+  if (JAC) {
+    const double iz2 = iz * iz;
+    J[0] = x * y * iz2 * cam.fx;           J[1] = -(1.0 + x * x * iz2) * cam.fx; J[2] = y * iz * cam.fx;
+    J[3] = -iz * cam.fx;                   J[4] = 0.0;                           J[5] = x * iz2 * cam.fx;
+    J[6] = (1.0 + y * y * iz2) * cam.fy;   J[7] = -x * y * iz2 * cam.fy;         J[8] = -x * iz * cam.fy;
+    J[9] = 0.0;                            J[10] = -iz * cam.fy;                 J[11] = y * iz2 * cam.fy;
+    J[12] = J[0] - bf * y * iz2;           J[13] = J[1] + bf * x * iz2;          J[14] = J[2];
+    J[15] = J[3];                          J[16] = 0.0;                          J[17] = J[5] - bf * iz2;
+  }
+}
+
 // EdgeSE3ProjectXYZOnlyPose: error = obs - project(R X + t); JAC: its Jacobian w.r.t. (omega, upsilon)
 template <bool JAC>
 __device__ __forceinline__ void reprojection(const Cam &cam, const double (&R)[9], const double (&t)[3], const double *X,
@@ -188,34 +221,57 @@ __device__ __forceinline__ void reprojection(const Cam &cam, const double (&R)[9
   }
 }
 
-// robust chi2 over the active observations of this frame (whole wave); SYSTEM: also H = sum w J^T J, b = -sum w J^T e
+// robust chi2 over the active observations of this frame (whole wave); SYSTEM: also H = sum w J^T J, b = -sum w J^T e.
+// robust: the Huber kernel with delta = sqrt(gate) of the observation's kind (rounds 0-2), else none.
 template <bool SYSTEM>
-__device__ double normal_equations(const Cam &cam, const Rigid &T, const double *Xw, const double *obs, int n,
-                                   const uint8_t *active, double delta, double (&H)[36], double (&b)[6], int lane) {
+__device__ double normal_equations(const Cam &cam, const Rigid &T, const Obs &ob, const uint8_t *active, bool robust,
+                                   double (&H)[36], double (&b)[6], int lane) {
   double R[9];
   rotation_of(T.q, R);
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-  for (int j = lane; j < n; j += 64) {
+  const double delta_m = robust ? sqrt(ob.gate_m) : 0.0, delta_s = robust ? sqrt(ob.gate_s) : 0.0;
+  for (int j = lane; j < ob.n; j += 64) {
     if (!active[j]) continue;
-    double e[2], J[12], depth;
-    reprojection<SYSTEM>(cam, R, T.t, Xw + 3 * j, obs + 2 * j, e, J, depth);
-    const double e2 = e[0] * e[0] + e[1] * e[1];
-    double rho = e2, w = 1.0;
-    if (delta > 0.0) {
-      const double en = sqrt(e2);
-      if (en > delta) { rho = 2.0 * en * delta - delta * delta; w = delta / en; }
-    }
-    acc[27] = acc[27] + rho;
-    if (SYSTEM) {
-      int k = 0;
+    if (j < ob.n_mono) {
+      double e[2], J[12], depth;
+      reprojection<SYSTEM>(cam, R, T.t, ob.X + 3 * j, ob.o + (size_t)ob.os * j, e, J, depth);
+      const double e2 = e[0] * e[0] + e[1] * e[1];
+      double rho = e2, w = 1.0;
+      if (delta_m > 0.0) {
+        const double en = sqrt(e2);
+        if (en > delta_m) { rho = 2.0 * en * delta_m - delta_m * delta_m; w = delta_m / en; }
+      }
+      acc[27] = acc[27] + rho;
+      if (SYSTEM) {
+        int k = 0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = r; c < 6; ++c) { acc[k] = acc[k] + w * (J[r] * J[c] + J[6 + r] * J[6 + c]); ++k; }
+          for (int c = r; c < 6; ++c) { acc[k] = acc[k] + w * (J[r] * J[c] + J[6 + r] * J[6 + c]); ++k; }
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc[21 + r] = acc[21 + r] - w * (J[r] * e[0] + J[6 + r] * e[1]);
+        for (int r = 0; r < 6; ++r) acc[21 + r] = acc[21 + r] - w * (J[r] * e[0] + J[6 + r] * e[1]);
+      }
+    } else {
+      double e[3], J[18];
+      reprojection_stereo<SYSTEM>(cam, ob.bf, R, T.t, ob.X + 3 * j, ob.o + (size_t)ob.os * j, e, J);
+      const double e2 = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+      double rho = e2, w = 1.0;
+      if (delta_s > 0.0) {
+        const double en = sqrt(e2);
+        if (en > delta_s) { rho = 2.0 * en * delta_s - delta_s * delta_s; w = delta_s / en; }
+      }
+      acc[27] = acc[27] + rho;
+      if (SYSTEM) {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) { acc[k] = acc[k] + w * ((J[r] * J[c] + J[6 + r] * J[6 + c]) + J[12 + r] * J[12 + c]); ++k; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] = acc[21 + r] - w * ((J[r] * e[0] + J[6 + r] * e[1]) + J[12 + r] * e[2]);
+      }
     }
   }
   if (SYSTEM) {
@@ -231,12 +287,12 @@ __device__ double normal_equations(const Cam &cam, const Rigid &T, const double 
 }
 
 // `iterations` Levenberg-Marquardt iterations with the damping policy of g2o's OptimizationAlgorithmLevenberg
-__device__ void levenberg(const Cam &cam, const double *Xw, const double *obs, int n, const uint8_t *active, double delta,
-                          int iterations, Rigid &T, int lane) {
+__device__ void levenberg(const Cam &cam, const Obs &ob, const uint8_t *active, bool robust, int iterations, Rigid &T,
+                          int lane) {
   double lambda = 0.0, nu = 2.0;
   for (int it = 0; it < iterations; ++it) {
     double H[36], b[6];
-    double current = normal_equations<true>(cam, T, Xw, obs, n, active, delta, H, b, lane);
+    double current = normal_equations<true>(cam, T, ob, active, robust, H, b, lane);
     if (it == 0) {
       double md = 0.0;
 #pragma unroll
@@ -254,7 +310,7 @@ __device__ void levenberg(const Cam &cam, const double *Xw, const double *obs, i
       double Hd[36], bd[6];
       if (ok) {
         left_update(dx, T);
-        trial = normal_equations<false>(cam, T, Xw, obs, n, active, delta, Hd, bd, lane);
+        trial = normal_equations<false>(cam, T, ob, active, robust, Hd, bd, lane);
       }
       double scale = 1e-3;
       if (ok) {
@@ -290,14 +346,22 @@ __device__ void inverse_of(const double (&q)[4], const double (&p)[3], double (&
 }
 
 // ------------------------------------------------------------------ FrameOptimization: one wave per frame
-__global__ void __launch_bounds__(64) frame_optimization_kernel(Cam cam, double chi2_gate, const int *counts, const double *Xw,
-                                                                const double *obs, int cap, double *q_wc, double *p_wc,
-                                                                uint8_t *inlier, uint8_t *level0, int *n_inliers) {
+// counts_s == nullptr: mono edges only (os = 2).  Else frame f holds counts[f] mono edges followed by counts_s[f] stereo
+// edges, rows of os = 3 numbers.
+__global__ void __launch_bounds__(64) frame_optimization_kernel(Cam cam, double bf, double gate_m, double gate_s, const int *counts,
+                                                                const int *counts_s, const double *Xw, const double *obs,
+                                                                int cap, double *q_wc, double *p_wc, uint8_t *inlier,
+                                                                uint8_t *level0, int *n_inliers) {
   const int f = blockIdx.x, lane = threadIdx.x;
-  const int n = counts[f];
-  const double *X = Xw + (size_t)f * cap * 3, *O = obs + (size_t)f * cap * 2;
+  Obs ob;
+  ob.n_mono = counts[f];
+  ob.n = ob.n_mono + (counts_s ? counts_s[f] : 0);
+  ob.os = counts_s ? 3 : 2;
+  ob.X = Xw + (size_t)f * cap * 3;
+  ob.o = obs + (size_t)f * cap * ob.os;
+  ob.bf = bf; ob.gate_m = gate_m; ob.gate_s = gate_s;
+  const int n = ob.n;
   uint8_t *inl = inlier + (size_t)f * cap, *lvl = level0 + (size_t)f * cap;
-  const double delta = sqrt(chi2_gate);
   double qn[4] = {q_wc[4 * f], q_wc[4 * f + 1], q_wc[4 * f + 2], q_wc[4 * f + 3]};
   const double pn[3] = {p_wc[3 * f], p_wc[3 * f + 1], p_wc[3 * f + 2]};
   unit(qn);
@@ -308,15 +372,23 @@ __global__ void __launch_bounds__(64) frame_optimization_kernel(Cam cam, double 
   int outliers = 0;
   for (int round = 0; round < 4; ++round) {
     T = prior;                                                  // :266-267 every round restarts from the prior
-    levenberg(cam, X, O, n, lvl, round < 3 ? delta : 0.0, 10, T, lane);
+    levenberg(cam, ob, lvl, round < 3, 10, T, lane);            // :289-290, :304-305 no robust kernel after round 2
     double R[9];
     rotation_of(T.q, R);
     int bad = 0;
     for (int j = lane; j < n; j += 64) {
-      double e[2], J[12], depth;
-      reprojection<false>(cam, R, T.t, X + 3 * j, O + 2 * j, e, J, depth);
-      const float chi2 = (float)(e[0] * e[0] + e[1] * e[1]);    // :279 const float chi2
-      const bool out = chi2 > chi2_gate;
+      bool out;
+      if (j < ob.n_mono) {
+        double e[2], J[12], depth;
+        reprojection<false>(cam, R, T.t, ob.X + 3 * j, ob.o + (size_t)ob.os * j, e, J, depth);
+        const float chi2 = (float)(e[0] * e[0] + e[1] * e[1]);  // :279 const float chi2
+        out = chi2 > gate_m;
+      } else {
+        double e[3], J[18];
+        reprojection_stereo<false>(cam, bf, R, T.t, ob.X + 3 * j, ob.o + (size_t)ob.os * j, e, J);
+        const float chi2 = (float)((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);   // :295
+        out = chi2 > gate_s;
+      }
       inl[j] = out ? 0 : 1;
       lvl[j] = out ? 0 : 1;
       bad += out ? 1 : 0;
@@ -557,7 +629,9 @@ __global__ void __launch_bounds__(64) pnp_finish_kernel(Cam cam, double gate2, d
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave re-reads inl / X / O written by other lanes
   __builtin_amdgcn_s_waitcnt(0);
   quaternion_of(R, T.q);
-  levenberg(cam, X, O, n, inl, 0.0, 10, T, lane);            // refinement on the inliers (OpenCV: SOLVEPNP_ITERATIVE)
+  Obs ref;                                                    // refinement on the inliers (OpenCV: SOLVEPNP_ITERATIVE)
+  ref.X = X; ref.o = O; ref.n = n; ref.n_mono = n; ref.os = 2; ref.bf = 0.0; ref.gate_m = 0.0; ref.gate_s = 0.0;
+  levenberg(cam, ref, inl, false, 10, T, lane);
   double Rr[9];
   rotation_of(T.q, Rr);
   if (lane == 0) {
@@ -580,7 +654,7 @@ struct urf_pose {
   hipStream_t st = nullptr;
   int *d_counts = nullptr, *d_ok = nullptr, *d_count = nullptr, *d_ninl = nullptr;
   float *d_obj = nullptr, *d_img = nullptr;
-  double *d_X = nullptr, *d_uv = nullptr, *d_hyp = nullptr, *d_pose = nullptr, *d_q = nullptr, *d_p = nullptr;
+  double *d_X = nullptr, *d_uv = nullptr, *d_uv3 = nullptr, *d_hyp = nullptr, *d_pose = nullptr, *d_q = nullptr, *d_p = nullptr;
   uint8_t *d_inl = nullptr, *d_lvl = nullptr;
 };
 
@@ -603,6 +677,7 @@ extern "C" int urf_pose_create(int device, int max_batch, int capacity, urf_pose
   URF_HIP(hipMalloc((void **)&h->d_img, B * C * 2 * 4));
   URF_HIP(hipMalloc((void **)&h->d_X, B * C * 3 * 8));
   URF_HIP(hipMalloc((void **)&h->d_uv, B * C * 2 * 8));
+  URF_HIP(hipMalloc((void **)&h->d_uv3, B * C * 3 * 8));
   URF_HIP(hipMalloc((void **)&h->d_hyp, B * h->max_iters * 12 * 8));
   URF_HIP(hipMalloc((void **)&h->d_pose, B * 16 * 8));
   URF_HIP(hipMalloc((void **)&h->d_q, B * 4 * 8));
@@ -618,7 +693,7 @@ extern "C" void urf_pose_destroy(urf_pose *h) {
   (void)hipSetDevice(h->device);
   if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
   void *bufs[] = {h->d_counts, h->d_ninl, h->d_ok, h->d_count, h->d_obj, h->d_img, h->d_X, h->d_uv, h->d_hyp, h->d_pose,
-                  h->d_q, h->d_p, h->d_inl, h->d_lvl};
+                  h->d_q, h->d_p, h->d_inl, h->d_lvl, h->d_uv3};
   for (void *p : bufs) (void)hipFree(p);
   delete h;
 }
@@ -680,8 +755,37 @@ extern "C" int urf_frame_optimization(urf_pose *h, const urf_poseopt_config *cfg
   URF_HIP(hipMemcpyAsync(h->d_uv, obs, (size_t)B * cap * 16, hipMemcpyHostToDevice, st));
   URF_HIP(hipMemcpyAsync(h->d_q, q_wc, (size_t)B * 32, hipMemcpyHostToDevice, st));
   URF_HIP(hipMemcpyAsync(h->d_p, p_wc, (size_t)B * 24, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(frame_optimization_kernel, dim3(B), dim3(64), 0, st, cam, gate, h->d_counts, h->d_X, h->d_uv, cap, h->d_q,
-                     h->d_p, h->d_inl, h->d_lvl, h->d_ninl);
+  hipLaunchKernelGGL(frame_optimization_kernel, dim3(B), dim3(64), 0, st, cam, 0.0, gate, 0.0, h->d_counts, (const int *)nullptr,
+                     h->d_X, h->d_uv, cap, h->d_q, h->d_p, h->d_inl, h->d_lvl, h->d_ninl);
+  URF_HIP(hipGetLastError());
+  URF_HIP(hipMemcpyAsync(q_wc, h->d_q, (size_t)B * 32, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(p_wc, h->d_p, (size_t)B * 24, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(inlier, h->d_inl, (size_t)B * cap, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipMemcpyAsync(n_inliers, h->d_ninl, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  URF_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int urf_frame_optimization_stereo(urf_pose *h, const urf_poseopt_stereo_config *cfg, int B, const int *n_mono,
+                                             const int *n_stereo, const double *Xw, const double *obs, int cap, double *q_wc,
+                                             double *p_wc, uint8_t *inlier, int *n_inliers) {
+  URF_CHECK(cfg && n_stereo && Xw && obs && q_wc && p_wc && inlier && n_inliers, "urf_frame_optimization_stereo: null argument");
+  if (pose_check(h, B, n_mono, cap)) return -2;
+  for (int f = 0; f < B; ++f)
+    URF_CHECK(n_stereo[f] >= 0 && n_mono[f] + n_stereo[f] <= cap, "frame %d: %d + %d observations above the row capacity %d", f,
+              n_mono[f], n_stereo[f], cap);
+  const double gate_m = cfg->chi2_mono > 0 ? cfg->chi2_mono : 5.991, gate_s = cfg->chi2_stereo > 0 ? cfg->chi2_stereo : 7.815;
+  const Cam cam = {cfg->fx, cfg->fy, cfg->cx, cfg->cy};
+  URF_HIP(hipSetDevice(h->device));
+  hipStream_t st = h->st;
+  URF_HIP(hipMemcpyAsync(h->d_counts, n_mono, (size_t)B * 4, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(h->d_count, n_stereo, (size_t)B * 4, hipMemcpyHostToDevice, st));   // (the hypothesis counters double as the stereo counts)
+  URF_HIP(hipMemcpyAsync(h->d_X, Xw, (size_t)B * cap * 24, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(h->d_uv3, obs, (size_t)B * cap * 24, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(h->d_q, q_wc, (size_t)B * 32, hipMemcpyHostToDevice, st));
+  URF_HIP(hipMemcpyAsync(h->d_p, p_wc, (size_t)B * 24, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(frame_optimization_kernel, dim3(B), dim3(64), 0, st, cam, cfg->bf, gate_m, gate_s, h->d_counts, h->d_count,
+                     h->d_X, h->d_uv3, cap, h->d_q, h->d_p, h->d_inl, h->d_lvl, h->d_ninl);
   URF_HIP(hipGetLastError());
   URF_HIP(hipMemcpyAsync(q_wc, h->d_q, (size_t)B * 32, hipMemcpyDeviceToHost, st));
   URF_HIP(hipMemcpyAsync(p_wc, h->d_p, (size_t)B * 24, hipMemcpyDeviceToHost, st));

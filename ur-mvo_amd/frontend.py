@@ -603,3 +603,21 @@ class PoseStage:
         check(_lib.lib().urf_frame_optimization(self._h, C.byref(cfg), B, _p(n), _p(X), _p(obs), cap, _p(q), _p(p), _p(inl),
                                                 _p(k)), "urf_frame_optimization")
         return [(int(k[f]), q[f].copy(), p[f].copy(), inl[f, :n[f]].copy()) for f in range(B)]
+
+
+    def FrameOptimizationStereo(self, bf, map_points, observations, n_mono, q_wc, p_wc, chi2_mono=5.991, chi2_stereo=7.815):
+        """FrameOptimization with stereo edges: per frame observations [n, 3] = (u, v, u_right), the first n_mono[f] rows mono
+        (u_right unused) -> per frame (n - outliers, q_wc, p_wc, inlier flags[n])"""
+        n, cap, X = self._pack(map_points, 3, np.float64)
+        _, _, obs = self._pack(observations, 3, np.float64)
+        B = len(n)
+        nm = np.ascontiguousarray(n_mono, np.int32)
+        ns = (n - nm).astype(np.int32)
+        q = np.ascontiguousarray(np.asarray(q_wc, np.float64).reshape(B, 4)).copy()
+        p = np.ascontiguousarray(np.asarray(p_wc, np.float64).reshape(B, 3)).copy()
+        cfg = _lib.PoseOptStereoConfig(*self.cam, float(bf), chi2_mono, chi2_stereo)
+        inl = np.zeros((B, cap), np.uint8)
+        k = np.zeros(B, np.int32)
+        check(_lib.lib().urf_frame_optimization_stereo(self._h, C.byref(cfg), B, _p(nm), _p(ns), _p(X), _p(obs), cap, _p(q), _p(p),
+                                                       _p(inl), _p(k)), "urf_frame_optimization_stereo")
+        return [(int(k[f]), q[f].copy(), p[f].copy(), inl[f, :n[f]].copy()) for f in range(B)]
