@@ -254,3 +254,16 @@ def test_integration_patches_apply_to_the_reference(tmp_path):
     out = open(tmp_path / "src" / "tracking.cc").read()
     assert "ExtractFeatureBatch" in out and "std::thread point_ectraction_thread" not in out
     assert "usleep(30000);" not in open(tmp_path / "main_py.cpp").read()
+
+
+def test_shim_headers_opencv_branch_is_well_formed():
+    """the shim headers choose their OpenCV / Eigen branch with __has_include; this image has neither library, so that branch
+    (SuperPoint::visualization's cv::cvtColor / cv::circle / cv::imwrite, include/super_point.h) is otherwise never seen by a
+    compiler.  Syntax check only (-fsyntax-only) against declaration stubs kept under tests/cpp/cv_stubs."""
+    import subprocess
+    src = "#include <super_point.h>\n#include <super_glue.h>\n#include <point_matching.h>\n#include <epipolar_geometry.h>\n" \
+          "#ifndef URF_HAVE_CV\n#error the OpenCV branch was not selected\n#endif\n" \
+          "void f(SuperPoint &sp, const cv::Mat &im) { sp.visualization(\"x\", im); }\n"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "cpp", "cv_stubs"),
+                        "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr[-3000:]
