@@ -292,7 +292,7 @@ def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H,
     bench streams (the bench line counts them)."""
     import torch
     frames, ofeats, _ = bench_stream_oracle(H, W)
-    monkeypatch.setenv("URF_GUARD_SP_ULPS", "100")
+    monkeypatch.setenv("URF_GUARD_SP_ULPS", "100" if W == 640 else "40")     # (the wider frames hold more candidates per score interval)
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=2)
     assert sp.build(sp_blob)
     monkeypatch.delenv("URF_GUARD_SP_ULPS")
@@ -304,7 +304,7 @@ def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H,
     sp.sync()
     hdr = slots[:, :4].cpu().numpy().view(np.int32)
     st = sp.near_tie_reruns()
-    assert st["frames"] == 16 and st["cut_resolved"] >= 6 and st["cut_resolved"] + st["redone"] == int((hdr[:, 1] != 0).sum()), (st, hdr[:, 1])
+    assert st["frames"] == 16 and st["cut_resolved"] >= 5 and st["cut_resolved"] + st["redone"] == int((hdr[:, 1] != 0).sum()), (st, hdr[:, 1])
     assert st["candidates"] >= 2 * st["cut_resolved"]
     for j in range(16):
         f = F.slot_to_host(slots[j].data_ptr())

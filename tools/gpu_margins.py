@@ -71,7 +71,8 @@ for (H, W) in ((480, 640), (376, 1241)):
         hm = heat[0] > THR * 0.5
         h0, h1 = heat[0][hm].astype(np.float64), heat[1][hm].astype(np.float64)
         rec.setdefault("heat_err_over_s_1ms_max", []).append(float((np.abs(h1 - h0) / (h0 * (1 - h0) + 1e-7)).max()))
-        rec.setdefault("heat_err_minus_model_ulps_max", []).append(float(((np.abs(h1 - h0) - 2e-5 * h0 * (1 - h0)) / np.spacing(heat[0][hm])).max()))
+        # the product's constants (sp_api.hip kGuardSpDelta / kGuardSpUlps): what is left of the error after the delta term, in ulps
+        rec.setdefault("heat_err_minus_model_ulps_max", []).append(float(((np.abs(h1 - h0) - 1.6e-4 * h0 * (1 - h0)) / np.spacing(heat[0][hm])).max()))
         # NMS near-ties: pixels that are not the maximum of their 9x9 window but within eps (relative) of it, where it matters
         from scipy.ndimage import maximum_filter
         mx = maximum_filter(heat[0], size=9, mode="constant", cval=0.0)

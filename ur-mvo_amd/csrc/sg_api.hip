@@ -118,6 +118,11 @@ struct urf_pm {
   unsigned long long *g_stats = nullptr;
   unsigned long long pairs_seen = 0;
   float g_z = 0.0f;
+  // the exact redo of a device batch as ONE graph launch behind the fast pass (pm_guard_stream), one graph per (pairs, outlier stage)
+  struct RedoGraph { int P; bool ransac; hipGraph_t graph; hipGraphExec_t exec; };
+  std::vector<RedoGraph> redo_graphs;
+  bool redo_in_stream = false;     // the last batch's redo ran in the stream: nothing left to do at fetch time
+  int graph_mode = -1;             // URF_GUARD_GRAPH: 1 (default) = captured graph, 0 = the same launches one by one
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -404,6 +409,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->g_flags, h->counts_r, h->r_nfinal, h->r_fmatches, h->g_stats};
     for (void *p : bufs) (void)hipFree(p);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
+    for (const urf_pm::RedoGraph &g : h->redo_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     (void)hipHostFree(h->h_matches);
     (void)hipHostFree(h->h_n);
     (void)hipHostFree(h->h_rs_err);
@@ -553,6 +559,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
       return -1;
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
+  h->redo_in_stream = false;
   h->pairs_seen += (unsigned long long)P;
   return pm_tail(h, P, want_Z, ransac, prof, h->fast, false);
 }
@@ -591,28 +598,65 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   return 0;
 }
 
-// Guarded fast mode, after the batch's results have been waited for (and after pm_check_resident): pairs whose guard word is set
-// are redone in the exact mode -- the 18 layers from the encoded keypoints (h->x still holds them: the fast layers work on their
-// own f16 planes), log-domain Sinkhorn, decode, outlier stage -- with the counts of all other pairs masked to zero, so that every
-// kernel skips them.  P == 1 (host API, `in_place`): the exact results simply replace the fast ones, Z and index vectors included.
-// Returns 1 when lists were rewritten (the caller repeats its copies), 0 when no pair was flagged.
-static int pm_guard_redo(urf_pm *h, bool in_place) {
-  if (!h->guarded || h->last_P < 1) return 0;
-  const int P = h->last_P;
-  bool any = false;
-  for (int p = 0; p < P; ++p) any = any || h->h_gflags[p] != 0;
-  if (!any) return 0;
-  hipStream_t st = h->st;
-  if (launch_guard_counts(h->g_flags, h->counts, h->counts_r, P, h->g_stats, st)) return -1;
+// The exact pass over the flagged pairs of a batch of P pairs, as stream work: the counts of all other pairs are masked to
+// zero on the device, so every kernel skips them -- the 18 layers from the encoded keypoints (h->x still holds them: the
+// fast layers work on their own f16 planes), the final projection, log-domain Sinkhorn, decode, outlier stage into the redo
+// buffers, and the merge of the redone lists over the fast ones.
+static int pm_redo_launches(urf_pm *h, int P, bool want_Z, bool ransac, bool in_place) {
+  if (launch_guard_counts(h->g_flags, h->counts, h->counts_r, P, h->g_stats, h->st)) return -1;
   int *full = h->counts;
   h->counts = h->counts_r;
   int rc = pm_gnn_exact(h, 2 * P, false);
   if (!rc) rc = sg_linear(h, 2 * P, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr);
-  if (!rc) rc = pm_tail(h, P, h->last_Z, h->last_ransac, false, false, !in_place);
+  if (!rc) rc = pm_tail(h, P, want_Z, ransac, false, false, !in_place);
   h->counts = full;
   if (rc) return -1;
-  if (!in_place && launch_guard_merge(h->g_flags, h->r_fmatches, h->r_nfinal, h->fmatches, h->nfinal, P, st)) return -1;
-  URF_HIP(hipStreamSynchronize(st));
+  if (!in_place && launch_guard_merge(h->g_flags, h->r_fmatches, h->r_nfinal, h->fmatches, h->nfinal, P, h->st)) return -1;
+  return 0;
+}
+
+// Guarded fast mode, device batches: the exact pass is enqueued behind the fast one unconditionally -- the host never waits to
+// learn whether a pair was flagged, and when none was (the usual case) its ~300 kernels find zero counts and exit at once.
+// They are captured once per (pairs, outlier stage) into a HIP graph: one launch call instead of 300.
+static int pm_guard_stream(urf_pm *h, int P, bool ransac) {
+  if (!h->guarded) return 0;
+  if (h->graph_mode < 0) { const char *e = getenv("URF_GUARD_GRAPH"); h->graph_mode = e ? atoi(e) : 1; }
+  h->redo_in_stream = true;
+  if (h->graph_mode == 0) return pm_redo_launches(h, P, false, ransac, false);
+  for (const urf_pm::RedoGraph &g : h->redo_graphs)
+    if (g.P == P && g.ransac == ransac) { URF_HIP(hipGraphLaunch(g.exec, h->st)); return 0; }
+  // first batch of this shape: run the launches once directly (one-time kernel attributes are set outside a capture), then capture
+  if (pm_redo_launches(h, P, false, ransac, false)) return -1;
+  urf_pm::RedoGraph g = {P, ransac, nullptr, nullptr};
+  if (hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->graph_mode = 0; return 0; }
+  const int rc = pm_redo_launches(h, P, false, ransac, false);
+  const hipError_t ec = hipStreamEndCapture(h->st, &g.graph);
+  if (rc || ec != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    fprintf(stderr, "liburf_front: could not capture the guarded mode's redo pass into a HIP graph; using plain launches\n");
+    h->graph_mode = 0;
+    return 0;
+  }
+  h->redo_graphs.push_back(g);
+  return 0;
+}
+
+// Guarded fast mode, host APIs (one pair, results read back right away), after the results have been waited for (and after
+// pm_check_resident): a flagged pair is redone in the exact mode and the exact results simply replace the fast ones, Z and
+// index vectors included.  Device batches took the in-stream pass above.  Returns 1 when results were rewritten (the caller
+// repeats its copies), 0 when there was nothing to do.
+static int pm_guard_redo(urf_pm *h, bool in_place) {
+  if (!h->guarded || h->last_P < 1) return 0;
+  const int P = h->last_P;
+  if (h->redo_in_stream) {
+    for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
+    return 0;
+  }
+  bool any = false;
+  for (int p = 0; p < P; ++p) any = any || h->h_gflags[p] != 0;
+  if (!any) return 0;
+  if (pm_redo_launches(h, P, h->last_Z, h->last_ransac, in_place)) return -1;
+  URF_HIP(hipStreamSynchronize(h->st));
   for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
   return 1;
 }
@@ -640,6 +684,7 @@ static int pm_check_resident(urf_pm *h) {
           "(give-up %d of this handle)\n", h->last_P, h->rs_backoff, h->rs_fallbacks);
   URF_CHECK(h->last_P >= 1, "resident Sinkhorn gave up and there is no batch to redo");
   if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast, false)) return -1;
+  if (h->redo_in_stream && pm_guard_stream(h, h->last_P, h->last_ransac)) return -1;   // the redone tail has new guard words
   URF_HIP(hipStreamSynchronize(h->st));
   return 1;
 }
@@ -782,6 +827,7 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
                            h->x, h->st))
     return -1;
   if (pm_pipeline(h, P, false, outlier_rejection != 0)) return -1;
+  if (pm_guard_stream(h, P, outlier_rejection != 0)) return -1;
   URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipEventRecord(h->ev_done, h->st));

@@ -38,7 +38,7 @@ const char *last_error() {
 int g_profiling = 0;
 // guarded fast mode, SuperPoint: error model of a fast-mode score, delta * s * (1 - s) + ulps * ulp(s) (sp_kernels.hip);
 // measured maxima on both bench streams times a safety factor (DESIGN.md "Guarded fast mode", tools/gpu_margins.py)
-static const float kGuardSpDelta = 2e-4f, kGuardSpUlps = 32.0f;
+static const float kGuardSpDelta = 1.6e-4f, kGuardSpUlps = 8.0f;
 
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
 int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, const int *gate, hipStream_t st);
@@ -103,7 +103,7 @@ struct urf_sp {
   uint8_t *d_img = nullptr, *d_usermask = nullptr;
   int cand_cap = 0;
   // guarded fast mode: guard words, threshold-band scratch, redo list (gate), images of the frames to redo, counters
-  int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr, *g_amb = nullptr;
+  int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr, *g_amb = nullptr, *g_nms = nullptr;
   uint8_t *g_img = nullptr;
   unsigned long long *g_stats = nullptr;
   float g_delta = 0.0f, g_ulps = 0.0f;
@@ -312,7 +312,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     if (arena(h->R, false)) return -1;
     URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
     if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) ||
-        dalloc(&h->g_amb, B * (1 + kAmbMax)))
+        dalloc(&h->g_amb, B * (1 + kAmbMax)) || dalloc(&h->g_nms, B))
       return -1;
     if (dalloc(&h->g_img, B * H * W)) return -1;
     const char *e;
@@ -383,7 +383,7 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     for (void *p : bufs) (void)hipFree(p);
     void *rbufs[] = {h->R.a1, h->R.a2a, h->R.a2b, h->R.a3a, h->R.a3b, h->R.a4a, h->R.a4b, h->R.apd, h->R.logits, h->R.ddb, h->R.desc,
                      h->R.heat, h->R.scores, h->R.ss, h->R.mask, h->R.supp, h->R.counts, h->R.cand_score, h->R.cand_idx, h->R.cand_n,
-                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb};
+                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb, h->g_nms};
     for (void *p : rbufs) (void)hipFree(p);
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
@@ -578,10 +578,11 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   h->lastH = H; h->lastW = W; h->lastB = B;
   if (h->precision != 2) return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true);
   const int Hs = H / 8 * 8, Ws = W / 8 * 8;
-  g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.delta = h->g_delta; g.ulps = h->g_ulps;
+  g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.nms_hi = h->g_nms; g.delta = h->g_delta; g.ulps = h->g_ulps;
   SpGuard off = {};
   URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), h->st));
   URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), h->st));
+  URF_HIP(hipMemsetAsync(h->g_nms, 0, B * sizeof(int), h->st));
   if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3)) return -1;
   if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, h->st)) return -1;
   if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, nullptr, false, 3)) return -1;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
   __shared__ float hm[(NR + 8)][NC];
   const int b = blockIdx.z;
   URF_GATE_FULL(b);
-  bool near_tie = false;
+  float near_tie = 0.0f;     // the highest window maximum that some pixel came within the error of
   const size_t boff = (size_t)b * H * W;
   const int y0 = blockIdx.y * NR, x0 = blockIdx.x * NC;
   const int tid = threadIdx.x;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
     const float center = tin[r + 4][c + 4];
     // guard: a pixel that loses against its window's maximum by less than the two scores' error could win in the exact
     // mode (only where the maximum can become a keypoint at all)
-    if (MODE != 1 && g.flags && center != m && m > thr_lo && guard_near(center, m, g)) near_tie = true;
+    if (MODE != 1 && g.flags && center != m && m > thr_lo && guard_near(center, m, g)) near_tie = fmaxf(near_tie, m);
     if (MODE == 0) {
       mask[p] = (center == m) ? 1 : 0;
     } else if (MODE == 1) {
@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(256) nms_pass_kernel(const float *s, uint8_t *
       else mask[p] = mk;
     }
   }
-  if (MODE != 1 && g.flags && near_tie) atomicOr(&g.flags[b], 4);
+  // not a flag yet: a near-tie only matters if its maximum can reach the final keypoint set, which the top-k selection decides
+  // once it knows the cut (topk_kernel); positive floats order like their bit patterns
+  if (MODE != 1 && g.flags && near_tie > 0.0f) atomicMax(&g.nms_hi[b], __float_as_int(near_tie));
 }
 
 // guard: two surviving pixels within 4 px of each other (Chebyshev) can only be an exact tie of the fast scores (each is the
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256) nms_tie_kernel(const float *out, int H, i
       tie = tie || o[(size_t)yy * W + xx] > 0.0f;
     }
   }
-  if (tie) atomicOr(&g.flags[b], 4);
+  if (tie) atomicMax(&g.nms_hi[b], __float_as_int(c));
 }
 
 // ---------------------------------------------------------------- selection
@@ -304,8 +306,14 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
     for (int i = tid; i < n; i += 1024) { os[i] = cs[i]; oi[i] = ci[i]; }
     if (tid == 0) {
       kp_n[b] = n;
-      // guard: every candidate is kept, so a pixel within its error of the threshold changes the result
-      if (g.flags && g.band[b]) atomicOr(&g.flags[b], 2);
+      // guard: every candidate is kept, so a pixel within its error of the threshold changes the result, and so does any
+      // NMS near-tie whose maximum is a candidate
+      if (g.flags) {
+        int bits = g.band[b] ? 2 : 0;
+        if (__int_as_float(g.nms_hi[b]) > (float)thr - guard_err((float)thr, g.delta, g.ulps)) bits |= 4;
+        if (bits) atomicOr(&g.flags[b], bits);
+        g.amb[(size_t)b * (1 + kAmbMax)] = 0;
+      }
     }
     return;
   }
@@ -363,14 +371,16 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
       if (guard_near(cut, nxt, g)) bits |= 1;
       // a pixel within its error of the threshold matters only if it could enter the top k
       if (g.band[b] && guard_near(cut, thr, g)) bits |= 2;
+      // an NMS near-tie matters only if its maximum could be among the top k: at or above the cut's error band
+      if (__int_as_float(g.nms_hi[b]) >= cut - 2.1f * guard_err(cut, g.delta, g.ulps)) bits |= 4;
       s_cnt = bits;
       g.amb[(size_t)b * (1 + kAmbMax)] = 0;
     }
     __syncthreads();
     if (s_cnt & 1) {
       // the candidates within the error of the cut, on either side: their exact scores decide who is in (guard_resolve_kernel).
-      // One uniform error for the band (the scores in it differ by 1e-5 at most): 2 x 1.25 x err(cut)
-      const float band = 2.5f * guard_err(cut, g.delta, g.ulps);
+      // One uniform error for the band (the scores in it differ from the cut by a few 1e-6, so do their errors): 2.1 x err(cut)
+      const float band = 2.1f * guard_err(cut, g.delta, g.ulps);
       for (int i = tid; i < n; i += 1024) {
         const float d = cs[i] > cut ? cs[i] - cut : cut - cs[i];
         if (d <= band) {

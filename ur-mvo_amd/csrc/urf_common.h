@@ -82,6 +82,7 @@ struct SpGuard {
   int *flags;        // [B] bit 0: top-k cut (resolved per candidate), bit 1: threshold band, bit 2: NMS near-tie, bit 3: too many
                      // candidates at the cut (bits 1-3: the whole frame is redone); null = guard off
   int *band;         // [B] scratch: some candidate lies in the threshold band
+  int *nms_hi;       // [B] scratch: float bits of the highest window maximum an NMS near-tie involved
   int *amb;          // [B][1 + kAmbMax]: count and pixel indices of the candidates within the error of the cut
   float delta, ulps; // error model of a fast-mode score: delta * s * (1 - s) + ulps * ulp(s)
 };
