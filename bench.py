@@ -468,6 +468,7 @@ def main():
                                 "superpoint_causes": {k: sp_g[k] for k in ("cut_resolved", "candidates", "threshold", "nms", "cut_overflow")},
                                 "matcher_causes": {k: sum(g_[k] for g_ in pm_g) for k in ("threshold", "runner_up")}},
             "per_rank": per_rank,
+            "library": U._lib.lib().urf_build_info().decode(),
         }
         print(json.dumps(out))
     if world > 1 or force_dist:

@@ -30,6 +30,7 @@ extern "C" {
 #define URF_SG_BLOB_FLOATS 12003905
 
 const char *urf_last_error(void);
+const char *urf_build_info(void);   /* build time of this binary and the guard constants compiled into it */
 int urf_device_count(void);
 
 /* ------------------------------------------------------------ SuperPoint -- */

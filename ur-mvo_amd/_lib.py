@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "liburf_front.so")
 
 # every symbol include/urf.h declares
 SYMBOLS = [
-    "urf_last_error", "urf_device_count", "urf_sp_create", "urf_sp_build", "urf_sp_build_file",
+    "urf_last_error", "urf_build_info", "urf_device_count", "urf_sp_create", "urf_sp_build", "urf_sp_build_file",
     "urf_weights_save", "urf_sp_destroy", "urf_sp_infer", "urf_sp_infer_batch", "urf_slot_bytes",
     "urf_sp_infer_device", "urf_sp_sync", "urf_slot_to_host", "urf_sp_debug_tensor", "urf_pm_create",
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
@@ -109,6 +109,7 @@ def lib():
         if missing:
             raise RuntimeError(f"liburf_front.so lacks C-ABI symbols: {missing}")
         L.urf_last_error.restype = C.c_char_p
+        L.urf_build_info.restype = C.c_char_p
         L.urf_slot_bytes.restype = C.c_size_t
         L.urf_normalize_keypoints.restype = None
         L.urf_sp_destroy.restype = None

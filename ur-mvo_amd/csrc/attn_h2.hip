@@ -239,13 +239,18 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
       cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
       mn[t] = fmaxf(m[t], cm);
-      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn[t]);
-      m[t] = mn[t];
-      part[t] = part[t] * alpha;
+      // the running maximum of a query rarely moves after its first chunks: when it did not for any query of this tile
+      // (wave-uniform test) the rescale factor is exactly 1 and the 17 multiplications and the exponential are skipped --
+      // the same numbers either way
+      if (!__all(mn[t] == m[t])) {
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - mn[t]);
+        m[t] = mn[t];
+        part[t] = part[t] * alpha;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[t][dt][r] = oacc[t][dt][r] * alpha;
+          for (int r = 0; r < 4; ++r) oacc[t][dt][r] = oacc[t][dt][r] * alpha;
+      }
     }
     AT_STAMP(2);
     // ---- O^T += V^T P^T, 32 keys per k-step
