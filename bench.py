@@ -179,7 +179,7 @@ def main():
     # it.  NB global batches are cycled.
     OVERLAP = int(os.environ.get("URF_BENCH_OVERLAP", "2"))
     MATCHERS = int(os.environ.get("URF_BENCH_MATCHERS", "2")) if OVERLAP == 2 else 1
-    NB = MATCHERS + 3
+    NB = max(5, MATCHERS + 2)      # the ring (and with it the 40-frame stream the parity tests hold oracle results for) stays at 5 batches up to 3 matchers
     stream = synth.shift_stream(100, NB * BATCH * world, H, W)
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8

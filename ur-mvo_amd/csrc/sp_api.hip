@@ -174,7 +174,12 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_CHECK(n_floats == URF_SP_BLOB_FLOATS, "SP blob has %zu floats, expected %d", n_floats, URF_SP_BLOB_FLOATS);
   URF_CHECK(!h->built, "urf_sp_build: already built");
   URF_HIP(hipSetDevice(h->device));
-  URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  {
+    // URF_SP_PRIORITY (experiments): HIP stream priority of the handle's stream (hipDeviceGetStreamPriorityRange; lower = sooner)
+    const char *e = getenv("URF_SP_PRIORITY");
+    if (e) URF_HIP(hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, atoi(e)));
+    else URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  }
   // ---- repack weights: every tensor 256-B aligned; Pa||Da concatenated; Pb padded
   std::vector<float> host;
   auto put = [&](const float *src, size_t n) {

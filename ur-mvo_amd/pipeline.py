@@ -38,7 +38,9 @@ class SlotRingPipeline:
         self.dev, self.rank, self.world = device, int(rank), int(world)
         self.d_frames = d_frames
         self.NB = d_frames.shape[0] // self.B
-        assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 3, "ring too short for the matchers"
+        # ring slot k is refilled by SuperPoint(b + NB), enqueued in step b + NB - 1; the last slot of batch b is read by match(b + 1),
+        # which the host has fetched by step b + M: NB >= M + 2
+        assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 2, "ring too short for the matchers"
         self.overlap = overlap if len(self.pms) == 1 else 2
         self.outlier = bool(outlier_rejection)
         self.comm, self.gloo = comm, bool(gloo)
