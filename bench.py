@@ -266,6 +266,7 @@ def main():
     health = {"rank": rank, "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms),
               "frames_redone_exact": sp_g["redone"], "frames": sp_g["frames"], "cuts_resolved": sp_g["cut_resolved"],
               "pairs_redone_exact": sum(g_["redone"] for g_ in pm_g), "pairs": sum(g_["pairs"] for g_ in pm_g),
+              "pairs_flagged": sum(g_["flagged"] for g_ in pm_g),
               "region_s": [round(time_r, 4) for time_r in region_local],
               "superpoint_ms": round(float(np.mean(sp_ms)), 3) if sp_ms else None,
               "matching_ms": round(float(np.mean(pm_ms)), 3) if pm_ms else None}
@@ -464,6 +465,7 @@ def main():
             # error (all ranks, warm-up and timed regions; the reruns are part of the timed work)
             "near_tie_reruns": {"frames": sum(h_["frames_redone_exact"] for h_ in per_rank), "of_frames": sum(h_["frames"] for h_ in per_rank),
                                 "pairs": sum(h_["pairs_redone_exact"] for h_ in per_rank), "of_pairs": sum(h_["pairs"] for h_ in per_rank),
+                                "pairs_flagged_not_redone": sum(h_["pairs_flagged"] - h_["pairs_redone_exact"] for h_ in per_rank),
                                 "frames_with_cut_resolved_per_candidate": sum(h_["cuts_resolved"] for h_ in per_rank),
                                 "superpoint_causes": {k: sp_g[k] for k in ("cut_resolved", "candidates", "threshold", "nms", "cut_overflow")},
                                 "matcher_causes": {k: sum(g_[k] for g_ in pm_g) for k in ("threshold", "runner_up")}},

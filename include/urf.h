@@ -122,9 +122,12 @@ typedef struct {
   /* 0 = exact fp32 (bit-identical to the oracle, default); 1 = fast: the 18 GNN
    * layers run on the f16 matrix core with split operands (fp32-equivalent
    * accuracy, not bit-reproducible); 2 = guarded fast: as 1, and a pair in which a row's or
-   * column's best assignment lies within the fast mode's error of the matching threshold or of its runner-up is
-   * redone in the exact mode inside the library before its match list is handed out (urf_pm_fetch, urf_match,
-   * urf_sg_infer), so the match SET of every pair is the exact mode's.  urf_pm_near_tie_reruns() counts them. */
+   * column's best assignment lies within the fast PIPELINE's error (5e-4 on the log-assignment: the fast matcher's own
+   * error plus what the fast SuperPoint's descriptor noise induces) of the matching threshold or of its runner-up is
+   * flagged: urf_pm_near_tie_flags() names the pairs of the batch just fetched, urf_pm_near_tie_reruns() counts them.
+   * Pairs that are not flagged have the exact pipeline's match set.  A flagged pair is one whose decisive entries the
+   * reference's own arithmetic decides by rounding noise; with URF_GUARD_REDO_PAIRS=1 it is also redone with the exact
+   * matcher on the same slots (in the stream, behind the fast pass, as one HIP graph launch). */
   int precision;
   /* the reference call's own parameters (appended fields; all-zero = the reference's values):
    * ransac_threshold_px: distance to the epipolar line in pixels, findFundamentalMat's 3rd argument.  Used when
@@ -277,8 +280,13 @@ int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d
  * a caller that shipped the device lists elsewhere before fetching (the gather above) ships them again when this number moved. */
 int urf_pm_sinkhorn_fallbacks(const urf_pm *h);
 /* guarded fast mode (precision 2), counters since build(): out[0] = pairs redone in the exact mode, out[1] = pairs
- * processed, out[2] = pairs flagged by the threshold margin, out[3] = by the runner-up margin (n <= 8 values written) */
+ * processed, out[2] / out[3] = redone pairs by cause (threshold margin / runner-up margin), out[4] = pairs flagged
+ * (n <= 8 values written) */
 int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n);
+/* guard words of the P pairs of the batch handed out by the last urf_pm_fetch / urf_match / urf_sg_infer of this handle:
+ * 0 = the pair's match set is the exact pipeline's; bit 0 = a best assignment within the margin of the threshold,
+ * bit 1 = within the margin of its runner-up */
+int urf_pm_near_tie_flags(urf_pm *h, int *flags, int P);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */

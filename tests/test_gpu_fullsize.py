@@ -105,12 +105,18 @@ def _same_keypoints(feat, ofeat, prec, where):
     return not diff
 
 
-def _same_matches(got, want, feats, ofeats, prec, clean, where):
-    """one pair's match list against the oracle's.  feats / ofeats: (first, second) frame features of the run / the oracle."""
+def _same_matches(got, want, feats, ofeats, prec, clean, where, flagged=0):
+    """one pair's match list against the oracle's.  feats / ofeats: (first, second) frame features of the run / the oracle.
+    flagged: the pair's guard word in the guarded fast mode -- a flagged pair is one whose decisive entries sit within the
+    fast pipeline's error of the threshold or of a runner-up (the reference's own arithmetic decides them by rounding noise):
+    it is reported, and may differ from the oracle in those few entries; an unflagged pair may not."""
     if prec == 0:
         assert [tuple(m) for m in got] == [tuple(m) for m in want], where
         return
     a, b = _coords(got, *feats), _coords(want, *ofeats)
+    if prec == 2 and flagged:
+        assert len(a ^ b) <= 6 and len(a & b) >= 0.99 * len(a | b), (where, flagged)
+        return
     if clean:
         assert a == b, where                                       # identical correspondences
         if want:
@@ -150,12 +156,15 @@ def test_device_resident_pipeline_vs_oracle(U, F, sp_blob, sg_blob, H, W, prec, 
     sp.sync()
     pm.match_device_async([slots[j].data_ptr() for j in range(8)], [slots[j + 1].data_ptr() for j in range(8)], True)
     got = pm.fetch(8)
+    flags = pm.near_tie_flags(8)
+    assert prec == 2 or not any(flags)
     feats = [F.slot_to_host(slots[j].data_ptr()) for j in range(9)]
     same_kp = [_same_keypoints(feats[j], ofeats[j], prec, j) for j in range(9)]
     for j in range(8):
         assert len(want[j]) > 300
         _same_matches(got[j], want[j], (feats[j], feats[j + 1]), (ofeats[j], ofeats[j + 1]), prec,
-                      same_kp[j] and same_kp[j + 1], j)
+                      same_kp[j] and same_kp[j + 1], j, flags[j])
+    assert sum(f != 0 for f in flags) <= 3            # the guard does not flag wholesale
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
@@ -183,7 +192,9 @@ def test_bench_step_loop_vs_oracle(U, F, sp_blob, sg_blob, H, W, prec):
     assert pipe.NB == 5
     pipe.prologue()
     steps = 7
-    fetched = dict(pipe.run(0, steps) + pipe.drain())
+    flags = {}
+    rec = lambda b, mt, res: flags.__setitem__(b, mt.near_tie_flags(B))      # noqa: E731
+    fetched = dict(pipe.run(0, steps, rec) + pipe.drain(rec))
     sp.sync()
     assert sorted(fetched) == list(range(steps))
     # the ring holds batches 3 .. 7 (7 = frames 16 .. 23 again) at this point: frames of ring slot k = frames [8k, 8k + 8)
@@ -203,9 +214,11 @@ def test_bench_step_loop_vs_oracle(U, F, sp_blob, sg_blob, H, W, prec):
             want = olists["ref"][g]
             gp = (g - 1) % n
             _same_matches(got, want, (ring_feats[gp], ring_feats[g]), (ofeats[gp], ofeats[g]), prec,
-                          same_kp[gp] and same_kp[g], ("batch", b, "pair", j))
+                          same_kp[gp] and same_kp[g], ("batch", b, "pair", j), flags[b][j])
             assert len(want) > 300 or g == 0             # g == 0: frames 39 -> 0 share no scene content
     assert sum(m.sinkhorn_fallbacks() for m in pms) == 0
+    nflag = sum(f != 0 for b in flags for f in flags[b])
+    assert (prec == 2 or nflag == 0) and nflag <= 0.2 * steps * B
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
@@ -247,12 +260,14 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
     frames, ofeats, olists = bench_stream_oracle(H, W)
     monkeypatch.setenv("URF_GUARD_SP_ULPS", "1e7")
     monkeypatch.setenv("URF_GUARD_SG_Z", "50")
+    monkeypatch.setenv("URF_GUARD_REDO_PAIRS", "1")
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=4, precision=2)
     assert sp.build(sp_blob)
     pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=3, precision=2)
     assert pm.build(sg_blob)
     monkeypatch.delenv("URF_GUARD_SP_ULPS")
     monkeypatch.delenv("URF_GUARD_SG_Z")
+    monkeypatch.delenv("URF_GUARD_REDO_PAIRS")
     d = torch.from_numpy(np.stack(frames[:4])).cuda()
     slots = torch.zeros((4, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
@@ -270,7 +285,7 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
     for j in range(3):
         assert got[j] == olists["ref"][j + 1], j
     st = pm.near_tie_reruns()
-    assert st["redone"] == 3 and st["pairs"] == 3
+    assert st["redone"] == 3 and st["pairs"] == 3 and st["flagged"] == 3 and all(pm.near_tie_flags(3))
     # host APIs: one frame, one pair
     assert np.array_equal(sp.infer(frames[5]), ofeats[5])
     assert pm.MatchingPoints(ofeats[4], ofeats[5], True) == olists["ref"][5]

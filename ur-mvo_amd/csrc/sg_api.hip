@@ -47,10 +47,11 @@ enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC
 }  // namespace urf
 using namespace urf;
 static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e) / sqrt(64), folded into the Q projection
-// guarded fast mode, matcher: margin (log domain) within which the fast mode's log-assignment may differ from the exact
-// mode's on entries that can become a match; measured maximum on both bench streams times a safety factor (DESIGN.md
+// guarded fast mode, matcher: margin (log domain) within which the log-assignment of the fast pipeline may differ from the exact
+// pipeline's on entries that can become a match: the fast matcher's own error (measured maximum 2.0e-4 on both bench streams)
+// plus what the fast SuperPoint's descriptor noise induces even in the exact matcher (2.4e-4), with 10 % on top (DESIGN.md
 // "Guarded fast mode", tools/gpu_margins.py)
-static const float kGuardSgZ = 1e-4f;
+static const float kGuardSgZ = 5e-4f;
 
 struct urf_pm {
   urf_sg_config cfg;
@@ -123,6 +124,13 @@ struct urf_pm {
   std::vector<RedoGraph> redo_graphs;
   bool redo_in_stream = false;     // the last batch's redo ran in the stream: nothing left to do at fetch time
   int graph_mode = -1;             // URF_GUARD_GRAPH: 1 (default) = captured graph, 0 = the same launches one by one
+  // what happens to a flagged pair: 0 (default) = it is reported (urf_pm_near_tie_flags, counters) -- the exact matcher on the
+  // same slots could still differ from the oracle there, because the fast SuperPoint's descriptor noise moves those entries as
+  // much as the fast matcher does; 1 (URF_GUARD_REDO_PAIRS=1) = it is also redone in the exact mode
+  int redo_pairs = 0;
+  int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
+  bool flags_recorded = false;
+  unsigned long long pairs_flagged = 0;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -330,6 +338,10 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     memset(h->h_gflags, 0, P * sizeof(int));
     const char *e = getenv("URF_GUARD_SG_Z");
     h->g_z = e ? (float)atof(e) : kGuardSgZ;
+    e = getenv("URF_GUARD_REDO_PAIRS");
+    h->redo_pairs = e ? (atoi(e) != 0) : 0;
+    URF_CHECK(P <= 64, "guarded fast mode: max_pairs %zu above 64", P);
+    memset(h->last_flags, 0, sizeof(h->last_flags));
   }
   if (dalloc(&h->rs_err, 4)) return -1;
   URF_HIP(hipHostMalloc((void **)&h->h_rs_err, 4 * sizeof(int), hipHostMallocDefault));
@@ -560,6 +572,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
   h->redo_in_stream = false;
+  h->flags_recorded = false;
   h->pairs_seen += (unsigned long long)P;
   return pm_tail(h, P, want_Z, ransac, prof, h->fast, false);
 }
@@ -619,7 +632,7 @@ static int pm_redo_launches(urf_pm *h, int P, bool want_Z, bool ransac, bool in_
 // learn whether a pair was flagged, and when none was (the usual case) its ~300 kernels find zero counts and exit at once.
 // They are captured once per (pairs, outlier stage) into a HIP graph: one launch call instead of 300.
 static int pm_guard_stream(urf_pm *h, int P, bool ransac) {
-  if (!h->guarded) return 0;
+  if (!h->guarded || !h->redo_pairs) return 0;
   if (h->graph_mode < 0) { const char *e = getenv("URF_GUARD_GRAPH"); h->graph_mode = e ? atoi(e) : 1; }
   h->redo_in_stream = true;
   if (h->graph_mode == 0) return pm_redo_launches(h, P, false, ransac, false);
@@ -648,6 +661,14 @@ static int pm_guard_stream(urf_pm *h, int P, bool ransac) {
 static int pm_guard_redo(urf_pm *h, bool in_place) {
   if (!h->guarded || h->last_P < 1) return 0;
   const int P = h->last_P;
+  if (!h->flags_recorded) {             // (a second call after a redo finds the pinned words cleared: keep the recorded ones)
+    for (int p = 0; p < P && p < 64; ++p) { h->last_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
+    h->flags_recorded = true;
+  }
+  if (!h->redo_pairs) {
+    for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
+    return 0;
+  }
   if (h->redo_in_stream) {
     for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
     return 0;
@@ -845,7 +866,14 @@ extern "C" int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n)
     URF_HIP(hipMemcpy(v, h->g_stats, sizeof(v), hipMemcpyDeviceToHost));   // written by redo passes only, which are synchronous
   }
   v[1] = h->pairs_seen;
+  v[4] = h->pairs_flagged;
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 0;
+}
+
+extern "C" int urf_pm_near_tie_flags(urf_pm *h, int *flags, int P) {
+  URF_CHECK(h && h->built && flags && P >= 1 && P <= 64, "urf_pm_near_tie_flags: bad argument");
+  for (int p = 0; p < P; ++p) flags[p] = h->guarded ? h->last_flags[p] : 0;
   return 0;
 }
 

@@ -185,7 +185,13 @@ class _PM:
         """guarded fast mode: dict(redone, pairs, threshold, runner_up) since build()"""
         v = (C.c_ulonglong * 8)()
         check(_lib.lib().urf_pm_near_tie_reruns(self._h, v, 8), "urf_pm_near_tie_reruns")
-        return dict(redone=int(v[0]), pairs=int(v[1]), threshold=int(v[2]), runner_up=int(v[3]))
+        return dict(redone=int(v[0]), pairs=int(v[1]), threshold=int(v[2]), runner_up=int(v[3]), flagged=int(v[4]))
+
+    def near_tie_flags(self, P=1):
+        """guard words of the pairs of the batch handed out last (0 = the pair's match set is the exact pipeline's)"""
+        f = (C.c_int * P)()
+        check(_lib.lib().urf_pm_near_tie_flags(self._h, f, P), "urf_pm_near_tie_flags")
+        return [int(f[p]) for p in range(P)]
 
     def stage_ms(self):
         ms = (C.c_float * 16)()
