@@ -211,6 +211,7 @@ def main():
     ring = pipe.ring
 
     sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
+    sp_stages = []
     n_matches = []
     kept = {}                      # batch index -> match lists (last steps), for the exact-mode cross-check
 
@@ -218,7 +219,7 @@ def main():
         age = (pipe.sp_calls - 1) - b          # SP(b) finished before match(b); how many SP calls ago?
         if 0 <= age <= 3:
             s = sp.stage_ms(age=age)
-            sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1])
+            sp_ms.append(sum(s[1:16])); conv1_ms.append(s[1]); sp_stages.append(s[:17])
         p = mt.stage_ms()
         pm_ms.append(sum(p[:7])); attn_ms.append(p[7]); lin_ms.append(p[1] + p[2] - p[7])
         sink_ms.append(p[4]); ransac_ms.append(p[6])
@@ -274,6 +275,9 @@ def main():
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, health)
+    # SuperPoint stage by stage inside the timed region (guarded mode: the exact pass over the redo list and the resolution of
+    # the top-k cuts run between "select" and "desc_norm" and are counted under "select")
+    sp_stage_insitu = ({n_: round(float(v_), 3) for n_, v_ in zip(F.SP_STAGES, np.mean(np.array(sp_stages), axis=0))} if sp_stages else None)
     insitu = {"superpoint": float(np.mean(sp_ms)) if sp_ms else None, "matching": float(np.mean(pm_ms)),
               "linear": float(np.mean(lin_ms)), "attention": float(np.mean(attn_ms))}
 
@@ -458,6 +462,7 @@ def main():
             "cpu_baseline": cpu,
             "exact_mode": exact,
             "stage_ms_per_step": stage_means,
+            "superpoint_stages_in_timed_region_ms": sp_stage_insitu,
             "matches_per_step": round(float(np.mean(n_matches)), 1),
             "matches_last_step_all_ranks_at_rank0": gathered_total,
             "sinkhorn_fallbacks": sum(h_["sinkhorn_fallbacks"] for h_ in per_rank),   # resident launches redone with the streaming kernels, all ranks
