@@ -193,6 +193,11 @@ int urf_pm_share_stream(urf_pm *h, urf_sp *sp);
 int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp);
 int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h);
 void *urf_sp_stream(urf_sp *h);
+/* urf_sp_stream: the stream a call READS its frames on (order producers -- an undistortion, a copy -- against it).
+ * urf_sp_result_stream: the stream on which a call's slots become FINAL (order consumers -- an all-gather, a copy of the
+ * headers -- against it).  The same stream except in the guarded fast mode, whose exact pass and descriptor tail run on a
+ * second stream so that the next call's fast pass overlaps them. */
+void *urf_sp_result_stream(urf_sp *h);
 /* the handles' HIP streams (hipStream_t), for callers that order their own work (an RCCL
  * all-gather of the slots, torch ops) against the library's with events instead of host syncs */
 void *urf_pm_stream(urf_pm *h);

@@ -224,10 +224,12 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
     d_in = d_und;
   }
   if (urf_sp_infer_device(h->sp, n, d_in, h->frows, h->fcols, slot_ptr(h, k, 0))) return -1;
-  // keypoint counts (slot headers) come down behind SP(b), long before the batch is collected
+  // keypoint counts (slot headers) come down behind SP(b) -- on the stream where the slots become final --, long before the
+  // batch is collected
+  hipStream_t rs = (hipStream_t)urf_sp_result_stream(h->sp);
   URF_HIP(hipMemcpy2DAsync(h->h_K + (size_t)k * h->B, sizeof(int), slot_ptr(h, k, 0), h->slot_bytes, sizeof(int), n,
-                           hipMemcpyDeviceToHost, st));
-  URF_HIP(hipEventRecord(h->ev_K[k], st));
+                           hipMemcpyDeviceToHost, rs));
+  URF_HIP(hipEventRecord(h->ev_K[k], rs));
   h->batch_first[k] = h->frames_seen;
   h->batch_n[k] = n;
   h->batch_id[k] = b;

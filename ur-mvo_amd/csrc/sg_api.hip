@@ -991,7 +991,7 @@ extern "C" int urf_pm_stage_ms(urf_pm *h, float *ms, int n) {
 extern "C" void *urf_sp_stream(urf_sp *h);
 extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
   URF_CHECK(h && h->built && sp, "urf_pm_share_stream: handles must be built");
-  void *st = urf_sp_stream(sp);
+  void *st = urf_sp_result_stream(sp);     // (the stream on which SuperPoint's slots become final)
   URF_CHECK(st, "urf_pm_share_stream: SuperPoint handle is not built");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipStreamSynchronize(h->st));
@@ -1012,9 +1012,10 @@ extern "C" int urf_pm_device_(urf_pm *h) { return h ? h->device : 0; }
 //   urf_sp_wait_for_sinkhorn(sp, pm): the SuperPoint stream waits until the matcher
 //     has reached the Sinkhorn stage of its last enqueued batch.
 extern "C" void *urf_sp_stream(urf_sp *h);
+extern "C" void *urf_sp_result_stream(urf_sp *h);
 extern "C" int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp) {
   URF_CHECK(h && h->built && sp, "urf_pm_wait_for_sp: bad handle");
-  hipStream_t ss = (hipStream_t)urf_sp_stream(sp);
+  hipStream_t ss = (hipStream_t)urf_sp_result_stream(sp);   // where the slots become final
   URF_CHECK(ss, "SuperPoint handle is not built");
   URF_HIP(hipSetDevice(h->device));
   if (ss == h->st) return 0;

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace urf {
@@ -100,11 +101,21 @@ struct urf_sp {
   // activations and selection scratch of a batch: A = the handle's arena; R = the arena of the frames the guarded fast mode
   // (precision 2) redoes in the exact mode
   SpArena A, R;
+  // guarded fast mode runs on two streams: the fast pass of batch b + 1 on `st` overlaps the exact pass / resolution / tail of
+  // batch b on `stx` (a latency-bound chain of small launches), so consecutive calls alternate between two fast arenas (A is
+  // the one of the call being enqueued, A2 the other) and two sets of guard buffers
+  SpArena A2;
+  hipStream_t stx = nullptr;         // where a call's slots become final; == st unless guarded
+  hipEvent_t ev_fast = nullptr;      // fast pass + redo list of the current call enqueued on st
+  hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of the call that last used arena A / A2 (by parity)
+  int parity = 0;
   uint8_t *d_img = nullptr, *d_usermask = nullptr;
   int cand_cap = 0;
   // guarded fast mode: guard words, threshold-band scratch, redo list (gate), images of the frames to redo, counters
   int *g_flags = nullptr, *g_band = nullptr, *g_gate = nullptr, *g_amb = nullptr, *g_nms = nullptr;
   uint8_t *g_img = nullptr;
+  int *g2_flags = nullptr, *g2_band = nullptr, *g2_gate = nullptr, *g2_amb = nullptr, *g2_nms = nullptr;   // the other set
+  uint8_t *g2_img = nullptr;
   unsigned long long *g_stats = nullptr;
   float g_delta = 0.0f, g_ulps = 0.0f;
   double *d_feat = nullptr;
@@ -321,12 +332,19 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     // guarded fast mode: a second arena for the frames redone in the exact mode (every frame of a batch can be), the guard
     // words and the redo list.  Error model of a fast-mode score (sp_kernels.hip): measured by tools/gpu_margins.py on
     // both bench streams (DESIGN.md "Guarded fast mode"), overridable for experiments.
-    if (arena(h->R, false)) return -1;
+    if (arena(h->R, false) || arena(h->A2, true)) return -1;
     URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
     if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) ||
         dalloc(&h->g_amb, B * (1 + kAmbMax)) || dalloc(&h->g_nms, B))
       return -1;
-    if (dalloc(&h->g_img, B * H * W)) return -1;
+    if (dalloc(&h->g2_flags, B) || dalloc(&h->g2_band, B) || dalloc(&h->g2_gate, kGateInts) || dalloc(&h->g2_amb, B * (1 + kAmbMax)) ||
+        dalloc(&h->g2_nms, B))
+      return -1;
+    if (dalloc(&h->g_img, B * H * W) || dalloc(&h->g2_img, B * H * W)) return -1;
+    URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
+    URF_HIP(hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming));
+    URF_HIP(hipEventCreateWithFlags(&h->ev_tail[0], hipEventDisableTiming));
+    URF_HIP(hipEventCreateWithFlags(&h->ev_tail[1], hipEventDisableTiming));
     const char *e;
     h->g_delta = (e = getenv("URF_GUARD_SP_DELTA")) ? (float)atof(e) : kGuardSpDelta;
     h->g_ulps = (e = getenv("URF_GUARD_SP_ULPS")) ? (float)atof(e) : kGuardSpUlps;
@@ -339,6 +357,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   for (int k = 0; k < 4; ++k)
     for (int i = 0; i <= ST_COUNT; ++i) URF_HIP(hipEventCreate(&h->evs[k][i]));
   h->ev = h->evs[0];
+  if (!h->stx) h->stx = h->st;
   // the arena was zeroed with hipMemset on the null stream, which the handle's non-blocking stream does not wait
   // for: without this a first call could run before (or while) its buffers are being cleared
   URF_HIP(hipDeviceSynchronize());
@@ -389,13 +408,22 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
+    if (h->stx != h->st) {
+      (void)hipStreamSynchronize(h->stx);
+      (void)hipStreamDestroy(h->stx);
+      (void)hipEventDestroy(h->ev_fast); (void)hipEventDestroy(h->ev_tail[0]); (void)hipEventDestroy(h->ev_tail[1]);
+    }
     void *bufs[] = {h->d_wh, h->d_wl, h->d_wts, h->d_img, h->d_usermask, h->A.a1, h->A.a2a, h->A.a2b, h->A.a3a, h->A.a3b, h->A.a4a, h->A.a4b, h->A.apd,
                     h->A.logits, h->A.ddb, h->A.desc, h->A.heat, h->A.scores, h->A.ss, h->A.mask, h->A.supp, h->A.counts,
                     h->A.cand_score, h->A.cand_idx, h->A.cand_n, h->A.kp_score, h->A.kp_idx, h->A.kp_n, h->d_feat, h->d_slots};
     for (void *p : bufs) (void)hipFree(p);
     void *rbufs[] = {h->R.a1, h->R.a2a, h->R.a2b, h->R.a3a, h->R.a3b, h->R.a4a, h->R.a4b, h->R.apd, h->R.logits, h->R.ddb, h->R.desc,
                      h->R.heat, h->R.scores, h->R.ss, h->R.mask, h->R.supp, h->R.counts, h->R.cand_score, h->R.cand_idx, h->R.cand_n,
-                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb, h->g_nms};
+                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb, h->g_nms,
+                     h->g2_flags, h->g2_band, h->g2_gate, h->g2_img, h->g2_amb, h->g2_nms,
+                     h->A2.a1, h->A2.a2a, h->A2.a2b, h->A2.a3a, h->A2.a3b, h->A2.a4a, h->A2.a4b, h->A2.apd, h->A2.logits, h->A2.ddb,
+                     h->A2.desc, h->A2.heat, h->A2.scores, h->A2.ss, h->A2.mask, h->A2.supp, h->A2.counts, h->A2.cand_score, h->A2.cand_idx,
+                     h->A2.cand_n, h->A2.kp_score, h->A2.kp_idx, h->A2.kp_n};
     for (void *p : rbufs) (void)hipFree(p);
     (void)hipHostFree(h->h_img);
     (void)hipHostFree(h->h_feat);
@@ -409,9 +437,8 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
 
 // the eight 3x3 convolutions in the fast precision mode (h2conv.hip).  Each fp32
 // activation buffer of N floats is reused as two f16 planes of N halfs.
-static int sp_convs_fast(urf_sp *h, const SpArena &A, int B, const uint8_t *d_imgs, int H, int W) {
+static int sp_convs_fast(urf_sp *h, const SpArena &A, int B, const uint8_t *d_imgs, int H, int W, hipStream_t st) {
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
-  hipStream_t st = h->st;
   const float *wt = h->d_wts;
   const bool prof = urf::g_profiling != 0;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
@@ -462,10 +489,9 @@ static int sp_convs_fast(urf_sp *h, const SpArena &A, int B, const uint8_t *d_im
 // part: 1 = up to the softmax, 2 = NMS and selection, 4 = descriptor normalisation and sampling (bit mask; 7 = everything).
 static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const uint8_t *d_imgs, int H, int W,
                           const uint8_t *d_mask, double *d_feat, float *d_slots, const int *gate, const SpGuard &guard,
-                          int *kp_n_out, bool timed, int part = 7) {
+                          int *kp_n_out, bool timed, int part, hipStream_t st) {
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
   const int Hs = H8 * 8, Ws = W8 * 8;
-  hipStream_t st = h->st;
   const float *wt = h->d_wts;
   const bool prof = urf::g_profiling != 0 && timed;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
@@ -486,7 +512,7 @@ static int sp_pipeline_on(urf_sp *h, const SpArena &A, bool fast, int B, const u
   };
   if (part & 1) {
   if (fast) {
-    if (sp_convs_fast(h, A, B, d_imgs, H, W)) return -1;
+    if (sp_convs_fast(h, A, B, d_imgs, H, W, st)) return -1;
   } else {
   mark(ST_CONV1);
   {  // conv1a (fused, VALU) + conv1b + relu + pool
@@ -588,19 +614,32 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
                        float *d_slots) {
   SpGuard g = {};
   h->lastH = H; h->lastW = W; h->lastB = B;
-  if (h->precision != 2) return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true);
+  if (h->precision != 2)
+    return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 7, h->st);
+  // this call's fast arena and guard buffers: the other set is still being read by the previous call's chain on stx
+  std::swap(h->A, h->A2);
+  std::swap(h->g_flags, h->g2_flags); std::swap(h->g_band, h->g2_band); std::swap(h->g_gate, h->g2_gate);
+  std::swap(h->g_amb, h->g2_amb); std::swap(h->g_nms, h->g2_nms); std::swap(h->g_img, h->g2_img);
+  h->parity ^= 1;
+  hipStream_t st = h->st, sx = h->stx;
+  URF_HIP(hipStreamWaitEvent(st, h->ev_tail[h->parity], 0));     // the call two back has left this set (never recorded: no wait)
   const int Hs = H / 8 * 8, Ws = W / 8 * 8;
   g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.nms_hi = h->g_nms; g.delta = h->g_delta; g.ulps = h->g_ulps;
   SpGuard off = {};
-  URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), h->st));
-  URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), h->st));
-  URF_HIP(hipMemsetAsync(h->g_nms, 0, B * sizeof(int), h->st));
-  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3)) return -1;
-  if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, h->st)) return -1;
-  if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, nullptr, false, 3)) return -1;
-  if (launch_guard_resolve(h->g_gate, h->g_amb, h->R.heat, Hs * Ws, h->A.kp_score, h->A.kp_idx, h->A.kp_n, B, h->st)) return -1;
-  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, off, nullptr, true, 4)) return -1;
-  return sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false, 4);
+  URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), st));
+  URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), st));
+  URF_HIP(hipMemsetAsync(h->g_nms, 0, B * sizeof(int), st));
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3, st)) return -1;
+  if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, st)) return -1;
+  URF_HIP(hipEventRecord(h->ev_fast, st));
+  URF_HIP(hipStreamWaitEvent(sx, h->ev_fast, 0));
+  // from here on `stx`: the next call's fast pass may start on `st` right away
+  if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, nullptr, false, 3, sx)) return -1;
+  if (launch_guard_resolve(h->g_gate, h->g_amb, h->R.heat, Hs * Ws, h->A.kp_score, h->A.kp_idx, h->A.kp_n, B, sx)) return -1;
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, off, nullptr, true, 4, sx)) return -1;
+  if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false, 4, sx)) return -1;
+  URF_HIP(hipEventRecord(h->ev_tail[h->parity], sx));
+  return 0;
 }
 
 static int sp_check_dims(urf_sp *h, int B, int rows, int cols) {
@@ -632,10 +671,10 @@ extern "C" int urf_sp_infer_batch(urf_sp *h, int B, const uint8_t *const *imgs, 
   if (prof) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   URF_HIP(hipMemcpyAsync(h->d_img, h->h_img, B * fsz, hipMemcpyHostToDevice, h->st));
   if (sp_pipeline(h, B, h->d_img, rows, cols, nullptr, h->d_feat, h->d_slots)) return -1;
-  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, B * sizeof(int), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)B * kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  if (prof) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
-  URF_HIP(hipStreamSynchronize(h->st));
+  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, B * sizeof(int), hipMemcpyDeviceToHost, h->stx));
+  URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)B * kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->stx));
+  if (prof) (void)hipEventRecord(h->ev[ST_COUNT], h->stx);
+  URF_HIP(hipStreamSynchronize(h->stx));
   sp_collect_times(h);
   for (int b = 0; b < B; ++b) URF_CHECK(h->h_n[b] <= cap, "feature buffer too small: K=%d > cap=%d", h->h_n[b], cap);
   for (int b = 0; b < B; ++b) {
@@ -663,10 +702,10 @@ extern "C" int urf_sp_infer(urf_sp *h, const uint8_t *img, int rows, int cols, s
   sp_flip_events(h);
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   if (sp_pipeline(h, 1, h->d_img, rows, cols, h->d_usermask, h->d_feat, h->d_slots)) return -1;
-  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, sizeof(int), hipMemcpyDeviceToHost, h->st));
-  URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
-  URF_HIP(hipStreamSynchronize(h->st));
+  URF_HIP(hipMemcpyAsync(h->h_n, h->A.kp_n, sizeof(int), hipMemcpyDeviceToHost, h->stx));
+  URF_HIP(hipMemcpyAsync(h->h_feat, h->d_feat, (size_t)kCap * 259 * sizeof(double), hipMemcpyDeviceToHost, h->stx));
+  if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->stx);
+  URF_HIP(hipStreamSynchronize(h->stx));
   sp_collect_times(h);
   URF_CHECK(h->h_n[0] <= cap, "feature buffer too small: K=%d > cap=%d", h->h_n[0], cap);
   *K = h->h_n[0];
@@ -681,7 +720,7 @@ extern "C" int urf_sp_infer_device(urf_sp *h, int B, const uint8_t *d_imgs, int 
   sp_flip_events(h);
   if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_UPLOAD], h->st);
   if (sp_pipeline(h, B, d_imgs, rows, cols, nullptr, nullptr, (float *)d_slots)) return -1;
-  if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->st);
+  if (urf::g_profiling) (void)hipEventRecord(h->ev[ST_COUNT], h->stx);
   return 0;
 }
 
@@ -689,6 +728,7 @@ extern "C" int urf_sp_sync(urf_sp *h) {
   URF_CHECK(h && h->built, "SuperPoint handle is not built");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipStreamSynchronize(h->st));
+  if (h->stx != h->st) URF_HIP(hipStreamSynchronize(h->stx));
   sp_collect_times(h);
   return 0;
 }
@@ -743,6 +783,7 @@ extern "C" int urf_sp_debug_tensor(urf_sp *h, int which, float *out, size_t n) {
     default: URF_CHECK(false, "unknown debug tensor %d", which);
   }
   URF_HIP(hipStreamSynchronize(h->st));
+  if (h->stx != h->st) URF_HIP(hipStreamSynchronize(h->stx));
   URF_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -767,3 +808,4 @@ extern "C" int urf_sp_stage_ms(urf_sp *h, float *ms, int n) {
 }
 
 extern "C" void *urf_sp_stream(urf_sp *h) { return h && h->built ? (void *)h->st : nullptr; }
+extern "C" void *urf_sp_result_stream(urf_sp *h) { return h && h->built ? (void *)h->stx : nullptr; }

@@ -77,6 +77,10 @@ class SuperPoint:
         """the handle's hipStream_t (for torch.cuda.ExternalStream / event ordering)"""
         return _lib.lib().urf_sp_stream(self._h)
 
+    def result_stream_ptr(self):
+        """the hipStream_t on which a call's slots become final (== stream_ptr() except in the guarded fast mode)"""
+        return _lib.lib().urf_sp_result_stream(self._h)
+
     def infer(self, image, mask=None):
         """infer(image, mask, features) -> features [K,259] (or None on failure)."""
         image = np.asarray(image)

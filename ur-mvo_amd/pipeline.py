@@ -59,7 +59,7 @@ class SlotRingPipeline:
                 m.share_stream(sp)
         if comm is not None:
             M = len(self.pms)
-            self.sp_ext = torch.cuda.ExternalStream(sp.stream_ptr(), device=device)
+            self.sp_ext = torch.cuda.ExternalStream(sp.result_stream_ptr(), device=device)    # where SuperPoint's slots become final
             self.pm_ext = [torch.cuda.ExternalStream(m.stream_ptr(), device=device) for m in self.pms]
             self.cs = torch.cuda.Stream(device=device)
             self.gathered_buf = torch.zeros((self.NB, self.world * self.B, sf), dtype=torch.float32, device=device)
