@@ -14,14 +14,16 @@ U = load_pkg(); F, synth = U.frontend, U.synth
 print(U._lib.lib().urf_build_info().decode())
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 t0 = int(sys.argv[2]) if len(sys.argv) > 2 else 18
-H, W = 480, 640
-frames = synth.shift_stream(seed, 21, H, W)
+nfr = int(sys.argv[3]) if len(sys.argv) > 3 else 21
+H, W = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (480, 640)
+t1 = int(sys.argv[6]) if len(sys.argv) > 6 else t0 + 1
+frames = synth.shift_stream(seed, nfr, H, W)
 spb, sgb = synth.pack_sp(synth.sp_weights(0)), synth.pack_sg(synth.sg_weights(0))
 feats = {}
 for prec in (0, 1, 2):
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, precision=prec)
     assert sp.build(spb)
-    feats[prec] = [sp.infer(frames[t0]), sp.infer(frames[t0 + 1])]
+    feats[prec] = [sp.infer(frames[t0]), sp.infer(frames[t1])]
     if prec == 2:
         print("SuperPoint guard counters", sp.near_tie_reruns())
 for prec in (1, 2):
@@ -47,7 +49,9 @@ for sp_prec in (0, 2):
         lst = pm.MatchingPoints(f0, f1, True)
         res[(sp_prec, sg_prec)] = (coords(i0, f0, f1), m0, {(f0[q, 1], f0[q, 2], f1[t, 1], f1[t, 2]) for q, t, _ in lst}, Z, f0, f1)
         print(f"SuperPoint {sp_prec} / matcher {sg_prec}: {int((i0 >= 0).sum())} matches before, {len(lst)} after the outlier stage;"
-              f" guard counters {sg.near_tie_reruns()} {pm.near_tie_reruns()}")
+              f" guard counters {sg.near_tie_reruns()} {pm.near_tie_reruns()} flags {pm.near_tie_flags(1)}")
+        near = np.sort(np.abs(np.exp(Z[:-1, :-1].max(1).astype(np.float64)) - 0.5))[:4]
+        print("      closest row maxima to the threshold (probability):", near)
 ref = res[(0, 0)]
 for key, (c, m0, after, Z, f0, f1) in res.items():
     d = set(c) ^ set(ref[0])
