@@ -341,7 +341,8 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
         dalloc(&h->g2_nms, B))
       return -1;
     if (dalloc(&h->g_img, B * H * W) || dalloc(&h->g2_img, B * H * W)) return -1;
-    URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
+    // URF_SP_TWO_STREAMS=0 (A/B runs): the exact pass stays in the handle's one stream
+    if (const char *e2 = getenv("URF_SP_TWO_STREAMS"); !e2 || atoi(e2) != 0) URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
     URF_HIP(hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[0], hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[1], hipEventDisableTiming));
@@ -411,8 +412,8 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     if (h->stx != h->st) {
       (void)hipStreamSynchronize(h->stx);
       (void)hipStreamDestroy(h->stx);
-      (void)hipEventDestroy(h->ev_fast); (void)hipEventDestroy(h->ev_tail[0]); (void)hipEventDestroy(h->ev_tail[1]);
     }
+    if (h->ev_fast) { (void)hipEventDestroy(h->ev_fast); (void)hipEventDestroy(h->ev_tail[0]); (void)hipEventDestroy(h->ev_tail[1]); }
     void *bufs[] = {h->d_wh, h->d_wl, h->d_wts, h->d_img, h->d_usermask, h->A.a1, h->A.a2a, h->A.a2b, h->A.a3a, h->A.a3b, h->A.a4a, h->A.a4b, h->A.apd,
                     h->A.logits, h->A.ddb, h->A.desc, h->A.heat, h->A.scores, h->A.ss, h->A.mask, h->A.supp, h->A.counts,
                     h->A.cand_score, h->A.cand_idx, h->A.cand_n, h->A.kp_score, h->A.kp_idx, h->A.kp_n, h->d_feat, h->d_slots};
