@@ -332,17 +332,22 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     // guarded fast mode: a second arena for the frames redone in the exact mode (every frame of a batch can be), the guard
     // words and the redo list.  Error model of a fast-mode score (sp_kernels.hip): measured by tools/gpu_margins.py on
     // both bench streams (DESIGN.md "Guarded fast mode"), overridable for experiments.
-    if (arena(h->R, false) || arena(h->A2, true)) return -1;
+    const char *e2s = getenv("URF_SP_TWO_STREAMS");
+    const bool two_streams = e2s && atoi(e2s) != 0;
+    if (arena(h->R, false) || (two_streams && arena(h->A2, true))) return -1;
     URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
     if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) ||
         dalloc(&h->g_amb, B * (1 + kAmbMax)) || dalloc(&h->g_nms, B))
       return -1;
-    if (dalloc(&h->g2_flags, B) || dalloc(&h->g2_band, B) || dalloc(&h->g2_gate, kGateInts) || dalloc(&h->g2_amb, B * (1 + kAmbMax)) ||
-        dalloc(&h->g2_nms, B))
+    if (two_streams && (dalloc(&h->g2_flags, B) || dalloc(&h->g2_band, B) || dalloc(&h->g2_gate, kGateInts) ||
+                        dalloc(&h->g2_amb, B * (1 + kAmbMax)) || dalloc(&h->g2_nms, B) || dalloc(&h->g2_img, B * H * W)))
       return -1;
-    if (dalloc(&h->g_img, B * H * W) || dalloc(&h->g2_img, B * H * W)) return -1;
-    // URF_SP_TWO_STREAMS=0 (A/B runs): the exact pass stays in the handle's one stream
-    if (const char *e2 = getenv("URF_SP_TWO_STREAMS"); !e2 || atoi(e2) != 0) URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
+    if (dalloc(&h->g_img, B * H * W)) return -1;
+    // URF_SP_TWO_STREAMS=1 (A/B runs; measured and NOT the default): the exact pass, the cut resolution and the descriptor tail on
+    // a second stream beside the next call's fast pass, with two alternating fast arenas.  Same box, 640x480, frames/s: unguarded
+    // 1900-1940; guarded on one stream 1757; on two streams 1508 -- and 1619 even with nothing flagged (1921 on one stream): the
+    // second arena set and the cross-stream events cost more than the chain's latency
+    if (const char *e2 = getenv("URF_SP_TWO_STREAMS"); e2 && atoi(e2) != 0) URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
     URF_HIP(hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[0], hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[1], hipEventDisableTiming));
@@ -617,13 +622,16 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   h->lastH = H; h->lastW = W; h->lastB = B;
   if (h->precision != 2)
     return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 7, h->st);
-  // this call's fast arena and guard buffers: the other set is still being read by the previous call's chain on stx
-  std::swap(h->A, h->A2);
-  std::swap(h->g_flags, h->g2_flags); std::swap(h->g_band, h->g2_band); std::swap(h->g_gate, h->g2_gate);
-  std::swap(h->g_amb, h->g2_amb); std::swap(h->g_nms, h->g2_nms); std::swap(h->g_img, h->g2_img);
-  h->parity ^= 1;
   hipStream_t st = h->st, sx = h->stx;
-  URF_HIP(hipStreamWaitEvent(st, h->ev_tail[h->parity], 0));     // the call two back has left this set (never recorded: no wait)
+  const bool two = sx != st;
+  if (two) {
+    // this call's fast arena and guard buffers: the other set is still being read by the previous call's chain on stx
+    std::swap(h->A, h->A2);
+    std::swap(h->g_flags, h->g2_flags); std::swap(h->g_band, h->g2_band); std::swap(h->g_gate, h->g2_gate);
+    std::swap(h->g_amb, h->g2_amb); std::swap(h->g_nms, h->g2_nms); std::swap(h->g_img, h->g2_img);
+    h->parity ^= 1;
+    URF_HIP(hipStreamWaitEvent(st, h->ev_tail[h->parity], 0));   // the call two back has left this set (never recorded: no wait)
+  }
   const int Hs = H / 8 * 8, Ws = W / 8 * 8;
   g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.nms_hi = h->g_nms; g.delta = h->g_delta; g.ulps = h->g_ulps;
   SpGuard off = {};
@@ -632,14 +640,16 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   URF_HIP(hipMemsetAsync(h->g_nms, 0, B * sizeof(int), st));
   if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3, st)) return -1;
   if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, st)) return -1;
-  URF_HIP(hipEventRecord(h->ev_fast, st));
-  URF_HIP(hipStreamWaitEvent(sx, h->ev_fast, 0));
-  // from here on `stx`: the next call's fast pass may start on `st` right away
+  if (two) {
+    URF_HIP(hipEventRecord(h->ev_fast, st));
+    URF_HIP(hipStreamWaitEvent(sx, h->ev_fast, 0));
+  }
+  // from here on `stx` (two-stream variant: the next call's fast pass may start on `st` right away)
   if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, nullptr, false, 3, sx)) return -1;
   if (launch_guard_resolve(h->g_gate, h->g_amb, h->R.heat, Hs * Ws, h->A.kp_score, h->A.kp_idx, h->A.kp_n, B, sx)) return -1;
   if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, off, nullptr, true, 4, sx)) return -1;
   if (sp_pipeline_on(h, h->R, false, B, h->g_img, H, W, d_mask, d_feat, d_slots, h->g_gate, off, h->A.kp_n, false, 4, sx)) return -1;
-  URF_HIP(hipEventRecord(h->ev_tail[h->parity], sx));
+  if (two) URF_HIP(hipEventRecord(h->ev_tail[h->parity], sx));
   return 0;
 }
 
