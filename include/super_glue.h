@@ -20,9 +20,9 @@
 #ifndef URF_SHIM_PRECISION_DEFINED
 #define URF_SHIM_PRECISION_DEFINED
 #include <cstdlib>
-inline int urf_shim_precision() {   // URF_PRECISION = 0 (exact, default) | 1 (fast) | 2 (guarded fast); see super_point.h
+inline int urf_shim_precision() {   // URF_PRECISION = 2 (guarded fast, default) | 0 (exact) | 1 (fast); see super_point.h
   const char *e = std::getenv("URF_PRECISION");
-  return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
+  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
 }
 #endif
 

@@ -23,15 +23,16 @@
 #include "urf.h"
 
 // Precision mode of the handles the shims create (the reference's config structs have no such field):
-// environment variable URF_PRECISION = 0 (exact fp32, bit-identical to the oracle; default), 1 (fast:
-// split-f16 matrix-core path, fp32-equivalent accuracy, ~3x the throughput) or 2 (guarded fast: as 1,
-// with every frame / pair whose discrete decisions sit within the fast mode's error redone in the exact mode).
+// environment variable URF_PRECISION = 2 (the default: guarded fast -- the split-f16 matrix-core path at ~3x the exact mode's
+// throughput, with every decision of the SuperPoint tail that sits within its error resolved in exact arithmetic on the device,
+// so the keypoint set of every frame is the exact mode's, and near-tied pairs flagged), 0 (exact fp32:
+// every tensor bit-identical to the CPU oracle) or 1 (fast without the guard).
 #ifndef URF_SHIM_PRECISION_DEFINED
 #define URF_SHIM_PRECISION_DEFINED
 #include <cstdlib>
 inline int urf_shim_precision() {
   const char *e = std::getenv("URF_PRECISION");
-  return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
+  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
 }
 #endif
 

@@ -314,13 +314,19 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     fr[0].tofile(f0p)
     fr[1].tofile(f1p)
     vis = str(tmp_path / "keypoints")
-    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W), vis], text=True).strip().split("\n")
-    # the shims pick the precision mode from URF_PRECISION: the fast handles give the same lists here
-    fast = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True,
-                                   env=dict(os.environ, URF_PRECISION="1")).strip().split("\n")
-    # same counts; keypoint INDICES may differ where near-tied scores swap places in the score-sorted list
-    same = sum(a.split()[:2] == b.split()[:2] for a, b in zip(fast[1:], out[1:]))
-    assert fast[0] == out[0] and same >= 0.95 * (len(out) - 1)
+    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W), vis], text=True,
+                                  env=dict(os.environ, URF_PRECISION="0")).strip().split("\n")
+    # the shims pick the precision mode from URF_PRECISION (default: 2, the guarded fast mode): the fast handles give the same
+    # lists here
+    for mode in ("1", None):
+        env = dict(os.environ)
+        env.pop("URF_PRECISION", None)
+        if mode:
+            env["URF_PRECISION"] = mode
+        fast = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True, env=env).strip().split("\n")
+        # same counts; keypoint INDICES may differ where near-tied scores swap places in the score-sorted list
+        same = sum(a.split()[:2] == b.split()[:2] for a, b in zip(fast[1:], out[1:]))
+        assert fast[0] == out[0] and same >= 0.95 * (len(out) - 1)
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=400, engine_file=spw), max_height=H, max_width=W)
     assert sp.build()                                     # engine_file path (deserialize_engine)
     f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])
@@ -378,7 +384,8 @@ def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
                                        "--repeats", "2", "--no-cpu-baseline", "--no-exact-check"], env=env, text=True, stderr=subprocess.DEVNULL)
         res.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
     assert res[0]["matches_per_step"] == res[1]["matches_per_step"] > 8 * 600
-    assert res[1]["n_gpus"] == 1 and res[1]["value"] > 0.5 * res[0]["value"]
+    # (a 4-step region: the three RCCL calls of a step and the end-of-region gathers weigh far more here than in a real run)
+    assert res[1]["n_gpus"] == 1 and res[1]["value"] > 0.3 * res[0]["value"]
     # the match lists also travelled through the gather to rank 0 (urf_comm_gather on the matcher stream)
     assert res[0]["matches_last_step_all_ranks_at_rank0"] is None and res[1]["matches_last_step_all_ranks_at_rank0"] > 8 * 600
 
