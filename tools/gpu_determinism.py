@@ -14,7 +14,7 @@ from __graft_entry__ import load_pkg  # noqa: E402
 U = load_pkg(); F, synth, P = U.frontend, U.synth, U.pipeline
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 spb, sgb = synth.pack_sp(synth.sp_weights(0)), synth.pack_sg(synth.sg_weights(0))
-print(U._lib.lib().urf_build_info().decode(), "URF_SP_TWO_STREAMS =", os.environ.get("URF_SP_TWO_STREAMS", "(unset: on)"))
+print(U._lib.lib().urf_build_info().decode(), "URF_SP_TWO_STREAMS =", os.environ.get("URF_SP_TWO_STREAMS", "(unset: off)"))
 for (H, W) in ((376, 1241), (480, 640)):
     frames = synth.shift_stream(100, 40, H, W)
     dev = torch.device("cuda", 0)

@@ -16,6 +16,7 @@
 // wave hit 32 distinct banks), weights [64][80] f32 (stride 80 likewise).
 // Accumulation order: acc=bias; for 64-ch chunk; for tap; for c.
 #include "urf_common.h"
+#include <stdlib.h>
 
 namespace urf {
 
@@ -25,7 +26,10 @@ constexpr int TH = 8, TW = 16;
 constexpr int IN_STRIDE = 66;
 constexpr int W_STRIDE = 80;
 
-template <int TAPS, bool POOL, bool FUSE1A>
+// MB = 16-channel output blocks per workgroup: 4 (the tile above), or 1 for the redo pass of the guarded fast mode, whose
+// launches hold a few tiles each and are bound by the length of one wave's MFMA chain -- a quarter of the channels per
+// workgroup, four times the workgroups, the weights fetched two taps ahead.  The chain of every output is the same.
+template <int TAPS, bool POOL, bool FUSE1A, int MB = 4>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PH = (TAPS == 9) ? TH + 2 : TH;
@@ -39,7 +43,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   const int px = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
   if (a.gate && b >= a.gate[0]) return;
-  const int cout_base = blockIdx.y * 64;
+  const int cout_base = blockIdx.y * (16 * MB);
 
   int y0 = 0, x0 = 0;
   if (TAPS == 9) {
@@ -69,9 +73,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     }
   }
 
-  f32x4 acc[4][2];
+  f32x4 acc[MB][2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < MB; ++m) {
     f32x4 bv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -96,15 +100,15 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   // ---- register prefetch (issue early, commit to LDS late): weights of the next
   // (chunk, tap) stage and, for TAPS==1, the next chunk's input rows fly while
   // the MFMAs of the current stage run.
-  f32x4 wpf[4];
-  auto issue_w = [&](int ch, int tap) {
+  f32x4 wpf[MB], wpf2[1];   // (wpf2: the second request in flight, MB == 1)
+  auto issue_w = [&](int ch, int tap, f32x4 *wr) {
     const int c0 = ch * 64;
     const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
     const float *wsrc = a.w + ((size_t)tap * a.Cin + c0) * a.Cout;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < MB; ++u) {
       const int i = tid + 256 * u;
-      const int k = i >> 4, j = i & 15;
+      const int k = i / (4 * MB), j = i % (4 * MB);
       const int co = cout_base + 4 * j;
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
       if (k < kc) {
@@ -116,14 +120,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
           for (int r = 0; r < 4; ++r) v[r] = (co + r < a.Cout) ? sp[r] : 0.0f;
         }
       }
-      wpf[u] = v;
+      wr[u] = v;
     }
   };
-  auto commit_w = [&]() {
+  auto commit_w = [&](const f32x4 *wr) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < MB; ++u) {
       const int i = tid + 256 * u;
-      *(f32x4 *)(w_tile + (i >> 4) * W_STRIDE + 4 * (i & 15)) = wpf[u];
+      *(f32x4 *)(w_tile + (i / (4 * MB)) * W_STRIDE + 4 * (i % (4 * MB))) = wr[u];
     }
   };
   f32x4 ipf[8];  // TAPS==1 only: 128 rows x (kc/4) float4
@@ -168,11 +172,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     }
   };
 
-  issue_w(0, 0);
-  if (TAPS == 1) issue_in(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
+  auto stage_input = [&](int ch) {
     const int c0 = ch * 64;
     const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
+    (void)c0; (void)kc;
     if (FUSE1A) {
       // ---- fused conv1a: u8 patch -> f32 -> 3x3 conv (VALU fma chain) -> relu
       const uint8_t *img = (const uint8_t *)a.in + (size_t)b * a.in_bstride;
@@ -289,17 +292,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
       commit_in(ch);
     }
 
-    for (int tap = 0; tap < TAPS; ++tap) {
-      commit_w();
-      __syncthreads();  // in_tile + w_tile of this stage visible
-      {                 // prefetch the next stage
-        const bool last_tap = (tap + 1 == TAPS);
-        if (!last_tap) issue_w(ch, tap + 1);
-        else if (ch + 1 < nchunks) {
-          issue_w(ch + 1, 0);
-          if (TAPS == 1) issue_in(ch + 1);
-        }
-      }
+  };
+  auto compute_tap = [&](int tap, int kc) {
       const int toff = (TAPS == 9) ? ((tap / 3) * PW + (tap % 3)) * IN_STRIDE : 0;
       const float *bp0 = in_tile + bpix[0] + toff;
       const float *bp1 = in_tile + bpix[1] + toff;
@@ -307,27 +301,22 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
 #define URF_KSTEP(k)                                                                              \
   {                                                                                               \
     const float b0 = bp0[k], b1 = bp1[k];                                                         \
-    const float a0 = ap[(k) * W_STRIDE], a1 = ap[(k) * W_STRIDE + 16], a2 = ap[(k) * W_STRIDE + 32], \
-                a3 = ap[(k) * W_STRIDE + 48];                                                     \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);                 \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);                 \
-    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, acc[2][0], 0, 0, 0);                 \
-    acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b0, acc[3][0], 0, 0, 0);                 \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);                 \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);                 \
-    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, acc[2][1], 0, 0, 0);                 \
-    acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b1, acc[3][1], 0, 0, 0);                 \
+    float am[MB];                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m) am[m] = ap[(k) * W_STRIDE + 16 * m];           \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m)                                                \
+      acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], b0, acc[m][0], 0, 0, 0);            \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m)                                                \
+      acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], b1, acc[m][1], 0, 0, 0);            \
   }
       if (kc == 64) {
         // fast path: fully unrolled and software-pipelined by hand -- the LDS
         // operand reads of k-step k+1 are issued before the 8 MFMAs of k-step k
         // (two register sets), so their latency hides behind 256 MFMA cycles.
-        float pa[2][4], pb[2][2];
+        float pa[2][MB], pb[2][2];
 #define URF_LOAD(set, k)                                                               \
   {                                                                                    \
     pb[set][0] = bp0[k]; pb[set][1] = bp1[k];                                          \
-    pa[set][0] = ap[(k) * W_STRIDE]; pa[set][1] = ap[(k) * W_STRIDE + 16];             \
-    pa[set][2] = ap[(k) * W_STRIDE + 32]; pa[set][3] = ap[(k) * W_STRIDE + 48];        \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m) pa[set][m] = ap[(k) * W_STRIDE + 16 * m]; \
   }
         URF_LOAD(0, 0)
 #pragma unroll
@@ -338,7 +327,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MB; ++m)
               acc[m][r2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][m], pb[cur][r2], acc[m][r2], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -347,7 +336,50 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
         for (int k = 0; k < kc; k += 4) URF_KSTEP(k)
       }
 #undef URF_KSTEP
-      __syncthreads();  // every wave is done with w_tile (and in_tile after the last tap)
+  };
+
+  if constexpr (MB == 4) {
+    issue_w(0, 0, wpf);
+    if (TAPS == 1) issue_in(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * 64;
+      const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
+      stage_input(ch);
+      for (int tap = 0; tap < TAPS; ++tap) {
+        commit_w(wpf);
+        __syncthreads();  // in_tile + w_tile of this stage visible
+        {                 // prefetch the next stage
+          const bool last_tap = (tap + 1 == TAPS);
+          if (!last_tap) issue_w(ch, tap + 1, wpf);
+          else if (ch + 1 < nchunks) {
+            issue_w(ch + 1, 0, wpf);
+            if (TAPS == 1) issue_in(ch + 1);
+          }
+        }
+        compute_tap(tap, kc);
+        __syncthreads();  // every wave is done with w_tile (and in_tile after the last tap)
+      }
+    }
+  } else {
+    // stages (chunk, tap) flattened; the weights of stage s + 2 are requested when stage s has been committed to LDS, so two
+    // requests are always in flight (one float4 per thread each) beside a stage that is only 32 MFMAs per wave long
+    const int S = nchunks * TAPS;
+    issue_w(0, 0, wpf);
+    if (S > 1) issue_w(1 / TAPS, 1 % TAPS, wpf2);
+    auto stage = [&](int s2, f32x4 *wr) {
+      const int ch = s2 / TAPS, tap = s2 % TAPS;
+      const int c0 = ch * 64;
+      const int kc = FUSE1A ? 64 : ((a.Cin - c0) < 64 ? (a.Cin - c0) : 64);
+      if (tap == 0) stage_input(ch);
+      commit_w(wr);
+      __syncthreads();
+      if (s2 + 2 < S) issue_w((s2 + 2) / TAPS, (s2 + 2) % TAPS, wr);
+      compute_tap(tap, kc);
+      __syncthreads();
+    };
+    for (int s2 = 0; s2 < S; s2 += 2) {
+      stage(s2, wpf);
+      if (s2 + 1 < S) stage(s2 + 1, wpf2);
     }
   }
 
@@ -359,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     const int Ho = a.H >> 1, Wo = a.W >> 1;
     const int oy = (y0 >> 1) + wave, ox = (x0 + px) >> 1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MB; ++m) {
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -390,7 +422,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
       const float *resb = a.res ? a.res + (size_t)b * a.res_bstride + pix * a.res_ld + a.res_coff : nullptr;
       float *op = outb + pix * a.out_ld + a.out_coff;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MB; ++m) {
         const int co = cout_base + m * 16 + 4 * g;
         f32x4 v = acc[m][r2];
         if (a.relu) {
@@ -427,7 +459,10 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   } else {
     grid.x = (a.W + TH * TW - 1) / (TH * TW);
   }
-  grid.y = (a.Cout + 63) / 64;
+  // the redo pass of the guarded fast mode (target-gated launches: a handful of live tiles): 16 output channels per workgroup
+  static const bool split_env = [] { const char *e = getenv("URF_GUARD_SPLIT"); return !e || atoi(e) != 0; }();
+  const bool split = split_env && taps == 9 && !fuse1a && a.gate && a.t_scale > 0;   // (conv1: its fused first layer would be redone per quarter)
+  grid.y = split ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
   grid.z = batch;
   const size_t lds = conv_lds_bytes(taps, fuse1a);
   static DeviceOnce attr_done;
@@ -437,9 +472,18 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     attr_done.mark();
   }
-  if (taps == 9 && fuse1a && pool) {
+  if (split && fuse1a && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, true, 1>), grid, block, lds, st, a);
+  } else if (split && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, false, 1>), grid, block, lds, st, a);
+  } else if (split) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, false, false, 1>), grid, block, lds, st, a);
+  } else if (taps == 9 && fuse1a && pool) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, true>), grid, block, lds, st, a);
   } else if (taps == 9 && pool) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, false>), grid, block, lds, st, a);

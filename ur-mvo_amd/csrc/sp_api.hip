@@ -137,13 +137,11 @@ struct urf_sp {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" const char *urf_last_error(void) { return urf::last_error(); }
-// what this binary is: build time and the guard constants compiled in (bench.py prints it: a stale library is visible in the line)
-extern "C" const char *urf_build_info(void) {
-  static char info[160];
-  snprintf(info, sizeof(info), "liburf_front built %s %s; guard SuperPoint delta %.3g ulps %.3g", __DATE__, __TIME__,
-           (double)kGuardSpDelta, (double)kGuardSpUlps);
-  return info;
-}
+// (urf_build_info: build_info.hip, recompiled with every link)
+namespace urf {
+double build_guard_delta() { return (double)kGuardSpDelta; }
+double build_guard_ulps() { return (double)kGuardSpUlps; }
+}  // namespace urf
 extern "C" int urf_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

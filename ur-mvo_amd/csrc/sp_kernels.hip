@@ -150,14 +150,16 @@ __global__ void __launch_bounds__(256) nms_tie_kernel(const float *out, int H, i
   const float c = o[i];
   if (!(c > thr_lo)) return;
   const int y = i / W, x = i % W;
+  // (no short circuit: the 80 reads of a survivor are independent and go out together)
   bool tie = false;
+#pragma unroll
   for (int dy = -4; dy <= 4; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= H) continue;
+    const int yy = y + dy, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
     for (int dx = -4; dx <= 4; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
-      tie = tie || o[(size_t)yy * W + xx] > 0.0f;
+      const int xx = x + dx, xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      const bool other = yy == yc && xx == xc && !(dx == 0 && dy == 0);
+      tie = tie | (other & (o[(size_t)yc * W + xc] > 0.0f));
     }
   }
   if (tie) atomicMax(&g.nms_hi[b], __float_as_int(c));
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const float *desc /*[B][Hc*
 // After the fast pass of a batch (up to the top-k selection): frames whose guard word is set go to the redo list (layout:
 // urf_common.h), their u8 images to the redo arena.  A frame whose only ambiguity is the top-k cut needs nothing but the exact
 // scores of the cells of a few candidates (mode = their number, targets = their cells); any other bit: the whole frame.
-// One workgroup per frame.  stats: [0] frames redone whole, [1] frames seen, [2] frames with a cut resolved per candidate,
+// grid (frames, kCompactChunks): the chunks of a frame share the copy of its image.  stats: [0] frames redone whole, [1] frames seen, [2] frames with a cut resolved per candidate,
 // [3] threshold band, [4] NMS near-tie, [5] too many candidates at the cut, [6] candidates resolved.
 __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, const int *amb, int B, int Ws, int Wc,
                                                             const uint8_t *imgs, size_t img_bytes, uint8_t *redo_imgs,
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, co
     total += f;
   }
   const int mine = flags[b];
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
     if (b == 0) {
       gate[0] = total;
       atomicAdd(&stats[1], (unsigned long long)B);
@@ -593,12 +595,13 @@ __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, co
   if (!mine) return;
   const uint8_t *src = imgs + (size_t)b * img_bytes;
   uint8_t *dst = redo_imgs + (size_t)r * img_bytes;
+  const size_t first = (size_t)blockIdx.y * 256 + threadIdx.x, step = (size_t)gridDim.y * 256;
   if ((((size_t)src | (size_t)dst | img_bytes) & 15) == 0) {
     const uint4 *s4 = (const uint4 *)src;
     uint4 *d4 = (uint4 *)dst;
-    for (size_t i = threadIdx.x; i < img_bytes / 16; i += 256) d4[i] = s4[i];
+    for (size_t i = first; i < img_bytes / 16; i += step) d4[i] = s4[i];
   } else {
-    for (size_t i = threadIdx.x; i < img_bytes; i += 256) dst[i] = src[i];
+    for (size_t i = first; i < img_bytes; i += step) dst[i] = src[i];
   }
 }
 
@@ -607,12 +610,13 @@ __global__ void __launch_bounds__(256) guard_compact_kernel(const int *flags, co
 // Everything above the band is in the exact mode's top k, everything below it is out (the band is wider than twice the error);
 // the places the band's members held in the fast top k go to the band's best by (exact score descending, raster index
 // ascending) -- the exact mode's own rule.  The frame's keypoint list is rewritten in place, in score order, the band's members
-// carrying their exact scores.  One 1024-thread workgroup per redo slot.
+// carrying their exact scores: a merge by rank (the kept entries are in order already), no sort.  One 1024-thread workgroup
+// per redo slot.
 __global__ void __launch_bounds__(1024) guard_resolve_kernel(const int *gate, const int *amb, const float *heat_x, int HsWs,
                                                              float *kp_score, int *kp_idx, const int *kp_n) {
-  __shared__ unsigned long long keys[kCap];
-  __shared__ unsigned long long akey[kAmbMax];
-  __shared__ int s_in;
+  __shared__ unsigned long long akey[kAmbMax], asort[kAmbMax];
+  __shared__ int above[kAmbMax];     // kept entries that rank before the band's t-th best
+  __shared__ int wsum[16];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (r >= gate[0] || gate[kGateMode + r] < 0) return;
   const int b = gate[1 + r];
@@ -621,8 +625,8 @@ __global__ void __launch_bounds__(1024) guard_resolve_kernel(const int *gate, co
   const int n = kp_n[b];
   float *os = kp_score + (size_t)b * kCap;
   int *oi = kp_idx + (size_t)b * kCap;
-  if (tid == 0) s_in = 0;
   if (tid < kAmbMax) {
+    above[tid] = 0;
     akey[tid] = 0ull;
     if (tid < na) {
       const float sx = heat_x[(size_t)r * HsWs + ai[tid]];
@@ -630,44 +634,43 @@ __global__ void __launch_bounds__(1024) guard_resolve_kernel(const int *gate, co
     }
   }
   __syncthreads();
-  // the list without the band's members; count the places they held
+  // the band by (exact score descending, raster index ascending): the keys are distinct, a member's place is the number of
+  // members before it
+  if (tid < na) {
+    int place = 0;
+    for (int u = 0; u < na; ++u) place += akey[u] > akey[tid] ? 1 : 0;
+    asort[place] = akey[tid];
+  }
+  // the list (in key order already: topk_kernel sorted it) without the band's members, each kept entry with its place among
+  // the kept ones
   unsigned long long key = 0ull;
+  bool keep = false;
   if (tid < n) {
     const int idx = oi[tid];
     bool member = false;
     for (int t = 0; t < na; ++t) member = member || ai[t] == idx;
-    if (member) atomicAdd(&s_in, 1);
-    else key = ((unsigned long long)__float_as_uint(os[tid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+    keep = !member;
+    key = ((unsigned long long)__float_as_uint(os[tid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
   }
-  keys[tid] = key;
-  __syncthreads();
-  // the band's best by exact score (na <= 8: one thread sorts them), into the freed places (zeros sort last)
-  if (tid == 0) {
-    for (int i = 1; i < na; ++i) {
-      const unsigned long long k = akey[i];
-      int j = i - 1;
-      while (j >= 0 && akey[j] < k) { akey[j + 1] = akey[j]; --j; }
-      akey[j + 1] = k;
-    }
-    int t = 0;
-    for (int i = 0; i < n && t < s_in; ++i)
-      if (keys[i] == 0ull) keys[i] = akey[t++];
+  int kept;
+  int place = block_excl_scan(keep ? 1 : 0, wsum, kept);     // (its barriers also publish asort and end the reads of the list)
+  const int freed = n - kept;                                // the places the band's members held go to the band's best
+  for (int t = 0; t < freed; ++t) {
+    const unsigned long long bk = asort[t];
+    place += (keep && bk > key) ? 1 : 0;
+    const unsigned long long before = __ballot(keep && key > bk);
+    if ((tid & 63) == 0 && before) atomicAdd(&above[t], __popcll(before));
   }
   __syncthreads();
-  for (int size = 2; size <= kCap; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int i = tid, j = i ^ stride;
-      if (j > i) {
-        const unsigned long long a = keys[i], c = keys[j];
-        const bool desc = ((i & size) == 0);
-        if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[j] = a; }
-      }
-      __syncthreads();
-    }
+  if (keep) {
+    os[place] = __uint_as_float((unsigned)(key >> 32));
+    oi[place] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
   }
-  if (tid < n) {
-    os[tid] = __uint_as_float((unsigned)(keys[tid] >> 32));
-    oi[tid] = (int)(0xFFFFFFFFu - (unsigned)(keys[tid] & 0xFFFFFFFFu));
+  if (tid < freed) {
+    const unsigned long long bk = asort[tid];
+    const int at = tid + above[tid];
+    os[at] = __uint_as_float((unsigned)(bk >> 32));
+    oi[at] = (int)(0xFFFFFFFFu - (unsigned)(bk & 0xFFFFFFFFu));
   }
 }
 
@@ -726,7 +729,7 @@ int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, cons
 
 int launch_guard_compact(const int *flags, const int *amb, int B, int Ws, int Wc, const uint8_t *imgs, size_t img_bytes,
                          uint8_t *redo_imgs, int *gate, unsigned long long *stats, hipStream_t st) {
-  hipLaunchKernelGGL(guard_compact_kernel, dim3(B), dim3(256), 0, st, flags, amb, B, Ws, Wc, imgs, img_bytes, redo_imgs, gate,
+  hipLaunchKernelGGL(guard_compact_kernel, dim3(B, 16), dim3(256), 0, st, flags, amb, B, Ws, Wc, imgs, img_bytes, redo_imgs, gate,
                      stats);
   URF_HIP(hipGetLastError());
   return 0;
