@@ -32,4 +32,5 @@ timeout 300 python bench.py > $OUT/${TAG}_bench_fast_640x480.json 2> $OUT/bench.
 timeout 300 python bench.py --resolution 1241x376 --no-cpu-baseline > $OUT/${TAG}_bench_fast_1241x376.json 2>> $OUT/bench.err
 timeout 300 python bench.py --precision 0 --no-cpu-baseline > $OUT/${TAG}_bench_exact_640x480.json 2>> $OUT/bench.err
 timeout 300 python bench.py --precision 1 --no-cpu-baseline > $OUT/${TAG}_bench_unguarded_640x480.json 2>> $OUT/bench.err
+timeout 300 python bench.py --precision 1 --resolution 1241x376 --no-cpu-baseline > $OUT/${TAG}_bench_unguarded_1241x376.json 2>> $OUT/bench.err
 ls -la $OUT
