@@ -66,7 +66,7 @@ def test_loopback_world_collectives_have_the_layout_of_the_real_ones(U):
             comms[r].gather(local[r].data_ptr(), 128, 0, 0, streams[r].cuda_stream)
 
 
-@pytest.mark.parametrize("world,B,prec", [(8, 4, 1), (2, 4, 0)])
+@pytest.mark.parametrize("world,B,prec", [(8, 4, 2), (2, 4, 1), (2, 4, 0)])
 def test_sharded_pipeline_in_a_loopback_world_vs_oracle(U, sp_blob, sg_blob, world, B, prec):
     """BASELINE.json configs[3] geometry on ONE GPU: 1241x376 frames, batch 32 sharded 4 per rank over 8 logical ranks
     (urf_comm_init_loopback), every rank with its own SuperPoint and two matcher handles and the step loop bench.py runs

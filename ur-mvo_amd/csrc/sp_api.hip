@@ -334,12 +334,14 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     const bool two_streams = e2s && atoi(e2s) != 0;
     if (arena(h->R, false) || (two_streams && arena(h->A2, true))) return -1;
     URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
-    if (dalloc(&h->g_flags, B) || dalloc(&h->g_band, B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) ||
-        dalloc(&h->g_amb, B * (1 + kAmbMax)) || dalloc(&h->g_nms, B))
+    // (flags | band | nms in one block: one memset per call clears the three)
+    if (dalloc(&h->g_flags, 3 * B) || dalloc(&h->g_gate, kGateInts) || dalloc(&h->g_stats, 8) || dalloc(&h->g_amb, B * (1 + kAmbMax)))
       return -1;
-    if (two_streams && (dalloc(&h->g2_flags, B) || dalloc(&h->g2_band, B) || dalloc(&h->g2_gate, kGateInts) ||
-                        dalloc(&h->g2_amb, B * (1 + kAmbMax)) || dalloc(&h->g2_nms, B) || dalloc(&h->g2_img, B * H * W)))
+    h->g_band = h->g_flags + B; h->g_nms = h->g_flags + 2 * B;
+    if (two_streams && (dalloc(&h->g2_flags, 3 * B) || dalloc(&h->g2_gate, kGateInts) ||
+                        dalloc(&h->g2_amb, B * (1 + kAmbMax)) || dalloc(&h->g2_img, B * H * W)))
       return -1;
+    if (two_streams) { h->g2_band = h->g2_flags + B; h->g2_nms = h->g2_flags + 2 * B; }
     if (dalloc(&h->g_img, B * H * W)) return -1;
     // URF_SP_TWO_STREAMS=1 (A/B runs; measured and NOT the default): the exact pass, the cut resolution and the descriptor tail on
     // a second stream beside the next call's fast pass, with two alternating fast arenas.  Same box, 640x480, frames/s: unguarded
@@ -423,8 +425,8 @@ extern "C" void urf_sp_destroy(urf_sp *h) {
     for (void *p : bufs) (void)hipFree(p);
     void *rbufs[] = {h->R.a1, h->R.a2a, h->R.a2b, h->R.a3a, h->R.a3b, h->R.a4a, h->R.a4b, h->R.apd, h->R.logits, h->R.ddb, h->R.desc,
                      h->R.heat, h->R.scores, h->R.ss, h->R.mask, h->R.supp, h->R.counts, h->R.cand_score, h->R.cand_idx, h->R.cand_n,
-                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_band, h->g_gate, h->g_img, h->g_stats, h->g_amb, h->g_nms,
-                     h->g2_flags, h->g2_band, h->g2_gate, h->g2_img, h->g2_amb, h->g2_nms,
+                     h->R.kp_score, h->R.kp_idx, h->R.kp_n, h->g_flags, h->g_gate, h->g_img, h->g_stats, h->g_amb,
+                     h->g2_flags, h->g2_gate, h->g2_img, h->g2_amb,
                      h->A2.a1, h->A2.a2a, h->A2.a2b, h->A2.a3a, h->A2.a3b, h->A2.a4a, h->A2.a4b, h->A2.apd, h->A2.logits, h->A2.ddb,
                      h->A2.desc, h->A2.heat, h->A2.scores, h->A2.ss, h->A2.mask, h->A2.supp, h->A2.counts, h->A2.cand_score, h->A2.cand_idx,
                      h->A2.cand_n, h->A2.kp_score, h->A2.kp_idx, h->A2.kp_n};
@@ -633,9 +635,7 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
   const int Hs = H / 8 * 8, Ws = W / 8 * 8;
   g.flags = h->g_flags; g.band = h->g_band; g.amb = h->g_amb; g.nms_hi = h->g_nms; g.delta = h->g_delta; g.ulps = h->g_ulps;
   SpGuard off = {};
-  URF_HIP(hipMemsetAsync(h->g_flags, 0, B * sizeof(int), st));
-  URF_HIP(hipMemsetAsync(h->g_band, 0, B * sizeof(int), st));
-  URF_HIP(hipMemsetAsync(h->g_nms, 0, B * sizeof(int), st));
+  URF_HIP(hipMemsetAsync(h->g_flags, 0, 3 * (size_t)h->maxB * sizeof(int), st));   // flags | band | nms
   if (sp_pipeline_on(h, h->A, true, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 3, st)) return -1;
   if (launch_guard_compact(h->g_flags, h->g_amb, B, Ws, Ws / 8, d_imgs, (size_t)H * W, h->g_img, h->g_gate, h->g_stats, st)) return -1;
   if (two) {

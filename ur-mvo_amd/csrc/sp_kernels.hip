@@ -331,15 +331,18 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float *cand_score, con
       if ((u & msk) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      int r = s_rank, bin = 255;
-      for (; bin > 0; --bin) {
-        if (hist[bin] >= r) break;
-        r -= hist[bin];
+    {
+      // the bin that holds the r-th largest: the one whose count of strictly higher bins is < r <= that count + its own
+      // (thread t takes bin 255 - t, so an exclusive scan over the threads is the count above the bin; one thread matches)
+      const int r = s_rank, bin = 255 - tid;
+      const int own = tid < 256 ? hist[bin] : 0;
+      int tot;
+      const int above = block_excl_scan(own, wsum, tot);
+      if (tid < 256 && above < r && r <= above + own) {
+        s_rank = r - above;  // rank inside the chosen bin
+        s_prefix = prefix | ((unsigned)bin << (8 * pass));
+        s_mask = msk | (0xFFu << (8 * pass));
       }
-      s_rank = r;  // rank inside the chosen bin
-      s_prefix = prefix | ((unsigned)bin << (8 * pass));
-      s_mask = msk | (0xFFu << (8 * pass));
     }
     __syncthreads();
   }
