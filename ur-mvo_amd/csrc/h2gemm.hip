@@ -417,7 +417,9 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     }
     // URF_H2GEMM_BALANCE (default 2): bit 1 = 64-row tiles for launches of <= 2 cout tiles (measured: linear layers 1.775 -> 1.757 ms per
     // 8 pairs, pipeline +1.5 %); bit 0 = the 1.5-tile Q|K|V^T kernel (measured and NOT the default: 1.775 -> 1.890 ms, its 64-row
-    // transposed half tile is slower than the half-empty second round it removes)
+    // transposed half tile is slower than the half-empty second round it removes); bit 2 = 64-row tiles for EVERY
+    // token-major launch (measurement only: what two half tiles per resident slot cost against one full tile -- the K loop of the
+    // "persistent two-tile" variant of DESIGN.md section 8)
     static int balance = -1;
     if (balance < 0) { const char *e = getenv("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 2; }
     static int nt = -1;
@@ -426,7 +428,7 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     b.xflags = g_h2gemm_xflags | nt;
     if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768)
       hipLaunchKernelGGL(h2gemm_glds_qkv_kernel, dim3((a.rows + 127) / 128, 4, batch), dim3(512), lds, st, b);
-    else if ((balance & 2) && !a.ohT && a.Cout <= 256)
+    else if (!a.ohT && (((balance & 2) && a.Cout <= 256) || (balance & 4)))
       hipLaunchKernelGGL(h2gemm_glds_half_kernel, dim3((a.rows + 63) / 64, a.Cout / 128, batch), dim3(512), lds, st, b);
     else if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, b);
     else if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<1>), grid, dim3(512), lds, st, b);
