@@ -185,6 +185,14 @@ def main():
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
     del stream
     torch.cuda.synchronize()
+    # guarded fast mode: the guard's error model is checked against the exact mode on this stream's own frames before anything is
+    # timed (urf_sp_calibrate_guard_device: widens the constants if the frames need it; on these streams they hold as built)
+    guard_model = None
+    if PREC == 2:
+        cal = [sp.calibrate_guard(device_ptr=d_frames[k * BATCH].data_ptr(), B=BATCH, rows=H, cols=W) for k in range(NB)]
+        guard_model = {"delta_needed_by_the_stream": max(c_["delta_needed"] for c_ in cal),
+                       "c_needed_by_the_stream": max(c_["c_needed"] for c_ in cal), "delta": cal[-1]["delta"], "c": cal[-1]["c"],
+                       "frames_checked": NB * BATCH, "model": "|fast - exact| <= delta s (1 - s) + c eps s on the heat map"}
     F.set_profiling(True)
     # The step loop is ur-mvo_amd/pipeline.py (SlotRingPipeline; tests/test_gpu_fullsize.py runs the same object against the
     # CPU oracle).  URF_BENCH_OVERLAP: 0 = SuperPoint and the matcher on ONE in-order stream; 1 = SP(b+1) beside Sinkhorn(b)
@@ -474,6 +482,7 @@ def main():
                                 "frames_with_cut_resolved_per_candidate": sum(h_["cuts_resolved"] for h_ in per_rank),
                                 "superpoint_causes": {k: sp_g[k] for k in ("cut_resolved", "candidates", "threshold", "nms", "cut_overflow")},
                                 "matcher_causes": {k: sum(g_[k] for g_ in pm_g) for k in ("threshold", "runner_up")}},
+            "guard_model": guard_model,
             "per_rank": per_rank,
             "library": U._lib.lib().urf_build_info().decode(),
         }

@@ -69,6 +69,17 @@ class SuperPoint {
     return true;
   }
 
+  // Not in the reference: the guarded fast mode's error model checked against the exact mode on one of the
+  // deployment's own frames and widened if that frame needs it (urf_sp_calibrate_guard; a no-op in the other modes).  Call it
+  // after build() with a few representative frames when the weights are not the ones the built-in constants were measured on.
+  bool calibrate_guard(const cv::Mat &image) {
+    if (!h_) return false;
+    if (urf_shim_precision() != 2) return true;
+    const uint8_t *p = image.data;
+    if (urf_sp_calibrate_guard(h_, 1, &p, image.rows, image.cols, (size_t)image.step, nullptr) != 0) { report("calibrate_guard"); return false; }
+    return true;
+  }
+
   // infer(): src/super_point.cpp:121-156.  features is resized by the callee.
   bool infer(const cv::Mat &image, const cv::Mat &mask, Eigen::Matrix<double, 259, Eigen::Dynamic> &features) {
     if (!h_) return false;

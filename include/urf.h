@@ -100,6 +100,14 @@ int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K);
  * candidates resolved (n <= 8 values are written; zeros in the other modes).  Waits for the handle's stream. */
 int urf_sp_near_tie_reruns(urf_sp *h, unsigned long long *out, int n);
 
+/* guarded fast mode: check the error model the guard rests on -- |fast - exact| <= delta s (1 - s) + c eps s for every heat-map
+ * value s -- on B representative frames (host pointers / device pointer), and widen delta and c where these frames need it
+ * (never narrows).  The built-in constants (delta 1.6e-4, c 8) were measured on the synthetic bench streams; a deployment with
+ * its own weights calls this once after build() with a batch of its own frames.  out[0] = the delta the frames needed, out[1] =
+ * the c they needed, out[2], out[3] = the constants in use after the call (out may be null).  Synchronous. */
+int urf_sp_calibrate_guard(urf_sp *h, int B, const uint8_t *const *imgs, int rows, int cols, size_t step, double *out);
+int urf_sp_calibrate_guard_device(urf_sp *h, int B, const uint8_t *d_imgs, int rows, int cols, double *out);
+
 /* debug / parity taps (tests): dense tensors of the LAST single-frame call.
  * which: 0 = post-NMS scores [Hs][Ws], 1 = pre-NMS heat map [Hs][Ws],
  * 2 = dense descriptors [Hc][Wc][256], 100+i = conv i output (NHWC). */

@@ -386,6 +386,34 @@ def test_sweep_superpoint_fast_vs_exact(U, F, sp_blob, seed):
     assert sets[0] == sets[1]
 
 
+@pytest.mark.parametrize("H,W", [(480, 640), (376, 1241)])
+def test_guard_calibration_on_the_bench_streams(U, F, sp_blob, H, W, monkeypatch):
+    """urf_sp_calibrate_guard: the guard's error model |fast - exact| <= delta s (1 - s) + c eps s, measured against the exact
+    mode on frames the caller supplies.  (a) On the bench streams the built-in constants hold with head-room (they were measured
+    there: DESIGN.md section 11) and the call changes nothing; (b) a handle started with constants that are far too small gets
+    them widened to what the frames need, and then delivers the exact mode's keypoint sets again."""
+    frames = U.synth.shift_stream(100, 40, H, W)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=2)
+    assert sp.build(sp_blob)
+    for i in range(0, 40, 8):
+        c = sp.calibrate_guard(images=frames[i:i + 8])
+        assert 0 < c["delta_needed"] <= 1.6e-4 / 1.1 and c["c_needed"] <= 8.0 / 1.1, c
+        assert abs(c["delta"] - 1.6e-4) < 1e-9 and c["c"] == 8.0, c
+    sx = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8)
+    assert sx.build(sp_blob)
+    want = [{(r[1], r[2]) for r in f} for f in sx.infer_batch(frames[:8])]
+    monkeypatch.setenv("URF_GUARD_SP_DELTA", "1e-7")
+    monkeypatch.setenv("URF_GUARD_SP_ULPS", "0.25")
+    tight = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=8, precision=2)
+    assert tight.build(sp_blob)
+    c = tight.calibrate_guard(images=frames[:8])
+    assert c["c"] >= 1.1 * c["c_needed"] * 0.999 and c["c"] > 0.25 and c["delta"] >= 1.1 * c["delta_needed"] * 0.999 and c["delta"] > 1e-7, c
+    got = [{(r[1], r[2]) for r in f} for f in tight.infer_batch(frames[:8])]
+    assert got == want
+    with pytest.raises(RuntimeError, match="guarded"):
+        sx.calibrate_guard(images=frames[:2])
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_sweep_superpoint_guarded_vs_exact(U, F, sp_blob, seed):
     """the guarded fast mode on random sizes, keypoint budgets, border widths, masks and ragged batches: the keypoint SET of

@@ -56,6 +56,8 @@ int launch_sample(const float *desc, int Hc, int Wc, const float *kp_score, cons
                   hipStream_t st);
 int launch_guard_compact(const int *flags, const int *amb, int B, int Ws, int Wc, const uint8_t *imgs, size_t img_bytes,
                          uint8_t *redo_imgs, int *gate, unsigned long long *stats, hipStream_t st);
+int launch_guard_calib(const float *heat_fast, const float *heat_exact, size_t n, float delta, float ulps, float thr_lo,
+                       int *out, hipStream_t st);
 int launch_guard_resolve(const int *gate, const int *amb, const float *heat_x, int HsWs, float *kp_score, int *kp_idx,
                          const int *kp_n, int B, hipStream_t st);
 
@@ -752,6 +754,56 @@ extern "C" int urf_sp_near_tie_reruns(urf_sp *h, unsigned long long *out, int n)
   }
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 0;
+}
+
+// Guard calibration (include/urf.h): the fast and the exact pass up to the heat map on the caller's frames, the error model's
+// two constants widened where those frames need it.  Never narrows them.
+static int sp_calibrate(urf_sp *h, int B, const uint8_t *d_imgs, int rows, int cols, double *out) {
+  URF_CHECK(h->precision == 2, "urf_sp_calibrate_guard: the handle is not in the guarded fast mode (precision 2)");
+  const int Hs = rows / 8 * 8, Ws = cols / 8 * 8;
+  const size_t n = (size_t)B * Hs * Ws;
+  const SpGuard off = {};
+  hipStream_t st = h->st;
+  URF_HIP(hipStreamSynchronize(h->stx));     // (two-stream variant: the redo arena may still be in use)
+  if (sp_pipeline_on(h, h->A, true, B, d_imgs, rows, cols, nullptr, h->d_feat, h->d_slots, nullptr, off, nullptr, false, 1, st)) return -1;
+  if (sp_pipeline_on(h, h->R, false, B, d_imgs, rows, cols, nullptr, h->d_feat, h->d_slots, nullptr, off, nullptr, false, 1, st)) return -1;
+  const float margin = 1.10f;                // head-room over what the frames needed (the built-in delta has 14 % over its own measurement)
+  int *acc = h->g_gate;                      // (scratch: rebuilt by every call of the pipeline)
+  float need[2] = {0.0f, 0.0f}, first_c = 0.0f;
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: the c that the frames need beside the present delta (saturated scores: delta's term vanishes there);
+    // pass 1: the delta they need beside the c that results
+    URF_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(int), st));
+    if (launch_guard_calib(h->A.heat, h->R.heat, n, h->g_delta, h->g_ulps, (float)(h->cfg.keypoint_threshold * 0.5), acc, st)) return -1;
+    URF_HIP(hipMemcpyAsync(need, acc, sizeof(need), hipMemcpyDeviceToHost, st));
+    URF_HIP(hipStreamSynchronize(st));
+    if (pass == 0) {
+      first_c = need[1];
+      if (need[1] * margin > h->g_ulps) h->g_ulps = need[1] * margin;
+    } else if (need[0] * margin > h->g_delta) {
+      h->g_delta = need[0] * margin;
+    }
+  }
+  if (out) { out[0] = need[0]; out[1] = first_c; out[2] = h->g_delta; out[3] = h->g_ulps; }
+  return 0;
+}
+
+extern "C" int urf_sp_calibrate_guard_device(urf_sp *h, int B, const uint8_t *d_imgs, int rows, int cols, double *out) {
+  if (sp_check_dims(h, B, rows, cols)) return -2;
+  URF_CHECK(d_imgs, "urf_sp_calibrate_guard_device: null image pointer");
+  URF_HIP(hipSetDevice(h->device));
+  return sp_calibrate(h, B, d_imgs, rows, cols, out);
+}
+
+extern "C" int urf_sp_calibrate_guard(urf_sp *h, int B, const uint8_t *const *imgs, int rows, int cols, size_t step, double *out) {
+  if (sp_check_dims(h, B, rows, cols)) return -2;
+  URF_CHECK(imgs, "urf_sp_calibrate_guard: null image pointer");
+  URF_HIP(hipSetDevice(h->device));
+  const size_t fsz = (size_t)rows * cols;
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < rows; ++y) memcpy(h->h_img + b * fsz + (size_t)y * cols, imgs[b] + (size_t)y * step, cols);
+  URF_HIP(hipMemcpyAsync(h->d_img, h->h_img, B * fsz, hipMemcpyHostToDevice, h->st));
+  return sp_calibrate(h, B, h->d_img, rows, cols, out);
 }
 
 extern "C" int urf_slot_to_host(const void *d_slot, double *feat, int cap, int *K) {

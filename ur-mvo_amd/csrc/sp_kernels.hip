@@ -677,6 +677,33 @@ __global__ void __launch_bounds__(1024) guard_resolve_kernel(const int *gate, co
   }
 }
 
+// Calibration of the guard's error model err(s) = delta s (1 - s) + c eps s against the exact mode on caller-supplied frames:
+// over all pixels, out[0] = the delta that the fast heat map's error needs given c, out[1] = the c it needs given delta
+// (bit patterns of non-negative floats, atomicMax).  s is the FAST score, as in guard_err's callers.
+// Only scores that can take part in a decision count (at least one of the two above thr_lo, half the keypoint threshold -- the
+// guard's own relevance rule); a score of exactly 1 has no delta term, its error is c's to cover (pass 0 of the caller).
+__global__ void __launch_bounds__(256) guard_calib_kernel(const float *heat_fast, const float *heat_exact, size_t n,
+                                                          float delta, float ulps, float thr_lo, int *out) {
+  float need_d = 0.0f, need_c = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float a = heat_fast[i], x = heat_exact[i];
+    const float e = a > x ? a - x : x - a;
+    if (!(a > thr_lo || x > thr_lo) || !(a > 0.0f)) continue;
+    const float bend = a * (a < 1.0f ? 1.0f - a : 0.0f), grain = 1.1920929e-7f * a;
+    if (e > ulps * grain && bend > 0.0f) need_d = fmaxf(need_d, (e - ulps * grain) / bend);
+    if (e > delta * bend) need_c = fmaxf(need_c, (e - delta * bend) / grain);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    need_d = fmaxf(need_d, __shfl_xor(need_d, d, 64));
+    need_c = fmaxf(need_c, __shfl_xor(need_c, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], __float_as_int(need_d));
+    atomicMax(&out[1], __float_as_int(need_c));
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 int launch_softmax(const float *logits, int ld, int Hc, int Wc, float *heat, int B, const int *gate, hipStream_t st) {
   dim3 grid((Hc * Wc + 255) / 256, B);
@@ -740,6 +767,14 @@ int launch_guard_compact(const int *flags, const int *amb, int B, int Ws, int Wc
 int launch_guard_resolve(const int *gate, const int *amb, const float *heat_x, int HsWs, float *kp_score, int *kp_idx,
                          const int *kp_n, int B, hipStream_t st) {
   hipLaunchKernelGGL(guard_resolve_kernel, dim3(B), dim3(1024), 0, st, gate, amb, heat_x, HsWs, kp_score, kp_idx, kp_n);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_guard_calib(const float *heat_fast, const float *heat_exact, size_t n, float delta, float ulps, float thr_lo,
+                       int *out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+  hipLaunchKernelGGL(guard_calib_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, heat_fast, heat_exact, n, delta, ulps, thr_lo, out);
   URF_HIP(hipGetLastError());
   return 0;
 }

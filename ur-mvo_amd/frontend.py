@@ -125,6 +125,20 @@ class SuperPoint:
         return dict(redone=int(v[0]), frames=int(v[1]), cut_resolved=int(v[2]), threshold=int(v[3]), nms=int(v[4]),
                     cut_overflow=int(v[5]), candidates=int(v[6]))
 
+    def calibrate_guard(self, images=None, device_ptr=None, B=0, rows=0, cols=0):
+        """guarded fast mode: check (and widen where needed) the guard's error model on representative frames -- a list of
+        u8 images, or a device pointer to B frames.  Returns delta / c the frames needed and the constants now in use."""
+        out = (C.c_double * 4)()
+        if images is not None:
+            imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+            H, W = imgs[0].shape
+            ptrs = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
+            check(_lib.lib().urf_sp_calibrate_guard(self._h, len(imgs), ptrs, H, W, C.c_size_t(W), out), "urf_sp_calibrate_guard")
+        else:
+            check(_lib.lib().urf_sp_calibrate_guard_device(self._h, B, C.c_void_p(device_ptr), rows, cols, out),
+                  "urf_sp_calibrate_guard_device")
+        return dict(delta_needed=out[0], c_needed=out[1], delta=out[2], c=out[3])
+
     def debug_tensor(self, which, shape):
         out = np.zeros(shape, np.float32)
         check(_lib.lib().urf_sp_debug_tensor(self._h, which, _p(out), C.c_size_t(out.size)), "debug_tensor")
