@@ -217,6 +217,14 @@ def main():
     pipe = P.SlotRingPipeline(sp, pms, d_frames, BATCH, H, W, device=dev, rank=rank, world=world, comm=comm,
                               gloo=exchange and not async_exchange, overlap=OVERLAP)
     ring = pipe.ring
+    if PREC == 2:
+        # ... and the matcher's margin against the exact matcher, on the first pairs of the stream (urf_pm_calibrate_guard)
+        pipe.sp_step(0); pipe.sp_step(1); sp.sync()
+        c0 = [ring[0][j].data_ptr() for j in range(BATCH)]
+        c1 = [ring[0][j + 1].data_ptr() for j in range(BATCH - 1)] + [ring[1][0].data_ptr()]
+        calz = [m_.calibrate_guard(c0, c1) for m_ in pms]
+        guard_model.update({"matcher_z_difference_on_the_stream": max(c_["z_difference"] for c_ in calz),
+                            "matcher_margin": calz[-1]["margin"], "pairs_checked": BATCH})
 
     sp_ms, conv1_ms, pm_ms, lin_ms, attn_ms, sink_ms, ransac_ms = [], [], [], [], [], [], []
     sp_stages = []

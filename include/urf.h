@@ -300,6 +300,12 @@ int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n);
  * 0 = the pair's match set is the exact pipeline's; bit 0 = a best assignment within the margin of the threshold,
  * bit 1 = within the margin of its runner-up */
 int urf_pm_near_tie_flags(urf_pm *h, int *flags, int P);
+/* guarded fast mode: measure the fast matcher against the exact matcher on P pairs of device slots (as urf_match_device takes
+ * them) -- the largest difference of the two log-assignment matrices over the entries a decision can rest on (probability above
+ * 0.1 in either) -- and widen the handle's margin to 1.1 x (that + 2.4e-4, the share of the fast SuperPoint's descriptor noise)
+ * if it is smaller (never narrows).  out[0] = the measured difference, out[1] = the margin in use after the call (out may be
+ * null).  Synchronous; allocates and frees a scratch copy of the P matrices. */
+int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1, double *out);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */

@@ -414,6 +414,41 @@ def test_guard_calibration_on_the_bench_streams(U, F, sp_blob, H, W, monkeypatch
         sx.calibrate_guard(images=frames[:2])
 
 
+def test_matcher_guard_calibration_on_the_bench_stream(U, F, sp_blob, sg_blob, monkeypatch):
+    """urf_pm_calibrate_guard: the fast matcher against the exact matcher on pairs of the bench stream.  The measured difference
+    of the log-assignments stays inside what the built-in margin allots to the matcher (5e-4 = 1.1 x (its share + 2.4e-4 of
+    descriptor noise)), so the margin stays; a handle started with a margin far too small gets it widened."""
+    import torch
+    H, W, B = 480, 640, 8
+    frames = U.synth.shift_stream(100, B + 1, H, W)
+    dev = torch.device("cuda", 0)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B + 1, precision=2)
+    assert sp.build(sp_blob)
+    slots = torch.zeros((B + 1, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device=dev)
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    sp.infer_device(d_frames.data_ptr(), B + 1, H, W, slots.data_ptr())
+    sp.sync()
+    s0 = [slots[j].data_ptr() for j in range(B)]
+    s1 = [slots[j + 1].data_ptr() for j in range(B)]
+    pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B, precision=2)
+    assert pm.build(sg_blob)
+    before = pm.MatchingPointsDevice(s0, s1) if hasattr(pm, "MatchingPointsDevice") else None
+    c = pm.calibrate_guard(s0, s1)
+    assert 0 < c["z_difference"] < 2.1e-4 and abs(c["margin"] - 5e-4) < 1e-9, c
+    pm.match_device_async(s0, s1, True)
+    after = pm.fetch(B)
+    assert all(len(m) > 300 for m in after) and (before is None or before == after)
+    monkeypatch.setenv("URF_GUARD_SG_Z", "1e-6")
+    tight = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B, precision=2)
+    assert tight.build(sg_blob)
+    c2 = tight.calibrate_guard(s0, s1)
+    assert abs(c2["z_difference"] - c["z_difference"]) < 1e-9 and c2["margin"] >= 1.1 * (c2["z_difference"] + 2.4e-4) * 0.999, c2
+    exact = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B)
+    assert exact.build(sg_blob)
+    with pytest.raises(RuntimeError, match="guarded"):
+        exact.calibrate_guard(s0, s1)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_sweep_superpoint_guarded_vs_exact(U, F, sp_blob, seed):
     """the guarded fast mode on random sizes, keypoint budgets, border widths, masks and ragged batches: the keypoint SET of

@@ -36,6 +36,7 @@ int launch_decode(const int *counts, const float *C, const float *Ct, const floa
                   int P, hipStream_t st);
 int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st);
 int launch_guard_merge(const int *gflags, const void *rm, const int *rn, void *fm, int *fn, int P, hipStream_t st);
+int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st);
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
                   float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
                   double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
@@ -52,6 +53,7 @@ static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e
 // plus what the fast SuperPoint's descriptor noise induces even in the exact matcher (2.4e-4), with 10 % on top (DESIGN.md
 // "Guarded fast mode", tools/gpu_margins.py)
 static const float kGuardSgZ = 5e-4f;
+static const float kGuardSgDescNoise = 2.4e-4f;   // the descriptor-noise share of it (not measurable inside the matcher)
 
 struct urf_pm {
   urf_sg_config cfg;
@@ -853,6 +855,53 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipEventRecord(h->ev_done, h->st));
   h->pending_P = P;
+  return 0;
+}
+
+// Guard calibration (include/urf.h): the fast and the exact matcher on the same slots, the largest difference of their
+// log-assignments on the entries a decision can rest on (probability above 0.1 in either), the margin widened where needed.
+extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1, double *out) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(h->guarded, "urf_pm_calibrate_guard: the handle is not in the guarded fast mode (precision 2)");
+  URF_CHECK(P >= 1 && P <= h->maxP && d_slots0 && d_slots1, "urf_pm_calibrate_guard: bad argument");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipEventSynchronize(h->ev_done));
+  hipStream_t st = h->st;
+  for (int p = 0; p < P; ++p) {
+    h->h_slotptrs[2 * p] = (const float *)d_slots0[p];
+    h->h_slotptrs[2 * p + 1] = (const float *)d_slots1[p];
+  }
+  URF_HIP(hipMemcpyAsync(h->d_slotptrs, h->h_slotptrs, 2 * P * sizeof(float *), hipMemcpyHostToDevice, st));
+  if (launch_sg_prep_slots(h->d_slotptrs, 2 * P, h->cfg.image_width, h->cfg.image_height, h->counts, h->kin, h->kxy, h->x, st)) return -1;
+  const unsigned long long seen = h->pairs_seen;
+  if (pm_pipeline(h, P, true, false)) return -1;                      // the fast pass, Z kept
+  h->pairs_seen = seen;                                               // (not a batch of the caller's stream)
+  URF_HIP(hipStreamSynchronize(st));
+  if (h->h_rs_err && h->h_rs_err[0] != 0) {                           // the resident Sinkhorn gave up: nothing to measure against
+    (void)pm_check_resident(h);
+    URF_CHECK(false, "urf_pm_calibrate_guard: the chip-resident Sinkhorn launch gave up; call again");
+  }
+  const size_t zbytes = (size_t)P * (NP + 1) * LDC * sizeof(float);
+  float *zf = nullptr;
+  int *acc = nullptr;
+  URF_HIP(hipMalloc((void **)&zf, zbytes));
+  if (hipMalloc((void **)&acc, sizeof(int)) != hipSuccess) { (void)hipFree(zf); URF_CHECK(false, "urf_pm_calibrate_guard: out of device memory"); }
+  int rc = hipMemcpyAsync(zf, h->Z, zbytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -1;
+  // the exact pass from the same encoded keypoints (h->x: the fast layers work on their own planes), lists to the redo buffers
+  if (!rc) rc = pm_gnn_exact(h, 2 * P, false);
+  if (!rc) rc = sg_linear(h, 2 * P, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr);
+  if (!rc) rc = pm_tail(h, P, true, false, false, false, true);
+  float worst = 0.0f;
+  if (!rc) rc = hipMemsetAsync(acc, 0, sizeof(int), st) == hipSuccess ? 0 : -1;
+  if (!rc) rc = launch_guard_z_calib(h->counts, zf, h->Z, logf(0.1f), acc, P, st);
+  if (!rc) rc = hipMemcpyAsync(&worst, acc, sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess ? 0 : -1;
+  if (!rc) rc = hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
+  (void)hipFree(zf);
+  (void)hipFree(acc);
+  URF_CHECK(rc == 0, "urf_pm_calibrate_guard: a launch or copy failed");
+  const float need = 1.10f * (worst + kGuardSgDescNoise);
+  if (need > h->g_z) h->g_z = need;
+  if (out) { out[0] = worst; out[1] = h->g_z; }
   return 0;
 }
 

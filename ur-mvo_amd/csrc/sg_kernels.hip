@@ -598,6 +598,28 @@ __global__ void __launch_bounds__(256) guard_merge_kernel(const int *gflags, con
   for (int i = threadIdx.x; i < n; i += 256) fm[(size_t)p * NP + i] = rm[(size_t)p * NP + i];
   if (threadIdx.x == 0) fn[p] = n;
 }
+// Calibration of the matcher's margin: the largest |Z_fast - Z_exact| over the entries of the log-assignment matrices (keypoint
+// rows and columns, no dustbins) that either pass holds above log_floor -- the entries a decision can rest on.
+__global__ void __launch_bounds__(256) guard_z_calib_kernel(const int *counts, const float *zf, const float *zx, float log_floor,
+                                                            int *out) {
+  const int p = blockIdx.y, n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  float worst = 0.0f;
+  for (int i = blockIdx.x; i < n0; i += gridDim.x) {
+    const size_t row = ((size_t)p * (NP + 1) + i) * LDC;
+    for (int j = threadIdx.x; j < n1; j += 256) {
+      const float a = zf[row + j], x = zx[row + j];
+      if (a > log_floor || x > log_floor) worst = fmaxf(worst, a > x ? a - x : x - a);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) worst = fmaxf(worst, __shfl_xor(worst, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_int(worst));
+}
+int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st) {
+  hipLaunchKernelGGL(guard_z_calib_kernel, dim3(128, P), dim3(256), 0, st, counts, zf, zx, log_floor, out);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
 int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st) {
   hipLaunchKernelGGL(guard_counts_kernel, dim3(1), dim3(256), 0, st, gflags, counts, counts_r, P, stats);
   URF_HIP(hipGetLastError());

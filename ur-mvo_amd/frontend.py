@@ -205,6 +205,16 @@ class _PM:
         check(_lib.lib().urf_pm_near_tie_reruns(self._h, v, 8), "urf_pm_near_tie_reruns")
         return dict(redone=int(v[0]), pairs=int(v[1]), threshold=int(v[2]), runner_up=int(v[3]), flagged=int(v[4]))
 
+    def calibrate_guard(self, slot_ptrs0, slot_ptrs1):
+        """guarded fast mode: the fast matcher against the exact matcher on these pairs of device slots; widens the margin where
+        needed.  Returns the measured difference of the log-assignments and the margin now in use."""
+        P = len(slot_ptrs0)
+        a0 = (C.c_void_p * P)(*slot_ptrs0)
+        a1 = (C.c_void_p * P)(*slot_ptrs1)
+        out = (C.c_double * 2)()
+        check(_lib.lib().urf_pm_calibrate_guard(self._h, P, a0, a1, out), "urf_pm_calibrate_guard")
+        return dict(z_difference=out[0], margin=out[1])
+
     def near_tie_flags(self, P=1):
         """guard words of the pairs of the batch handed out last (0 = the pair's match set is the exact pipeline's)"""
         f = (C.c_int * P)()
