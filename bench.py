@@ -123,6 +123,9 @@ def main():
                          "the fast mode's error is redone in the exact mode inside the library (the reruns are inside the timed "
                          "region); 1 = fast without the guard; 0 = exact fp32 (bit-identical to the oracle)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
+    ap.add_argument("--no-guard-calibration", action="store_true",
+                    help="skip the check of the guard's error model before the timed region (counter-collection runs: its "
+                         "exact-mode launches would be tallied with the step's)")
     ap.add_argument("--resolution", default="640x480", choices=["640x480", "1241x376"],
                     help="frame size WxH: 640x480 (headline, BASELINE configs[2]) or the KITTI-size stream of configs[3]")
     args = ap.parse_args()
@@ -188,7 +191,8 @@ def main():
     # guarded fast mode: the guard's error model is checked against the exact mode on this stream's own frames before anything is
     # timed (urf_sp_calibrate_guard_device: widens the constants if the frames need it; on these streams they hold as built)
     guard_model = None
-    if PREC == 2:
+    CALIBRATE = PREC == 2 and not args.no_guard_calibration
+    if CALIBRATE:
         cal = [sp.calibrate_guard(device_ptr=d_frames[k * BATCH].data_ptr(), B=BATCH, rows=H, cols=W) for k in range(NB)]
         guard_model = {"delta_needed_by_the_stream": max(c_["delta_needed"] for c_ in cal),
                        "c_needed_by_the_stream": max(c_["c_needed"] for c_ in cal), "delta": cal[-1]["delta"], "c": cal[-1]["c"],
@@ -217,7 +221,7 @@ def main():
     pipe = P.SlotRingPipeline(sp, pms, d_frames, BATCH, H, W, device=dev, rank=rank, world=world, comm=comm,
                               gloo=exchange and not async_exchange, overlap=OVERLAP)
     ring = pipe.ring
-    if PREC == 2:
+    if CALIBRATE:
         # ... and the matcher's margin against the exact matcher, on the first pairs of the stream (urf_pm_calibrate_guard)
         pipe.sp_step(0); pipe.sp_step(1); sp.sync()
         c0 = [ring[0][j].data_ptr() for j in range(BATCH)]

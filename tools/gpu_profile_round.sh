@@ -13,16 +13,16 @@ cd /tmp
 pmc() {   # $1 = suffix of the summary file, rest = extra bench arguments
   SUF=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc_$c -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-exact-check "$@" > $R/$OUT/pmc_$c$SUF.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc_$c -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-exact-check --no-guard-calibration "$@" > $R/$OUT/pmc_$c$SUF.log 2>&1
   done
-  (cd $R && python tools/pmc_summary.py $(find $OUT/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm$SUF.json "python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-exact-check $*")
+  (cd $R && python tools/pmc_summary.py $(find $OUT/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm$SUF.json "python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-exact-check --no-guard-calibration $*")
   rm -rf $R/$OUT/pmc_FETCH_SIZE $R/$OUT/pmc_WRITE_SIZE
   cp $R/$OUT/${TAG}_pmc_hbm$SUF.json $R/profiles/ 2>/dev/null    # so that the bench lines below carry roofline.traffic
 }
 pmc ""
 pmc _1241x376 --resolution 1241x376
 pmc _exact --precision 0
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_fast -o st -- python3 $R/bench.py --steps 15 --warmup 2 --repeats 1 --no-cpu-baseline --no-exact-check > $R/$OUT/stats_fast.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_fast -o st -- python3 $R/bench.py --steps 15 --warmup 2 --repeats 1 --no-cpu-baseline --no-exact-check --no-guard-calibration > $R/$OUT/stats_fast.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_exact -o st -- python3 $R/bench.py --precision 0 --steps 15 --warmup 2 --repeats 1 --no-cpu-baseline > $R/$OUT/stats_exact.log 2>&1
 cd $R
 cp $(find $OUT/stats_fast -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_fast_kernel_stats.csv
