@@ -23,8 +23,8 @@
 // raises *err and the host redoes the batch with the streaming kernels (sg_api.hip) instead of hanging the GPU.
 //
 // Two kernels share the exchange: sinkhorn_resident_kernel keeps the plan tile in LDS (128 KiB, 1024 threads: the CU is
-// its alone), sinkhorn_regs_kernel -- the default -- keeps it in registers (512 threads, 64 VGPRs of plan per thread, 6 KB
-// of LDS, every pair of a batch in one launch).
+// its alone), sinkhorn_regs_kernel -- the default -- keeps it in registers (256 threads with 128 VGPRs of plan per thread, or
+// 512 threads with 64; 6 KB of LDS, every pair of a batch in one launch).
 #include "urf_common.h"
 #include "urf_math.h"
 
@@ -470,12 +470,16 @@ __device__ __forceinline__ float rs_rows32_sum(VAL val, int lane) {   // val(r) 
   return v[0] + rs_dpp<0xB1>(v[0]);   // lane ^ 1
 }
 
-template <int MINW>   // waves per SIMD the register budget is cut for: 3 -> 168 VGPRs, 4 -> 128
-__global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
+// MINW: waves per SIMD the register budget is cut for (3 -> 168 VGPRs, 4 -> 128, 1 -> no cut).  NC: columns per thread, 1024 / NC
+// threads: NC = 2 is the kernel described above; NC = 4 (URF_SINKHORN_REGS=3) is ONE wave per SIMD with 128 registers of plan,
+// which leaves the SIMD's other half of the register file to a second kernel's waves (an h2gemm workgroup needs 2 x 104).
+template <int MINW, int NC>
+__global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a) {
+  constexpr int T = 1024 / NC, NWV = T / 64;
   __shared__ __attribute__((aligned(16))) float avec[RS_ROWS];      // a_i of the own rows (0 for i >= n0)
   __shared__ __attribute__((aligned(16))) float pcvec[RS_ROWS];     // dustbin-column entries exp(alpha + u0_i + v0_dust)
-  __shared__ float rowpart[8][RS_ROWS];                             // per-wave partial row sums (or maxima)
-  __shared__ float wsum[8];                                         // per-wave partials of the dustbin-row sum
+  __shared__ float rowpart[NWV][RS_ROWS];                            // per-wave partial row sums (or maxima)
+  __shared__ float wsum[NWV];                                      // per-wave partials of the dustbin-row sum
   __shared__ float misc[4];                                         // [0] = b of the dustbin column, [1] = gave up, [2] = one XCD
   __shared__ float csumv[1028];                                     // reduced column sums of this iteration
   __shared__ double u0vec[RS_ROWS];
@@ -489,25 +493,42 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
   // plain pointers the compiler keeps 64 loop-invariant 64-bit addresses, spills them, and every load of a re-absorption
   // waits for its address to come back from scratch (measured: 76 k ticks per re-absorption against 11 k)
   const __amdgpu_buffer_rsrc_t Crs = __builtin_amdgcn_make_buffer_rsrc((void *)Cp, 0, (RS_NP + 1) * RS_LDC * 4, 0x00020000);
-  auto Cload = [&](int row, int second) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Crs, 4 * (int)threadIdx.x + 2048 * second, row * (RS_LDC * 4), 0));
+  auto Cload = [&](int row, int c) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Crs, 4 * (int)threadIdx.x + 4 * T * c, row * (RS_LDC * 4), 0));
   };
   u64 *xin = a.xin + (size_t)p * RS_XIN, *xbc = a.xbc + (size_t)p * RS_XBC;
   const float tot = (float)(n0 + n1);
   const float mu = 1.0f / tot, mu_d = (float)n1 / tot, nu = 1.0f / tot, nu_d = (float)n0 / tot;
   const float alpha = a.alpha;
   const int i0 = w * RS_ROWS;
-  const int c0 = tid, c1 = tid + RG_T;        // this thread's two columns
-  const bool ok0 = c0 < n1, ok1 = c1 < n1;
-  // the dustbin column's sum travels in the slot of column n1 (an invalid column) or, at n1 == 1024, in the extra slot of thread 0
-  const bool dust0 = n1 < RS_NP && c0 == n1, dust1 = n1 < RS_NP && c1 == n1;
-  const bool own_dust = (n1 < RS_NP) ? (dust0 || dust1) : (tid == 0);
-  const int dust_wave = (n1 & (RG_T - 1)) >> 6;
+  // this thread's columns: tid + T c.  The dustbin column's sum travels in the slot of column n1 (an invalid column) or, at
+  // n1 == 1024, in the extra slot of thread 0
+  int col[NC];
+  bool ok[NC], dust[NC];
+  bool own_dust = (n1 < RS_NP) ? false : (tid == 0);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    col[c] = tid + T * c;
+    ok[c] = col[c] < n1;
+    dust[c] = n1 < RS_NP && col[c] == n1;
+    own_dust = own_dust || dust[c];
+  }
+  const int dust_wave = (n1 & (T - 1)) >> 6;
 
-  float P0[RS_ROWS], P1[RS_ROWS];
-  float b0 = ok0 ? 1.0f : 0.0f, b1 = ok1 ? 1.0f : 0.0f, pd0 = 0.0f, pd1 = 0.0f;
-  double v00 = 0.0, v01 = 0.0, u0d = -(double)alpha, v0d = 0.0;
+  float P[NC][RS_ROWS];
+  float bc[NC], pd[NC];
+  double v0c[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { bc[c] = ok[c] ? 1.0f : 0.0f; pd[c] = 0.0f; v0c[c] = 0.0; }
+  double u0d = -(double)alpha, v0d = 0.0;
   float Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
+  // sum over this thread's columns of x_c y_c, highest column first (NC = 2: fma(x0, y0, x1 y1))
+  auto dotc = [&](auto xs, const float (&ys)[NC]) {
+    float acc = xs(NC - 1) * ys[NC - 1];
+#pragma unroll
+    for (int c = NC - 2; c >= 0; --c) acc = fma_rn(xs(c), ys[c], acc);
+    return acc;
+  };
 
   // ---- u0_i = -max_j C_ij over the valid columns and the dustbin entry alpha (all 64 loads first, then the wave maxima)
   {
@@ -516,10 +537,12 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
     for (int i = 0; i < RS_ROWS; ++i) {
       // unconditional loads (every (row, column) read here exists in the buffer); rows >= n0 too: their maxima are
       // never used (a wave-uniform test here would come back as a branch with a full wait behind every load)
-      const float x0 = Cload(i0 + i, 0), x1 = Cload(i0 + i, 1);
+      float xs[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xs[c] = Cload(i0 + i, c);
       float m = alpha;
-      m = ok0 ? fmaxf(m, x0) : m;
-      m = ok1 ? fmaxf(m, x1) : m;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) m = ok[c] ? fmaxf(m, xs[c]) : m;
       mv[i] = m;
     }
 #pragma unroll
@@ -532,7 +555,7 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
   if (tid < RS_ROWS) {
     float m = rowpart[0][tid];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) m = fmaxf(m, rowpart[q][tid]);
+    for (int q = 1; q < NWV; ++q) m = fmaxf(m, rowpart[q][tid]);
     u0vec[tid] = (i0 + tid < n0) ? -(double)m : -1.0e300;   // rows past the count: exp(C + u0 + v0) = 0 without a test in absorb()
   }
 
@@ -541,17 +564,23 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
 #pragma unroll
     for (int i = 0; i < RS_ROWS; ++i) {
       const double u0i = u0vec[i];
-      const float x0 = Cload(i0 + i, 0), x1 = Cload(i0 + i, 1);
-      const float q0 = __expf((float)(((double)x0 + u0i) + v00)), q1 = __expf((float)(((double)x1 + u0i) + v01));
-      P0[i] = ok0 ? q0 : 0.0f;          // rows >= n0: u0 = -1e300, the exponential is 0
-      P1[i] = ok1 ? q1 : 0.0f;
+      float xs[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xs[c] = Cload(i0 + i, c);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float q = __expf((float)(((double)xs[c] + u0i) + v0c[c]));
+        P[c][i] = ok[c] ? q : 0.0f;     // rows >= n0: u0 = -1e300, the exponential is 0
+      }
     }
     if (tid < RS_ROWS) pcvec[tid] = (i0 + tid < n0) ? __expf((float)(((double)alpha + u0vec[tid]) + v0d)) : 0.0f;
     if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
-    pd0 = ok0 ? __expf((float)(((double)alpha + u0d) + v00)) : 0.0f;
-    pd1 = ok1 ? __expf((float)(((double)alpha + u0d) + v01)) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      pd[c] = ok[c] ? __expf((float)(((double)alpha + u0d) + v0c[c])) : 0.0f;
+      bc[c] = ok[c] ? 1.0f : 0.0f;
+    }
     Pdd = __expf((float)(((double)alpha + u0d) + v0d));
-    b0 = ok0 ? 1.0f : 0.0f; b1 = ok1 ? 1.0f : 0.0f;
     bdust = 1.0f;
     __syncthreads();
   };
@@ -585,11 +614,11 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
     bdust = misc[0];
     RS_STAMP(0);
     {
-      const float sv = rs_rows32_sum([&](int r) { return fma_rn(P0[r], b0, P1[r] * b1); }, lane);
+      const float sv = rs_rows32_sum([&](int r) { return dotc([&](int c) { return P[c][r]; }, bc); }, lane);
       if ((lane & 1) == 0) rowpart[wv][rs_row_of_lane(lane)] = sv;
     }
     {
-      const float part = wave_sum_dpp_l63(fma_rn(pd0, b0, pd1 * b1));   // dustbin row: sum_j pd_j b_j
+      const float part = wave_sum_dpp_l63(dotc([&](int c) { return pd[c]; }, bc));   // dustbin row: sum_j pd_j b_j
       if (lane == 63) wsum[wv] = part;
     }
     RS_STAMP(1);
@@ -597,32 +626,35 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
     if (tid < RS_ROWS) {
       float r = rowpart[0][tid];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) r = r + rowpart[q][tid];
+      for (int q = 1; q < NWV; ++q) r = r + rowpart[q][tid];
       r = fma_rn(pcvec[tid], bdust, r);
       avec[tid] = (i0 + tid < n0) ? mu / r : 0.0f;
     }
     {
       float rd = wsum[0];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) rd = rd + wsum[q];
+      for (int q = 1; q < NWV; ++q) rd = rd + wsum[q];
       rd = fma_rn(Pdd, bdust, rd);
       ad = mu_d / rd;
     }
     __syncthreads();                      // avec written
     RS_STAMP(2);
     // ---------------- column pass: partial sums over the own 32 rows, all in registers
-    float creg0 = 0.0f, creg1 = 0.0f;
+    float creg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) creg[c] = 0.0f;
 #pragma unroll
     for (int q = 0; q < RS_ROWS / 4; ++q) {
       const f32x4 x = *(const f32x4 *)(avec + 4 * q);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        creg0 = fma_rn(x[e], P0[4 * q + e], creg0);
-        creg1 = fma_rn(x[e], P1[4 * q + e], creg1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) creg[c] = fma_rn(x[e], P[c][4 * q + e], creg[c]);
       }
     }
-    if (!ok0) creg0 = 0.0f;
-    if (!ok1) creg1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (!ok[c]) creg[c] = 0.0f;
     float cdust = 0.0f;
     if (wv == dust_wave) {                // the wave of the dustbin slot's owner (uniform branch)
 #pragma unroll
@@ -633,8 +665,9 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
       }
     }
     // ---------------- all-reduce of the 1025 column sums over the 32 workgroups of the pair (layout as above)
-    rs_store(xin + ((size_t)((c0 >> 5) * RS_WG + w) * 32 + (c0 & 31)), tag, dust0 ? cdust : creg0, near);
-    rs_store(xin + ((size_t)((c1 >> 5) * RS_WG + w) * 32 + (c1 & 31)), tag, dust1 ? cdust : creg1, near);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      rs_store(xin + ((size_t)((col[c] >> 5) * RS_WG + w) * 32 + (col[c] & 31)), tag, dust[c] ? cdust : creg[c], near);
     if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, near);
     RS_STAMP(3);
     if (wv == 0) {
@@ -662,11 +695,15 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
     __syncthreads();
     RS_STAMP(6);
     if (misc[1] != 0.0f) return;
-    const float csum0 = csumv[c0], csum1 = csumv[c1], csum2 = csumv[1024];
+    float csum_dust = csumv[1024];
     // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
-    b0 = ok0 ? nu / fma_rn(ad, pd0, csum0) : 0.0f;
-    b1 = ok1 ? nu / fma_rn(ad, pd1, csum1) : 0.0f;
-    if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, (n1 < RS_NP) ? (dust0 ? csum0 : csum1) : csum2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float cs = csumv[col[c]];
+      bc[c] = ok[c] ? nu / fma_rn(ad, pd[c], cs) : 0.0f;
+      if (dust[c]) csum_dust = cs;
+    }
+    if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, csum_dust);
     RS_STAMP(7);
     // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
     if (k == next_absorb && k < a.iters) {
@@ -675,8 +712,9 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
       bdust = misc[0];
       if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
       u0d = u0d + (double)__logf(ad);
-      if (ok0) v00 = v00 + (double)__logf(b0);
-      if (ok1) v01 = v01 + (double)__logf(b1);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (ok[c]) v0c[c] = v0c[c] + (double)__logf(bc[c]);
       v0d = v0d + (double)__logf(bdust);
       absorb();
     }
@@ -686,8 +724,9 @@ __global__ void __launch_bounds__(RG_T, MINW) sinkhorn_regs_kernel(RsArgs a) {
   bdust = misc[0];
   if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
   if (w == 0) {
-    if (ok0) a.v[(size_t)p * RS_LDC + c0] = (float)(v00 + (double)__logf(b0));
-    if (ok1) a.v[(size_t)p * RS_LDC + c1] = (float)(v01 + (double)__logf(b1));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (ok[c]) a.v[(size_t)p * RS_LDC + col[c]] = (float)(v0c[c] + (double)__logf(bc[c]));
     if (tid == 0) {
       a.u[(size_t)p * RS_LDC + n0] = (float)(u0d + (double)__logf(ad));
       a.v[(size_t)p * RS_LDC + n1] = (float)(v0d + (double)__logf(bdust));
@@ -755,8 +794,11 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // URF_SINKHORN_GROUP says otherwise; 2 = the same at 128 VGPRs (spills in the loop: slower); 0 = the LDS-resident kernel,
   // half the chip per launch.  Measured, 8 pairs, 100 iterations: 0.49 / 0.70 / 1.24 ms serialised and 1895 / 1820 / 1780
   // frames/s in the 3-stream pipeline
+  // 3 (default since round 3) = the register-resident kernel with FOUR columns per thread: 256 threads, one wave per SIMD at 270
+  // VGPRs without a spill, which leaves 240 registers of every SIMD lane to another stream's waves (measured against 1: 0.61 ->
+  // 0.53 ms serialised, +1 % in the pipeline at 640x480, even at 1241x376)
   static int regs = -1;
-  if (regs < 0) { const char *e = getenv("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 1; if (regs < 0 || regs > 2) regs = 1; }
+  if (regs < 0) { const char *e = getenv("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 3; if (regs < 0 || regs > 3) regs = 3; }
   int group = d.cus / RS_WG;
   if (regs) {
     const char *e = getenv("URF_SINKHORN_GROUP");
@@ -791,8 +833,9 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     }
     a.stamps = g_rs_stamps;
     URF_HIP(hipStreamWaitEvent(st, d.last, 0));
-    if (regs == 2) hipLaunchKernelGGL(sinkhorn_regs_kernel<4>, dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
-    else if (regs) hipLaunchKernelGGL(sinkhorn_regs_kernel<3>, dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
+    if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);
+    else if (regs == 2) hipLaunchKernelGGL((sinkhorn_regs_kernel<4, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
+    else if (regs) hipLaunchKernelGGL((sinkhorn_regs_kernel<3, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
