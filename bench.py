@@ -85,7 +85,7 @@ def pmc_traffic(kernel_label, resolution, prec):
     (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py) of this same command.  bench.py cannot collect counters about
     itself: the summary is the newest profiles/r*_pmc_hbm*.json for this resolution whose `source_sha` equals the
     sha of the kernel sources in this tree -- a summary taken on other kernels is refused (traffic = null)."""
-    tag = ("" if resolution == "640x480" else "_" + resolution) + ("_exact" if prec == 0 else "")
+    tag = ("" if resolution == "640x480" else "_" + resolution) + {0: "_exact", 1: "_fast", 2: "_guarded", 3: ""}[prec]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm{tag}.json")))
     if not files:
         return None, "no committed PMC summary for this resolution"
@@ -118,10 +118,13 @@ def main():
                     help="frames (and pairs) per GPU per step: 8 = BASELINE configs[2]; 4 with --gpus 8 and --resolution "
                          "1241x376 = configs[3] (batch 32 sharded over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", type=int, default=2, choices=[0, 1, 2],
-                    help="2 = guarded fast (default): split-f16 MFMA, and every frame / pair whose discrete decisions sit within "
-                         "the fast mode's error is redone in the exact mode inside the library (the reruns are inside the timed "
-                         "region); 1 = fast without the guard; 0 = exact fp32 (bit-identical to the oracle)")
+    ap.add_argument("--precision", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="3 = strict parity (default; the only mode besides 0 whose keypoints AND match index lists are the "
+                         "oracle's): SuperPoint in exact fp32, the matcher on the f16 matrix core (split operands), every pair with "
+                         "a decisive entry within the fast matcher's error of its alternative redone by the exact matcher inside the "
+                         "library, inside the timed region; 2 = guarded fast: fast SuperPoint with the top-k cut resolved in exact "
+                         "arithmetic (keypoint SET exact, order not), near-tied pairs flagged and NOT redone; 1 = fast without any "
+                         "guard; 0 = exact fp32 everywhere (every tensor bit-identical to the oracle)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
     ap.add_argument("--no-guard-calibration", action="store_true",
                     help="skip the check of the guard's error model before the timed region (counter-collection runs: its "
@@ -169,7 +172,8 @@ def main():
     spb = synth.pack_sp(synth.sp_weights(0))
     sgb = synth.pack_sg(synth.sg_weights(0))
     PREC = args.precision
-    FAST = PREC >= 1
+    FAST = PREC >= 1                  # the matcher runs on the f16 matrix core
+    SP_FAST = PREC in (1, 2)          # ... and so does SuperPoint (strict parity keeps it in exact fp32)
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
                       device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
@@ -182,7 +186,8 @@ def main():
     # it.  NB global batches are cycled.
     OVERLAP = int(os.environ.get("URF_BENCH_OVERLAP", "2"))
     MATCHERS = int(os.environ.get("URF_BENCH_MATCHERS", "2")) if OVERLAP == 2 else 1
-    NB = max(5, MATCHERS + 2)      # the ring (and with it the 40-frame stream the parity tests hold oracle results for) stays at 5 batches up to 3 matchers
+    AHEAD = int(os.environ.get("URF_BENCH_SP_AHEAD", "2")) if OVERLAP == 2 else 1   # batches SuperPoint is enqueued ahead of the matcher (pipeline.py)
+    NB = max(5, MATCHERS + 1 + AHEAD)      # the ring (and with it the 40-frame stream the parity tests hold oracle results for) stays at 5 batches for 2 matchers
     stream = synth.shift_stream(100, NB * BATCH * world, H, W)
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
@@ -191,8 +196,8 @@ def main():
     # guarded fast mode: the guard's error model is checked against the exact mode on this stream's own frames before anything is
     # timed (urf_sp_calibrate_guard_device: widens the constants if the frames need it; on these streams they hold as built)
     guard_model = None
-    CALIBRATE = PREC == 2 and not args.no_guard_calibration
-    if CALIBRATE:
+    CALIBRATE = PREC >= 2 and not args.no_guard_calibration
+    if CALIBRATE and PREC == 2:
         cal = [sp.calibrate_guard(device_ptr=d_frames[k * BATCH].data_ptr(), B=BATCH, rows=H, cols=W) for k in range(NB)]
         guard_model = {"delta_needed_by_the_stream": max(c_["delta_needed"] for c_ in cal),
                        "c_needed_by_the_stream": max(c_["c_needed"] for c_ in cal), "delta": cal[-1]["delta"], "c": cal[-1]["c"],
@@ -219,10 +224,11 @@ def main():
             dist.broadcast_object_list(ids, src=0)
         comm = D.Comm(world, rank, local_rank, ids[0])
     pipe = P.SlotRingPipeline(sp, pms, d_frames, BATCH, H, W, device=dev, rank=rank, world=world, comm=comm,
-                              gloo=exchange and not async_exchange, overlap=OVERLAP)
+                              gloo=exchange and not async_exchange, overlap=OVERLAP, sp_ahead=AHEAD)
     ring = pipe.ring
     if CALIBRATE:
         # ... and the matcher's margin against the exact matcher, on the first pairs of the stream (urf_pm_calibrate_guard)
+        guard_model = guard_model or {}
         pipe.sp_step(0); pipe.sp_step(1); sp.sync()
         c0 = [ring[0][j].data_ptr() for j in range(BATCH)]
         c1 = [ring[0][j + 1].data_ptr() for j in range(BATCH - 1)] + [ring[1][0].data_ptr()]
@@ -333,7 +339,7 @@ def main():
         Hc_, Wc_ = H // 2, W // 2
         conv1_gb = BATCH * (H * W + Hc_ * Wc_ * 64 * 4) / 1e9   # u8 frame in, pooled 64-channel map out (4 B/element)
         per_step = {   # name: (ms, GFLOP, GB) per step
-            ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if FAST else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
+            ("conv1a+conv1b fused (h2conv_kernel<pool,fuse1a>)" if SP_FAST else "conv1a+conv1b fused (conv_mfma_kernel<9,pool,fuse1a>)"):
                 (np.mean(conv1_ms), GF_CONV1 * BATCH, conv1_gb),
             ("SuperGlue linear layers (h2gemm_glds_kernel)" if FAST else "SuperGlue linear layers (gemm128 / conv_mfma_kernel<1>)"):
                 (np.mean(lin_ms), sg_linear_gflop(n_avg, n_avg) * BATCH,
@@ -358,23 +364,27 @@ def main():
                 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
         # fast mode: every product is 3 f16 MFMAs (hi*hi + hi*lo + lo*hi); the MFMA roof is priced on the
         # ALGORITHMIC flops (counted once), so its fraction is <= 1/3 by construction
-        peak_tf = F16_MFMA_PEAK_TF if FAST else FP32_MFMA_PEAK_TF
-        issue = 3 if FAST else 1
+        # Which roof: the dense contractions -- convolutions, linear layers, attention -- are priced on the
+        # MFMA roof of the instruction they run on, with the ALGORITHMIC flops counted once (a split-f16 product is three
+        # MFMAs, so those kernels cannot exceed 1/3: `mfma_issue_frac` is the same number times three); Sinkhorn on HBM.
+        def on_f16(name):
+            return ("h2" in name)
 
-        def roofs(ms_, gf_, gb_):
-            # (the few VALU flops of Sinkhorn are priced at the MFMA roof too: either way its HBM roof binds)
-            t_mfma, t_hbm = gf_ * issue / peak_tf, gb_ / HBM_PEAK_GBS * 1e3      # ms at each roof
-            return ("hbm" if t_hbm > t_mfma else "mfma"), t_mfma, t_hbm
+        def roofs(name, ms_, gf_, gb_):
+            peak_tf_ = F16_MFMA_PEAK_TF if on_f16(name) else FP32_MFMA_PEAK_TF
+            t_mfma, t_hbm = gf_ / peak_tf_, gb_ / HBM_PEAK_GBS * 1e3             # ms at each roof
+            return ("hbm" if "inkhorn" in name else "mfma"), t_mfma, t_hbm, peak_tf_
 
-        def frac_of(v):
-            b_, tm_, th_ = roofs(*v)
-            return max(tm_, th_) / v[0]           # minimum time at the binding roof / measured time
+        def frac_of(name, v):
+            b_, tm_, th_, _ = roofs(name, *v)
+            return (th_ if b_ == "hbm" else tm_) / v[0]       # minimum time at the family's roof / measured time
 
         # the kernel family reported = the one that loses the most time against its roof, ms x (1 - frac): stable from
         # run to run (the largest ms alone flips between two families that are within noise of each other)
-        dom = max(per_step, key=lambda k: per_step[k][0] * (1.0 - frac_of(per_step[k])))
+        dom = max(per_step, key=lambda k: per_step[k][0] * (1.0 - frac_of(k, per_step[k])))
         ms, gf, gb = per_step[dom]
-        bound, t_mfma, t_hbm = roofs(ms, gf, gb)      # the binding roof = the one with the larger minimum time
+        bound, t_mfma, t_hbm, peak_tf = roofs(dom, ms, gf, gb)
+        issue = 3 if on_f16(dom) else 1
         traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
         if bound == "hbm":
             achieved, peak, unit = gb / ms * 1e3, HBM_PEAK_GBS, "GB/s"
@@ -383,17 +393,19 @@ def main():
         roofline = {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
                     "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_note": traffic_src,
-                    "why_this_bound": f"minimum time at the HBM roof {t_hbm:.3f} ms vs at the MFMA roof {t_mfma:.3f} ms "
-                                      f"(algorithmic {gb:.2f} GB and {gf:.1f} GFLOP x{issue} MFMA per step)",
+                    "why_this_bound": f"SURVEY 8(d): dense contractions on the MFMA roof, Sinkhorn on HBM; for this family the minimum "
+                                      f"time at the MFMA roof is {t_mfma:.3f} ms (algorithmic {gf:.1f} GFLOP counted once; x{issue} MFMA "
+                                      f"instructions per product) and at the HBM roof {t_hbm:.3f} ms (byte model: {gb:.2f} GB per step)",
                     "tflops_logical": round(gf / ms, 2), "mfma_issue_frac": round(gf * issue / ms / peak_tf, 4),
+                    "hbm_model_frac": round(gb / ms * 1e3 / HBM_PEAK_GBS, 4),
                     "launch_ms": round(float(ms), 4), "algorithmic_gflop_per_step": round(gf, 2),
                     "algorithmic_gbytes_per_step": round(gb, 3),
                     "measured": "HIP events on the library stream, serialised 5-step pass right after the timed region "
                                 "(the timed region overlaps 3 streams; rocprofv3 --kernel-trace serialises as well)",
                     "in_timed_region_ms_per_step": {k: (round(v, 3) if v is not None else None) for k, v in insitu.items()},
                     "all_kernels": {k: {"ms_per_step": round(float(v[0]), 3), "tflops_logical": round(v[1] / v[0], 2),
-                                        "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(*v)[0],
-                                        "frac": round(frac_of(v), 4), "ms_below_roof": round(float(v[0] * (1 - frac_of(v))), 3)}
+                                        "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(k, *v)[0],
+                                        "frac": round(frac_of(k, v), 4), "ms_below_roof": round(float(v[0] * (1 - frac_of(k, v))), 3)}
                                     for k, v in per_step.items()}}
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
@@ -468,17 +480,18 @@ def main():
                         "frames_per_s": [round(total_frames / r, 2) for r in region_s],
                         "min": round(total_frames / max(region_s), 2), "max": round(total_frames / min(region_s), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
+            "dtype": ("f32 (SuperPoint, fp32 MFMA) + f16x2-split on the f16 MFMA with fp32 accumulate (matcher; flagged pairs redone in f32)"
+                      if PREC == 3 else "f16x2-split on the f16 MFMA, fp32 accumulate (fp32-equivalent; reference engine is TensorRT FP16)"
                       if FAST else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.resolution} grayscale stream, SuperPoint + SuperGlue match + 8-pt RANSAC, "
                                    f"batch={BATCH} frames/pairs per GPU per step (BASELINE.json "
                                    f"{'configs[3]: batch 32 over 8 GPUs' if (BATCH * world == 32 and args.resolution == '1241x376') else 'configs[2]'})",
                        "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
-                       "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": {0: "exact", 1: "fast", 2: "guarded fast"}[PREC],
+                       "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": {0: "exact", 1: "fast", 2: "guarded fast", 3: "strict parity"}[PREC],
                        "weights": "seeded synthetic (reference ships none)",
                        "streams": {0: "one in-order stream", 1: "2 streams: SP(b+1) beside Sinkhorn(b)",
-                                   2: "3 streams: Sinkhorn(b) beside GNN(b+1) and SP(b+2)"}[OVERLAP],
+                                   2: f"{1 + MATCHERS} streams: SuperPoint enqueued {AHEAD} batches ahead, {MATCHERS} matcher handles in turn"}[OVERLAP],
                        "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step (urf_comm_*, C ABI) + "
                                       f"gather of the match lists to rank 0"},
             "roofline": roofline,

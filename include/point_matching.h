@@ -16,6 +16,15 @@ class PointMatching {
       std::cout << "Erron in superglue building" << std::endl;
   }
   bool build(const float *blob, size_t n_floats) { return superglue.build(blob, n_floats); }
+  // Not in the reference: the guard word of the pair the last MatchingPoints call handled (urf_pm_near_tie_flags): 0 = its
+  // match list is the exact pipeline's; non-zero in the guarded fast mode (precision 2) = a decisive entry sat within the
+  // fast pipeline's error of its alternative and the list may differ there (in the strict mode, the default, such a pair
+  // was redone in exact arithmetic before the call returned: the word only says that this happened)
+  int last_near_tie_flags() {
+    int f = 0;
+    if (!superglue.handle() || urf_pm_near_tie_flags(superglue.handle(), &f, 1) != 0) return 0;
+    return f;
+  }
 
   // src/point_matching.cc:14-61
   int MatchingPoints(const Eigen::Matrix<double, 259, Eigen::Dynamic> &features0,

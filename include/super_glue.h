@@ -17,18 +17,16 @@
 #endif
 #include "urf.h"
 
-#ifndef URF_SHIM_PRECISION_DEFINED
-#define URF_SHIM_PRECISION_DEFINED
-#include <cstdlib>
-inline int urf_shim_precision() {   // URF_PRECISION = 2 (guarded fast, default) | 0 (exact) | 1 (fast); see super_point.h
-  const char *e = std::getenv("URF_PRECISION");
-  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
-}
-#endif
+#include "urf_shim.h"
 
 class SuperGlue {
  public:
-  explicit SuperGlue(const SuperGlueConfig &superglue_config) : superglue_config_(superglue_config) {}
+  explicit SuperGlue(const SuperGlueConfig &superglue_config) : superglue_config_(superglue_config) {
+    precision_ = urf_shim::split_engine_file(superglue_config.engine_file, &engine_path_);
+  }
+  // Not in the reference: the precision mode of the handle build() creates (urf_shim.h; default = strict parity)
+  void set_precision(int precision) { precision_ = precision; }
+  int precision() const { return precision_; }
   ~SuperGlue() { urf_pm_destroy(h_); }
   SuperGlue(const SuperGlue &) = delete;
   SuperGlue &operator=(const SuperGlue &) = delete;
@@ -66,7 +64,7 @@ class SuperGlue {
   void save_engine() {}
   bool deserialize_engine() {
     if (!h_) return false;
-    if (urf_pm_build_file(h_, superglue_config_.engine_file.c_str()) != 0) { report("deserialize_engine"); return false; }
+    if (urf_pm_build_file(h_, engine_path_.c_str()) != 0) { report("deserialize_engine"); return false; }
     return true;
   }
   urf_pm *handle() { return h_; }
@@ -77,12 +75,14 @@ class SuperGlue {
     c.image_width = superglue_config_.image_width;
     c.image_height = superglue_config_.image_height;
     c.matching_threshold = superglue_config_.matching_threshold;
-    c.precision = urf_shim_precision();
+    c.precision = precision_;
     if (urf_pm_create(&c, &h_) != 0) { report("create"); return false; }
     return true;
   }
   void report(const char *what) const { std::fprintf(stderr, "SuperGlue::%s: %s\n", what, urf_last_error()); }
   SuperGlueConfig superglue_config_;
+  std::string engine_path_;      // engine_file without the "#precision=N" suffix
+  int precision_ = URF_SHIM_PRECISION;
   urf_pm *h_ = nullptr;
 };
 

@@ -22,23 +22,16 @@
 #endif
 #include "urf.h"
 
-// Precision mode of the handles the shims create (the reference's config structs have no such field):
-// environment variable URF_PRECISION = 2 (the default: guarded fast -- the split-f16 matrix-core path at ~3x the exact mode's
-// throughput, with every decision of the SuperPoint tail that sits within its error resolved in exact arithmetic on the device,
-// so the keypoint set of every frame is the exact mode's, and near-tied pairs flagged), 0 (exact fp32:
-// every tensor bit-identical to the CPU oracle) or 1 (fast without the guard).
-#ifndef URF_SHIM_PRECISION_DEFINED
-#define URF_SHIM_PRECISION_DEFINED
-#include <cstdlib>
-inline int urf_shim_precision() {
-  const char *e = std::getenv("URF_PRECISION");
-  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
-}
-#endif
+#include "urf_shim.h"
 
 class SuperPoint {
  public:
-  explicit SuperPoint(const SuperPointConfig &super_point_config) : super_point_config_(super_point_config) {}
+  explicit SuperPoint(const SuperPointConfig &super_point_config) : super_point_config_(super_point_config) {
+    precision_ = urf_shim::split_engine_file(super_point_config.engine_file, &engine_path_);
+  }
+  // Not in the reference: the precision mode of the handle build() creates (urf_shim.h; default = strict parity)
+  void set_precision(int precision) { precision_ = precision; }
+  int precision() const { return precision_; }
   ~SuperPoint() { urf_sp_destroy(h_); }
   SuperPoint(const SuperPoint &) = delete;
   SuperPoint &operator=(const SuperPoint &) = delete;
@@ -52,7 +45,7 @@ class SuperPoint {
     c.keypoint_threshold = super_point_config_.keypoint_threshold;
     c.remove_borders = super_point_config_.remove_borders;
     c.max_height = 1500; c.max_width = 1500;  // TensorRT profile maximum, :55-60
-    c.max_batch = 1; c.device = 0; c.precision = urf_shim_precision();
+    c.max_batch = 1; c.device = 0; c.precision = precision_;
     if (urf_sp_create(&c, &h_) != 0) { report("create"); return false; }
     if (!deserialize_engine()) { urf_sp_destroy(h_); h_ = nullptr; return false; }
     return true;
@@ -63,7 +56,7 @@ class SuperPoint {
     c.max_keypoints = super_point_config_.max_keypoints;
     c.keypoint_threshold = super_point_config_.keypoint_threshold;
     c.remove_borders = super_point_config_.remove_borders;
-    c.max_height = max_h; c.max_width = max_w; c.max_batch = 1; c.device = 0; c.precision = urf_shim_precision();
+    c.max_height = max_h; c.max_width = max_w; c.max_batch = 1; c.device = 0; c.precision = precision_;
     if (urf_sp_create(&c, &h_) != 0) { report("create"); return false; }
     if (urf_sp_build(h_, blob, n_floats) != 0) { report("build"); urf_sp_destroy(h_); h_ = nullptr; return false; }
     return true;
@@ -74,7 +67,7 @@ class SuperPoint {
   // after build() with a few representative frames when the weights are not the ones the built-in constants were measured on.
   bool calibrate_guard(const cv::Mat &image) {
     if (!h_) return false;
-    if (urf_shim_precision() != 2) return true;
+    if (precision_ != 2) return true;
     const uint8_t *p = image.data;
     if (urf_sp_calibrate_guard(h_, 1, &p, image.rows, image.cols, (size_t)image.step, nullptr) != 0) { report("calibrate_guard"); return false; }
     return true;
@@ -135,13 +128,15 @@ class SuperPoint {
   void save_engine() {}  // the weight container is written by tooling (urf_weights_save)
   bool deserialize_engine() {
     if (!h_) return false;
-    if (urf_sp_build_file(h_, super_point_config_.engine_file.c_str()) != 0) { report("deserialize_engine"); return false; }
+    if (urf_sp_build_file(h_, engine_path_.c_str()) != 0) { report("deserialize_engine"); return false; }
     return true;
   }
 
  private:
   void report(const char *what) const { std::fprintf(stderr, "SuperPoint::%s: %s\n", what, urf_last_error()); }
   SuperPointConfig super_point_config_;
+  std::string engine_path_;      // engine_file without the "#precision=N" suffix
+  int precision_ = URF_SHIM_PRECISION;
   urf_sp *h_ = nullptr;
   std::vector<double> buf_;
   std::vector<std::vector<int>> keypoints_;

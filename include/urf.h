@@ -52,8 +52,16 @@ typedef struct {
    * of their cells and the band's members are ranked by their exact scores.  Any other near-tie: the frame is redone
    * in the exact mode inside the library before its slot is handed on.  Slot header word 1 says which: 1 = redone
    * whole, 2 = cut resolved per candidate, 0 = the fast pass stands.  Either way the
-   * keypoint SET of every frame is the exact mode's.  urf_sp_near_tie_reruns() counts both. */
+   * keypoint SET of every frame is the exact mode's.  urf_sp_near_tie_reruns() counts both.
+   * 3 = strict parity: the value a pipeline passes to BOTH handles when keypoints and match
+   * index lists must be the oracle's.  For SuperPoint it is the exact mode (slots bit-identical to the oracle: scores,
+   * order, descriptors); the matcher's half is described at urf_sg_config.precision. */
   int precision;
+  /* guarded fast mode (precision 2), error model of a fast-mode heat-map value s: |fast - exact| <= guard_delta s (1 - s) +
+   * guard_ulps ulp(s).  0 = the constants measured on the bench streams (1.6e-4, 8; urf_build_info() prints them);
+   * urf_sp_calibrate_guard() widens either where a deployment's frames need it.  (Appended fields; all-zero = defaults.) */
+  float guard_delta;
+  float guard_ulps;
 } urf_sp_config;
 
 typedef struct urf_sp urf_sp;
@@ -132,10 +140,14 @@ typedef struct {
    * accuracy, not bit-reproducible); 2 = guarded fast: as 1, and a pair in which a row's or
    * column's best assignment lies within the fast PIPELINE's error (5e-4 on the log-assignment: the fast matcher's own
    * error plus what the fast SuperPoint's descriptor noise induces) of the matching threshold or of its runner-up is
-   * flagged: urf_pm_near_tie_flags() names the pairs of the batch just fetched, urf_pm_near_tie_reruns() counts them.
-   * Pairs that are not flagged have the exact pipeline's match set.  A flagged pair is one whose decisive entries the
-   * reference's own arithmetic decides by rounding noise; with URF_GUARD_REDO_PAIRS=1 it is also redone with the exact
-   * matcher on the same slots (in the stream, behind the fast pass, as one HIP graph launch). */
+   * FLAGGED, not redone: urf_pm_near_tie_flags() names the pairs of the batch just fetched, urf_pm_near_tie_reruns()
+   * counts them.  Pairs that are not flagged have the exact pipeline's match set; a flagged pair keeps the fast lists
+   * unless redo_flagged_pairs = 1.
+   * 3 = strict parity, for slots made by an exact-mode SuperPoint (precision 0 or 3): the fast
+   * matcher with its margin shrunk to the matcher's OWN error (2.2e-4; the inputs carry no noise), and every flagged pair
+   * redone by the exact matcher on the same slots inside the library, behind the fast pass, before the lists are handed
+   * out.  The redo's inputs are bit-identical to the oracle's, so its lists are the oracle's: every pair's match list
+   * equals the exact mode's index for index. */
   int precision;
   /* the reference call's own parameters (appended fields; all-zero = the reference's values):
    * ransac_threshold_px: distance to the epipolar line in pixels, findFundamentalMat's 3rd argument.  Used when
@@ -146,6 +158,13 @@ typedef struct {
    *   ransac_iterations hypotheses count (EpipolarGeometry::_find_F). */
   float ransac_threshold_px;
   float ransac_confidence;
+  /* guard of the fast matcher (precision 2 and 3; appended fields, all-zero = the mode's defaults):
+   * redo_flagged_pairs: 0 = the mode's default (2: flagged pairs are reported only; 3: redone in the exact mode),
+   *   1 = redo them, -1 = never redo (precision 2 only; precision 3 without the redo is not strict and is refused).
+   * guard_margin: the margin on the log-assignment within which a decisive entry counts as near-tied; 0 = the mode's
+   *   default (2: 5e-4, 3: 2.2e-4).  urf_pm_calibrate_guard() widens it where a deployment's pairs need it. */
+  int redo_flagged_pairs;
+  float guard_margin;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -384,6 +403,10 @@ int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, s
  * feat: NULL or nframes matrices of 259 x URF_MAX_KEYPOINTS f64 (column-major). */
 int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat);
 int urf_fe_in_flight(urf_fe *h);
+/* 1 if the NEXT urf_fe_submit may name global frame `frame` in `ref` (its slot is still in the ring: one of the last
+ * 2 + history_batches SUBMITS, whatever their sizes), 0 if not, <0 on error.  A caller that tracks keyframes asks here
+ * instead of counting frames (batches are ragged), and matches the host features of a frame that has left the ring. */
+int urf_fe_frame_resident(urf_fe *h, long frame);
 urf_sp *urf_fe_superpoint(urf_fe *h);
 urf_pm *urf_fe_matcher(urf_fe *h, int i);
 
@@ -469,6 +492,8 @@ int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, flo
 int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
 /* test hook: the next `launches` resident Sinkhorn launches of this process report a give-up (exercises the recovery above) */
 int urf_probe_sinkhorn_fault(int launches);
+/* test hook: matcher handles built after this call stay on the streaming Sinkhorn for `batches` batches after a give-up (0 = the default, 64) */
+int urf_probe_sinkhorn_backoff(int batches);
 /* roof probe: the split-f16 MFMA inner loop, `waves_per_cu` in {4, 8, 16}: PFLOP/s of MFMA issue and the in-kernel clock the
  * chip holds under that load.  mode 0 = register-resident operands, no memory; 1 = plus the linear-layer kernel's fragment reads
  * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM */

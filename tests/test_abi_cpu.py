@@ -254,7 +254,8 @@ def test_integration_patches_apply_to_the_reference(tmp_path):
     added = set(re.findall(r"^\+.*?\b(urf_[a-z_]+)\(", text, re.M))
     assert {"urf_fe_create", "urf_fe_build_files", "urf_fe_submit", "urf_fe_collect", "urf_fe_destroy"} <= added
     from conftest import load_pkg
-    assert added - {"urf_shim_precision"} <= set(load_pkg()._lib.SYMBOLS)
+    assert added <= set(load_pkg()._lib.SYMBOLS)
+    assert "urf_fe_frame_resident(" in text and "getenv" not in text
     assert "usleep(30000)" in text and "-        usleep(30000);" in text
     if not os.path.isdir(ref) or not shutil.which("patch"):
         pytest.skip("reference tree (or patch) not available here")

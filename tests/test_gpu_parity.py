@@ -314,16 +314,19 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     fr[0].tofile(f0p)
     fr[1].tofile(f1p)
     vis = str(tmp_path / "keypoints")
-    out = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W), vis], text=True,
-                                  env=dict(os.environ, URF_PRECISION="0")).strip().split("\n")
-    # the shims pick the precision mode from URF_PRECISION (default: 2, the guarded fast mode): the fast handles give the same
-    # lists here
-    for mode in ("1", None):
-        env = dict(os.environ)
-        env.pop("URF_PRECISION", None)
-        if mode:
-            env["URF_PRECISION"] = mode
-        fast = subprocess.check_output([exe, spw, sgw, f0p, f1p, str(H), str(W)], text=True, env=env).strip().split("\n")
+    # the shims take the precision mode from a "#precision=N" suffix of engine_file (include/urf_shim.h), never from the environment
+    run = lambda sfx, *extra: subprocess.check_output([exe, spw + sfx, sgw + sfx, f0p, f1p, str(H), str(W), *extra], text=True,  # noqa: E731
+                                                      env=dict(os.environ, URF_PRECISION="1")).strip().split("\n")
+    out = run("#precision=0", vis)
+    # the DEFAULT of the drop-in headers is the strict-parity mode: the same keypoints in the same order and the same match
+    # index list as the exact mode, line for line (distances within the fast matcher's error)
+    strict = run("")
+    assert strict[0] == out[0] and len(strict) == len(out)
+    assert [l.split()[:2] for l in strict[1:]] == [l.split()[:2] for l in out[1:]]
+    assert max(abs(float(a.split()[2]) - float(b.split()[2])) for a, b in zip(strict[1:], out[1:])) < 1e-3
+    assert run("#precision=3") == strict
+    for sfx in ("#precision=1", "#precision=2"):
+        fast = run(sfx)
         # same counts; keypoint INDICES may differ where near-tied scores swap places in the score-sorted list
         same = sum(a.split()[:2] == b.split()[:2] for a, b in zip(fast[1:], out[1:]))
         assert fast[0] == out[0] and same >= 0.95 * (len(out) - 1)
@@ -594,7 +597,7 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("prec", [0, 1, 2, 3])
 def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec):
     """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
     SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)
@@ -623,7 +626,7 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
     coords = lambda lst, f0, f1: {(f0[q, 1], f0[q, 2], f1[t_, 1], f1[t_, 2]) for q, t_, _ in lst}   # noqa: E731
     for t in range(21):
         assert got_K[t] == ofeats[t].shape[0]
-        if prec == 0:
+        if prec in (0, 3):
             assert np.array_equal(got_f[t].astype(np.float32), ofeats[t].astype(np.float32))
         else:
             assert {(r[1], r[2]) for r in got_f[t]} == {(r[1], r[2]) for r in ofeats[t]}, t
@@ -631,6 +634,10 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
             ref = olists[t - 1]
             if prec == 0:
                 assert _as_tuples(got_m[t]) == ref, t
+            elif prec == 3:      # strict parity: the oracle's index list, position for position
+                got = _as_tuples(got_m[t])
+                assert [(q, t_) for q, t_, _ in got] == [(q, t_) for q, t_, _ in ref], t
+                assert np.abs(np.array([d for _, _, d in got]) - np.array([d for _, _, d in ref])).max() < 1e-3, t
             else:
                 a, b = coords(_as_tuples(got_m[t]), got_f[t - 1], got_f[t]), coords(ref, ofeats[t - 1], ofeats[t])
                 assert len(a & b) >= 0.99 * len(a | b), t
@@ -674,6 +681,36 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
     assert _as_tuples(fs.collect()[1][3]) == olists[11]
+
+
+def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg_blob):
+    """integration/tracking.patch's keyframe logic, restated: a live queue drains ONE frame per submit, the keyframe stays the
+    same for a long time, and the caller asks urf_fe_frame_resident() whether it may still name it.  The ring is counted in
+    submits (2 + history_batches = 4 here), not in frames: after four 1-frame submits the keyframe is gone although only four
+    frames (half a batch) have passed.  No submit may fail, and the answer must flip exactly when submit would start refusing."""
+    frames = np.stack(U.synth.shift_stream(29, 9, 240, 320, step=(0, 0)))
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=300), F.SuperGlueConfig(), batch=8, max_height=240, max_width=320,
+                       history_batches=2)
+    assert fs.build(sp_blob, sg_blob)
+    assert not fs.frame_resident(0)                      # nothing submitted yet
+    fs.submit(frames[0:1])                               # frame 0 = the keyframe
+    fs.collect()
+    seen = []
+    for t in range(1, 9):
+        ok = fs.frame_resident(0)
+        seen.append(ok)
+        if ok:
+            fs.submit(frames[t:t + 1], ref=[0])
+            K, m = fs.collect()
+            assert len(m[0]) > 100                       # matched against the keyframe (a static scene)
+        else:
+            with pytest.raises(RuntimeError, match="left the ring"):
+                fs.submit(frames[t:t + 1], ref=[0])      # what the frame-count arithmetic of round 3 would have done
+            assert fs.in_flight() == 0
+            fs.submit(frames[t:t + 1])                   # predecessor instead: the stream goes on
+            fs.collect()
+    assert seen == [True] * 4 + [False] * 4, seen
+    assert not fs.frame_resident(-1) and not fs.frame_resident(9)
 
 
 # ------------------------------------------------------------------ error behaviour of the boundary

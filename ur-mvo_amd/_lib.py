@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liburf_front.so")
+# URF_LIB: tools/ point this at the experiments build (liburf_front_exp.so, `make -C ur-mvo_amd/csrc experiments`) for A/B runs
+SO_PATH = os.environ.get("URF_LIB") or os.path.join(_HERE, "liburf_front.so")
 
 # every symbol include/urf.h declares
 SYMBOLS = [
@@ -22,11 +23,11 @@ SYMBOLS = [
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync", "urf_cam_size",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
-    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
+    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
     "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
-    "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_probe_sinkhorn_fault",
+    "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_probe_sinkhorn_fault", "urf_probe_sinkhorn_backoff",
     "urf_probe_sinkhorn_stamps", "urf_sg_debug_couplings", "urf_probe_mfma_roof", "urf_probe_h2gemm_xflags", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
 ]
 
@@ -34,14 +35,15 @@ SYMBOLS = [
 class SPConfig(C.Structure):
     _fields_ = [("max_keypoints", C.c_int), ("keypoint_threshold", C.c_double), ("remove_borders", C.c_int),
                 ("max_height", C.c_int), ("max_width", C.c_int), ("max_batch", C.c_int), ("device", C.c_int),
-                ("precision", C.c_int)]
+                ("precision", C.c_int), ("guard_delta", C.c_float), ("guard_ulps", C.c_float)]
 
 
 class SGConfig(C.Structure):
     _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("matching_threshold", C.c_double),
                 ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
-                ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float)]
+                ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
+                ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float)]
 
 
 class EpiConfig(C.Structure):

@@ -342,7 +342,7 @@ int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth
   // still gives a workgroup per CU (16 images x 4 heads x 4 query blocks = 256), else 1 tile x 8 waves.
   static int forced = -2;
   if (forced == -2) {
-    const char *e = getenv("URF_ATTN_VARIANT");
+    const char *e = urf::exp_env("URF_ATTN_VARIANT");
     forced = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
   }
   const int variant = forced >= 0 ? forced : (nimg >= 16 ? 2 : 0);

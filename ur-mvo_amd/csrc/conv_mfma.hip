@@ -460,7 +460,7 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     grid.x = (a.W + TH * TW - 1) / (TH * TW);
   }
   // the redo pass of the guarded fast mode (target-gated launches: a handful of live tiles): 16 output channels per workgroup
-  static const bool split_env = [] { const char *e = getenv("URF_GUARD_SPLIT"); return !e || atoi(e) != 0; }();
+  static const bool split_env = [] { const char *e = urf::exp_env("URF_GUARD_SPLIT"); return !e || atoi(e) != 0; }();
   const bool split = split_env && taps == 9 && !fuse1a && a.gate && a.t_scale > 0;   // (conv1: its fused first layer would be redone per quarter)
   grid.y = split ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
   grid.z = batch;

@@ -163,6 +163,25 @@ static int fe_enqueue_match(urf_fe *h, urf_fe::Pending &p) {
   return 0;
 }
 
+// Would the NEXT urf_fe_submit accept global frame `frame` as a reference?  The same test submit applies to a reference
+// outside its own batch: the frame sits in a ring entry that is not the one about to be refilled and is at most
+// NB - M - 1 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
+// drain --, so the window cannot be derived from a frame count; integration/tracking.patch asks here).
+static const uint8_t *fe_resident_slot(urf_fe *h, long want) {
+  const long b = h->next_batch;
+  const int k = (int)(b % h->NB);
+  for (int e = 0; e < h->NB; ++e)
+    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 1) && want >= h->batch_first[e] &&
+        want < h->batch_first[e] + h->batch_n[e])
+      return slot_ptr(h, e, (int)(want - h->batch_first[e]));
+  return nullptr;
+}
+extern "C" int urf_fe_frame_resident(urf_fe *h, long frame) {
+  URF_CHECK(h && h->built, "urf_fe_frame_resident: handle is not built");
+  if (frame < 0 || frame >= h->frames_seen) return 0;
+  return fe_resident_slot(h, frame) ? 1 : 0;
+}
+
 // Submit n <= batch frames (host u8, row stride `step`; frame stride `frame_stride` bytes).
 // ref: NULL, or n global frame indices: frame j is matched against frame ref[j] (-1 = its predecessor).
 // A referenced frame must be in this batch or in one of the 2 + history_batches batches before it.
@@ -199,10 +218,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
     } else {
       // window = the last NB - M - 1 batches: an older ring entry may be refilled by SuperPoint while
       // this batch's matcher (up to M submits behind) still reads it; entry k is being refilled now
-      for (int e = 0; e < h->NB && !src; ++e)
-        if (e != k && h->batch_id[e] >= b - (h->NB - h->M - 1) && want >= h->batch_first[e] &&
-            want < h->batch_first[e] + h->batch_n[e])
-          src = slot_ptr(h, e, (int)(want - h->batch_first[e]));
+      src = fe_resident_slot(h, want);
     }
     URF_CHECK(src, "urf_fe_submit: reference frame %ld has left the ring (history_batches too small)", want);
     s0.push_back(src);

@@ -393,7 +393,7 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
   // measured (tools/gpu_h2probe.py, 16384 rows): LDS-DMA 128x128 174-276 TFLOP/s logical > register-staged 128x128
   // 155-251 > register-staged 64x128 140-193 at every shape of the path
   if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
-    const char *e = getenv("URF_H2GEMM_VARIANT");
+    const char *e = urf::exp_env("URF_H2GEMM_VARIANT");
     g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
   }
   const int variant = g_h2gemm_variant;
@@ -403,7 +403,7 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     // 64 KiB: two stages of four planes (+ URF_H2GEMM_LDS_PAD bytes: occupancy experiments -- a padded workgroup keeps
     // its CU to itself and leaves registers / LDS for another stream's kernel)
     static long pad = -1;
-    if (pad < 0) { const char *e = getenv("URF_H2GEMM_LDS_PAD"); pad = e ? atol(e) : 0; if (pad < 0 || pad > 96 * 1024) pad = 0; }
+    if (pad < 0) { const char *e = urf::exp_env("URF_H2GEMM_LDS_PAD"); pad = e ? atol(e) : 0; if (pad < 0 || pad > 96 * 1024) pad = 0; }
     const size_t lds = sizeof(_Float16) * 2 * 4 * GP + (size_t)pad;
     dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
     static DeviceOnce attr_set;
@@ -421,9 +421,9 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     // token-major launch (measurement only: what two half tiles per resident slot cost against one full tile -- the K loop of the
     // "persistent two-tile" variant of DESIGN.md section 8)
     static int balance = -1;
-    if (balance < 0) { const char *e = getenv("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 2; }
+    if (balance < 0) { const char *e = urf::exp_env("URF_H2GEMM_BALANCE"); balance = e ? atoi(e) : 2; }
     static int nt = -1;
-    if (nt < 0) { const char *e = getenv("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
+    if (nt < 0) { const char *e = urf::exp_env("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;
     b.xflags = g_h2gemm_xflags | nt;
     if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768)

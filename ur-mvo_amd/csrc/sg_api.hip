@@ -6,6 +6,7 @@
 #include "h2.h"
 
 #include <math.h>
+#include <chrono>
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,8 +35,6 @@ int launch_decode(const int *counts, const float *C, const float *Ct, const floa
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
                   int P, hipStream_t st);
-int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st);
-int launch_guard_merge(const int *gflags, const void *rm, const int *rn, void *fm, int *fn, int P, hipStream_t st);
 int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st);
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
                   float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
@@ -54,6 +53,13 @@ static const double kQScale = 0.125 * 1.4426950408889634;   // fast mode: log2(e
 // "Guarded fast mode", tools/gpu_margins.py)
 static const float kGuardSgZ = 5e-4f;
 static const float kGuardSgDescNoise = 2.4e-4f;   // the descriptor-noise share of it (not measurable inside the matcher)
+// strict parity mode (precision 3): the slots come from the exact SuperPoint, so only the matcher's own error counts
+// (measured maximum 2.0e-4 on the entries a decision can rest on, both bench streams) with 10 % on top
+static const float kGuardSgZStrict = 2.2e-4f;
+
+static int g_backoff_override = 0;
+// test hook: handles built after this call stay on the streaming Sinkhorn for `batches` batches after a give-up (0 = the default, 64)
+extern "C" int urf_probe_sinkhorn_backoff(int batches) { g_backoff_override = batches; return 0; }
 
 struct urf_pm {
   urf_sg_config cfg;
@@ -110,26 +116,29 @@ struct urf_pm {
   const float **h_slotptrs = nullptr;
   hipEvent_t ev[PT_COUNT + 1];
   hipEvent_t ev_attn[18][2];
-  float stage_ms[PT_COUNT + 1];
+  float stage_ms[PT_COUNT + 2];      // [PT_COUNT + 1]: the exact redo of the batch's flagged pairs (host time: enqueue + wait)
   bool ev_valid = false;
   int pending_P = 0;     // pairs of the batch enqueued by urf_match_device_async and not fetched yet (0 = none)
-  // guarded fast mode (precision 2): per-pair guard words (device + pinned mirror), the masked counts and the result
-  // buffers of the exact redo, counters ([0] pairs redone, [1] pairs seen (host side), [2] threshold margin, [3] runner-up)
-  bool fast = false, guarded = false;
-  int *g_flags = nullptr, *h_gflags = nullptr, *counts_r = nullptr, *r_nfinal = nullptr;
-  urf_dmatch *r_fmatches = nullptr;
-  unsigned long long *g_stats = nullptr;
+  // guarded modes (precision 2, 3): per-pair guard words (device + pinned mirror), counters
+  bool fast = false, guarded = false, strict = false;
+  int *g_flags = nullptr, *h_gflags = nullptr;
   unsigned long long pairs_seen = 0;
   float g_z = 0.0f;
-  // the exact redo of a device batch as ONE graph launch behind the fast pass (pm_guard_stream), one graph per (pairs, outlier stage)
-  struct RedoGraph { int P; bool ransac; hipGraph_t graph; hipGraphExec_t exec; };
-  std::vector<RedoGraph> redo_graphs;
-  bool redo_in_stream = false;     // the last batch's redo ran in the stream: nothing left to do at fetch time
-  int graph_mode = -1;             // URF_GUARD_GRAPH: 1 (default) = captured graph, 0 = the same launches one by one
-  // what happens to a flagged pair: 0 (default) = it is reported (urf_pm_near_tie_flags, counters) -- the exact matcher on the
-  // same slots could still differ from the oracle there, because the fast SuperPoint's descriptor noise moves those entries as
-  // much as the fast matcher does; 1 (URF_GUARD_REDO_PAIRS=1) = it is also redone in the exact mode
+  // what happens to a flagged pair (urf_sg_config.redo_flagged_pairs): 0 (precision 2's default) = it is reported
+  // (urf_pm_near_tie_flags, counters) -- with slots from the FAST SuperPoint the exact matcher could still differ from the
+  // oracle there, because the descriptor noise moves those entries as much as the fast matcher does; 1 (precision 3 always) = it
+  // is redone in the exact mode, which on exact slots IS the oracle's result
   int redo_pairs = 0;
+  // The redo engine: an exact-mode handle of its own (own arena, this handle's stream).  When the host holds the guard words
+  // of a batch (urf_pm_fetch, or the end of a host call) and some pair is flagged, the encoded keypoints of just the
+  // flagged pairs are copied over, the exact pipeline runs with launch grids sized for THOSE pairs, and its lists replace
+  // the fast ones.  Nothing is enqueued for a batch without a flagged pair.  (Round 4 measured the alternative -- the exact
+  // pass enqueued unconditionally behind every fast pass over all 8 pairs, unflagged ones masked to zero counts on the
+  // device -- at 4 ms of stream time per batch for ~300 launches that do nothing and 12 ms when one pair of eight was
+  // flagged, against 4.5 ms for the pair alone: DESIGN.md section 12.)
+  urf_pm *redo = nullptr;
+  unsigned long long pairs_redone = 0, cause_thr = 0, cause_run = 0;
+  float redo_ms = 0.0f;            // host time of the last batch's redo (enqueue + wait), profiling
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
   bool flags_recorded = false;
   unsigned long long pairs_flagged = 0;
@@ -164,9 +173,18 @@ extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
     URF_CHECK(h->r_conf < 1.0, "ransac_confidence must be below 1");
   }
   h->precision = cfg->precision;
-  URF_CHECK(h->precision >= 0 && h->precision <= 2, "precision must be 0 (exact fp32), 1 (fast split-f16) or 2 (fast, guarded)");
+  if (!(h->precision >= 0 && h->precision <= 3)) {
+    delete h;
+    URF_CHECK(false, "precision must be 0 (exact fp32), 1 (fast split-f16), 2 (fast, guarded) or 3 (strict parity)");
+  }
   h->fast = h->precision >= 1;
-  h->guarded = h->precision == 2;
+  h->guarded = h->precision >= 2;
+  h->strict = h->precision == 3;
+  if (h->strict && cfg->redo_flagged_pairs < 0) {
+    delete h;
+    URF_CHECK(false, "precision 3 (strict parity) without the exact redo of flagged pairs is not strict: redo_flagged_pairs must be 0 or 1");
+  }
+  if (cfg->guard_margin < 0.0f) { delete h; URF_CHECK(false, "guard_margin must not be negative"); }
   *out = h;
   return 0;
 }
@@ -176,7 +194,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   URF_CHECK(n_floats == URF_SG_BLOB_FLOATS, "SG blob has %zu floats, expected %d", n_floats, URF_SG_BLOB_FLOATS);
   URF_CHECK(!h->built, "urf_pm_build: already built");
   URF_HIP(hipSetDevice(h->device));
-  URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  if (const char *e = urf::exp_env("URF_PM_PRIORITY")) URF_HIP(hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, atoi(e)));
+  else URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   URF_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   URF_HIP(hipEventCreateWithFlags(&h->ev_sink, hipEventDisableTiming));
   URF_HIP(hipEventCreateWithFlags(&h->ev_ext, hipEventDisableTiming));
@@ -327,21 +346,20 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       h->rs_on = false;
     }
     h->rs_wanted = h->rs_on;
-    if (const char *e = getenv("URF_SINKHORN_BACKOFF")) { const int v = atoi(e); if (v >= 1) h->rs_backoff_next = v; }   // tests
+    if (g_backoff_override >= 1) h->rs_backoff_next = g_backoff_override;   // tests (urf_probe_sinkhorn_backoff)
     h->rs_xin_bytes = sinkhorn_resident_xin_granules((int)P) * sizeof(unsigned long long);
     h->rs_xbc_bytes = sinkhorn_resident_xbc_granules((int)P) * sizeof(unsigned long long);
     if (dalloc(&h->rs_xin, sinkhorn_resident_xin_granules((int)P)) || dalloc(&h->rs_xbc, sinkhorn_resident_xbc_granules((int)P))) return -1;
   }
   if (h->guarded) {
-    if (dalloc(&h->g_flags, P) || dalloc(&h->counts_r, NI) || dalloc(&h->r_nfinal, P) || dalloc(&h->r_fmatches, P * NP) ||
-        dalloc(&h->g_stats, 8))
-      return -1;
+    if (dalloc(&h->g_flags, P)) return -1;
     URF_HIP(hipHostMalloc((void **)&h->h_gflags, P * sizeof(int), hipHostMallocDefault));
     memset(h->h_gflags, 0, P * sizeof(int));
-    const char *e = getenv("URF_GUARD_SG_Z");
-    h->g_z = e ? (float)atof(e) : kGuardSgZ;
-    e = getenv("URF_GUARD_REDO_PAIRS");
-    h->redo_pairs = e ? (atoi(e) != 0) : 0;
+    // margin and redo policy come from the configuration (urf_sg_config.guard_margin / redo_flagged_pairs), never from the
+    // environment: they decide what the handle guarantees
+    h->g_z = h->cfg.guard_margin > 0.0f ? h->cfg.guard_margin : (h->strict ? kGuardSgZStrict : kGuardSgZ);
+    h->redo_pairs = h->cfg.redo_flagged_pairs != 0 ? (h->cfg.redo_flagged_pairs > 0) : (h->strict ? 1 : 0);
+    if (const char *e = urf::exp_env("URF_REDO_OFF"); e && atoi(e) != 0) h->redo_pairs = 0;   // what-if timing runs (experiments build): results are NOT strict
     URF_CHECK(P <= 64, "guarded fast mode: max_pairs %zu above 64", P);
     memset(h->last_flags, 0, sizeof(h->last_flags));
   }
@@ -401,6 +419,16 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   // for: without this a first call could run before (or while) its buffers are being cleared
   URF_HIP(hipDeviceSynchronize());
   h->built = true;
+  if (h->guarded && h->redo_pairs) {
+    // the redo engine (see urf_pm::redo): an exact-mode handle with the same configuration and weights, on THIS handle's stream
+    urf_sg_config rc = h->cfg;
+    rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
+    if (urf_pm_create(&rc, &h->redo)) return -1;
+    if (urf_pm_build(h->redo, blob, n_floats)) return -1;
+    (void)hipStreamDestroy(h->redo->st);
+    h->redo->st = h->st;
+    h->redo->own_stream = false;
+  }
   return 0;
 }
 
@@ -412,6 +440,9 @@ extern "C" int urf_pm_build_file(urf_pm *h, const char *path) {
 
 extern "C" void urf_pm_destroy(urf_pm *h) {
   if (!h) return;
+  if (h->built && h->st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->st); }
+  urf_pm_destroy(h->redo);      // (runs on this handle's stream: before that stream goes)
+  h->redo = nullptr;
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
@@ -420,10 +451,9 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
-                    h->g_flags, h->counts_r, h->r_nfinal, h->r_fmatches, h->g_stats};
+                    h->g_flags};
     for (void *p : bufs) (void)hipFree(p);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
-    for (const urf_pm::RedoGraph &g : h->redo_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     (void)hipHostFree(h->h_matches);
     (void)hipHostFree(h->h_n);
     (void)hipHostFree(h->h_rs_err);
@@ -497,7 +527,7 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
     // SIMD, and loses against two h2gemm launches at four waves per SIMD -- 1.87 vs 1.77 ms per 8 pairs serialised,
     // 1590 vs 1720 frames/s in the 3-stream pipeline (it also keeps the other streams' kernels off its CUs).
     static int fused = -1;
-    if (fused < 0) { const char *e = getenv("URF_GNN_FUSED"); fused = e ? (atoi(e) != 0) : 0; }
+    if (fused < 0) { const char *e = urf::exp_env("URF_GNN_FUSED"); fused = e ? (atoi(e) != 0) : 0; }
     if (fused) {
       // merge + MLP0 + ReLU + MLP1 + residual in ONE launch, the hidden activations stay in LDS (h2mlp.hip)
       if (launch_h2mlp(h->xh, h->xl, h->oh, h->ol, h->d_wh + h->H[l].w1, h->d_wl + h->H[l].w1, h->d_wh + h->H[l].w2,
@@ -524,7 +554,7 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
   return 0;
 }
 
-static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast, bool redo);
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast);
 
 // keypoint encoder: 4(3)->32->64->128->256->256, + descriptors; fp32 in every mode
 static int pm_kenc(urf_pm *h, int NI) {
@@ -573,22 +603,20 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
       return -1;
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
-  h->redo_in_stream = false;
   h->flags_recorded = false;
   h->pairs_seen += (unsigned long long)P;
-  return pm_tail(h, P, want_Z, ransac, prof, h->fast, false);
+  return pm_tail(h, P, want_Z, ransac, prof, h->fast);
 }
 
 // scores -> Sinkhorn -> decode -> outlier stage, from the projected descriptors h->mdesc (which stay in place until the next
 // pm_pipeline of this handle: pm_check_resident can run this again).  fast: the fast mode's Sinkhorn and, when the handle is
-// guarded, the near-tie guard of the decode.  redo: the exact pass of the guarded mode over the flagged pairs -- the final
-// lists go to the redo buffers (the fast lists of the other pairs stay where they are).
-static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast, bool redo) {
+// guarded, the near-tie guard of the decode.
+static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast) {
   hipStream_t st = h->st;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
-  if (!redo) (void)hipEventRecord(h->ev_sink, st);
+  (void)hipEventRecord(h->ev_sink, st);
   if (fast && h->rs_on) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
     if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
@@ -597,7 +625,7 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
   } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, fast, st)) return -1;
   mark(PT_DECODE);
-  const bool guard = fast && h->guarded && !redo;
+  const bool guard = fast && h->guarded;
   if (guard) URF_HIP(hipMemsetAsync(h->g_flags, 0, P * sizeof(int), st));
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
                     h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,
@@ -607,80 +635,63 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   mark(PT_RANSAC);
   if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
                     h->cfg.ransac_seed, h->r_iters, h->r_sigma, h->r_conf, nullptr, ransac ? 1 : 0, h->matches,
-                    redo ? h->r_fmatches : h->fmatches, redo ? h->r_nfinal : h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
+                    h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
     return -1;
   mark(PT_COUNT);
   return 0;
 }
 
-// The exact pass over the flagged pairs of a batch of P pairs, as stream work: the counts of all other pairs are masked to
-// zero on the device, so every kernel skips them -- the 18 layers from the encoded keypoints (h->x still holds them: the
-// fast layers work on their own f16 planes), the final projection, log-domain Sinkhorn, decode, outlier stage into the redo
-// buffers, and the merge of the redone lists over the fast ones.
-static int pm_redo_launches(urf_pm *h, int P, bool want_Z, bool ransac, bool in_place) {
-  if (launch_guard_counts(h->g_flags, h->counts, h->counts_r, P, h->g_stats, h->st)) return -1;
-  int *full = h->counts;
-  h->counts = h->counts_r;
-  int rc = pm_gnn_exact(h, 2 * P, false);
-  if (!rc) rc = sg_linear(h, 2 * P, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr);
-  if (!rc) rc = pm_tail(h, P, want_Z, ransac, false, false, !in_place);
-  h->counts = full;
-  if (rc) return -1;
-  if (!in_place && launch_guard_merge(h->g_flags, h->r_fmatches, h->r_nfinal, h->fmatches, h->nfinal, P, h->st)) return -1;
-  return 0;
-}
-
-// Guarded fast mode, device batches: the exact pass is enqueued behind the fast one unconditionally -- the host never waits to
-// learn whether a pair was flagged, and when none was (the usual case) its ~300 kernels find zero counts and exit at once.
-// They are captured once per (pairs, outlier stage) into a HIP graph: one launch call instead of 300.
-static int pm_guard_stream(urf_pm *h, int P, bool ransac) {
-  if (!h->guarded || !h->redo_pairs) return 0;
-  if (h->graph_mode < 0) { const char *e = getenv("URF_GUARD_GRAPH"); h->graph_mode = e ? atoi(e) : 1; }
-  h->redo_in_stream = true;
-  if (h->graph_mode == 0) return pm_redo_launches(h, P, false, ransac, false);
-  for (const urf_pm::RedoGraph &g : h->redo_graphs)
-    if (g.P == P && g.ransac == ransac) { URF_HIP(hipGraphLaunch(g.exec, h->st)); return 0; }
-  // first batch of this shape: run the launches once directly (one-time kernel attributes are set outside a capture), then capture
-  if (pm_redo_launches(h, P, false, ransac, false)) return -1;
-  urf_pm::RedoGraph g = {P, ransac, nullptr, nullptr};
-  if (hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->graph_mode = 0; return 0; }
-  const int rc = pm_redo_launches(h, P, false, ransac, false);
-  const hipError_t ec = hipStreamEndCapture(h->st, &g.graph);
-  if (rc || ec != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    fprintf(stderr, "liburf_front: could not capture the guarded mode's redo pass into a HIP graph; using plain launches\n");
-    h->graph_mode = 0;
-    return 0;
-  }
-  h->redo_graphs.push_back(g);
-  return 0;
-}
-
-// Guarded fast mode, host APIs (one pair, results read back right away), after the results have been waited for (and after
-// pm_check_resident): a flagged pair is redone in the exact mode and the exact results simply replace the fast ones, Z and
-// index vectors included.  Device batches took the in-stream pass above.  Returns 1 when results were rewritten (the caller
-// repeats its copies), 0 when there was nothing to do.
-static int pm_guard_redo(urf_pm *h, bool in_place) {
+// The redo of a batch's flagged pairs, once the host holds the guard words (h->h_gflags: the batch's fast pass has been waited
+// for).  The flagged pairs' encoded keypoints (h->x after pm_kenc: fp32 in every mode, and untouched by the fast layers, which
+// work on their own f16 planes), counts and pixel coordinates go to slots 0 .. n - 1 of the redo engine; its exact pipeline
+// runs over those n pairs; its lists -- and, for the one-pair host calls, its index vectors, scores and log-assignment --
+// replace the fast ones in this handle's buffers.  Returns 1 when results were rewritten (the caller repeats its copies), 0
+// when there was nothing to do.
+static int pm_guard_redo(urf_pm *h) {
   if (!h->guarded || h->last_P < 1) return 0;
   const int P = h->last_P;
   if (!h->flags_recorded) {             // (a second call after a redo finds the pinned words cleared: keep the recorded ones)
     for (int p = 0; p < P && p < 64; ++p) { h->last_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
     h->flags_recorded = true;
   }
-  if (!h->redo_pairs) {
-    for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
-    return 0;
-  }
-  if (h->redo_in_stream) {
-    for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
-    return 0;
-  }
-  bool any = false;
-  for (int p = 0; p < P; ++p) any = any || h->h_gflags[p] != 0;
-  if (!any) return 0;
-  if (pm_redo_launches(h, P, h->last_Z, h->last_ransac, in_place)) return -1;
-  URF_HIP(hipStreamSynchronize(h->st));
+  h->redo_ms = 0.0f;
+  int idx[64], n = 0;
+  for (int p = 0; p < P; ++p)
+    if (h->h_gflags[p]) idx[n++] = p;
   for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
+  if (!h->redo_pairs || n == 0) return 0;
+  urf_pm *r = h->redo;
+  URF_CHECK(r && r->built && r->st == h->st, "the redo engine of this handle is not built");
+  const auto t0 = std::chrono::steady_clock::now();
+  hipStream_t st = h->st;
+  for (int k = 0; k < n; ++k) {
+    const int p = idx[k];
+    h->cause_thr += (h->last_flags[p] & 1) != 0;
+    h->cause_run += (h->last_flags[p] & 2) != 0;
+    URF_HIP(hipMemcpyAsync(r->counts + 2 * k, h->counts + 2 * p, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(r->kxy + (size_t)2 * k * NP * 2, h->kxy + (size_t)2 * p * NP * 2, (size_t)2 * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(r->x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  // the exact layers, the final projection and the tail over n pairs (grids sized for n, not for the batch)
+  if (pm_gnn_exact(r, 2 * n, false)) return -1;
+  if (sg_linear(r, 2 * n, r->x, 256, 256, nullptr, 0, 0, r->wf, r->bf, 256, r->mdesc, 256, false, nullptr)) return -1;
+  r->last_P = n; r->last_Z = h->last_Z; r->last_ransac = h->last_ransac;
+  if (pm_tail(r, n, h->last_Z, h->last_ransac, false, false)) return -1;
+  for (int k = 0; k < n; ++k) {
+    const int p = idx[k];
+    URF_HIP(hipMemcpyAsync(h->nfinal + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->fmatches + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
+  }
+  if (P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
+    URF_HIP(hipMemcpyAsync(h->idx0, r->idx0, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->idx1, r->idx1, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->ms0, r->ms0, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->ms1, r->ms1, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (h->last_Z) URF_HIP(hipMemcpyAsync(h->Z, r->Z, (size_t)(NP + 1) * LDC * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  URF_HIP(hipStreamSynchronize(st));
+  h->pairs_redone += (unsigned long long)n;
+  h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 1;
 }
 
@@ -706,18 +717,17 @@ static int pm_check_resident(urf_pm *h) {
           "co-resident within 0.25 s); batch redone with the streaming kernels, which this handle keeps for the next %d batches "
           "(give-up %d of this handle)\n", h->last_P, h->rs_backoff, h->rs_fallbacks);
   URF_CHECK(h->last_P >= 1, "resident Sinkhorn gave up and there is no batch to redo");
-  if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast, false)) return -1;
-  if (h->redo_in_stream && pm_guard_stream(h, h->last_P, h->last_ransac)) return -1;   // the redone tail has new guard words
-  URF_HIP(hipStreamSynchronize(h->st));
+  if (pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast)) return -1;
+  URF_HIP(hipStreamSynchronize(h->st));   // (the redone tail has new guard words: pm_guard_redo reads them next)
   return 1;
 }
 
 // after a batch's results have been waited for: the resident Sinkhorn's give-up, then the guarded mode's near-ties.
 // > 0: device results were rewritten (the caller repeats its copies); < 0: error
-static int pm_after_wait(urf_pm *h, bool in_place) {
+static int pm_after_wait(urf_pm *h) {
   const int r1 = pm_check_resident(h);
   if (r1 < 0) return -1;
-  const int r2 = pm_guard_redo(h, in_place);
+  const int r2 = pm_guard_redo(h);
   if (r2 < 0) return -1;
   return r1 + r2;
 }
@@ -735,6 +745,7 @@ static void pm_collect_times(urf_pm *h) {
     if (hipEventElapsedTime(&ms, h->ev_attn[l][0], h->ev_attn[l][1]) == hipSuccess) at += ms;
   }
   h->stage_ms[PT_COUNT] = at;
+  h->stage_ms[PT_COUNT + 1] = 0.0f;    // (the redo of this batch, if any, happens after this point: urf_pm_stage_ms reads redo_ms)
   h->ev_valid = true;
 }
 
@@ -799,7 +810,7 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
                                hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipStreamSynchronize(h->st));
     if (pass == 0) pm_collect_times(h);
-    const int redo = pm_after_wait(h, true);
+    const int redo = pm_after_wait(h);
     if (redo < 0) return -3;
     if (redo == 0) break;
   }
@@ -823,7 +834,7 @@ extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, 
     URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipStreamSynchronize(h->st));
     if (pass == 0) pm_collect_times(h);
-    const int redo = pm_after_wait(h, true);
+    const int redo = pm_after_wait(h);
     if (redo < 0) return -3;
     if (redo == 0) break;
   }
@@ -850,7 +861,6 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
                            h->x, h->st))
     return -1;
   if (pm_pipeline(h, P, false, outlier_rejection != 0)) return -1;
-  if (pm_guard_stream(h, P, outlier_rejection != 0)) return -1;
   URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
   URF_HIP(hipEventRecord(h->ev_done, h->st));
@@ -862,8 +872,9 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
 // log-assignments on the entries a decision can rest on (probability above 0.1 in either), the margin widened where needed.
 extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1, double *out) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
-  URF_CHECK(h->guarded, "urf_pm_calibrate_guard: the handle is not in the guarded fast mode (precision 2)");
+  URF_CHECK(h->guarded, "urf_pm_calibrate_guard: the handle is not in a guarded mode (precision 2 or 3)");
   URF_CHECK(P >= 1 && P <= h->maxP && d_slots0 && d_slots1, "urf_pm_calibrate_guard: bad argument");
+  URF_CHECK(h->pending_P == 0, "urf_pm_calibrate_guard: a batch is in flight (urf_pm_fetch it first): the calibration reuses its buffers");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));
   hipStream_t st = h->st;
@@ -873,9 +884,17 @@ extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slo
   }
   URF_HIP(hipMemcpyAsync(h->d_slotptrs, h->h_slotptrs, 2 * P * sizeof(float *), hipMemcpyHostToDevice, st));
   if (launch_sg_prep_slots(h->d_slotptrs, 2 * P, h->cfg.image_width, h->cfg.image_height, h->counts, h->kin, h->kxy, h->x, st)) return -1;
+  // (not a batch of the caller's stream: the bookkeeping of the last handed-out batch survives the call)
   const unsigned long long seen = h->pairs_seen;
+  const int keep_P = h->last_P;
+  const bool keep_Z = h->last_Z, keep_ransac = h->last_ransac, keep_rec = h->flags_recorded;
+  struct Restore {
+    urf_pm *h; int P; bool Z, ransac, rec;
+    ~Restore() { h->last_P = P; h->last_Z = Z; h->last_ransac = ransac; h->flags_recorded = rec;
+                 for (int p = 0; p < h->maxP && p < 64; ++p) h->h_gflags[p] = 0; }
+  } restore{h, keep_P, keep_Z, keep_ransac, keep_rec};
   if (pm_pipeline(h, P, true, false)) return -1;                      // the fast pass, Z kept
-  h->pairs_seen = seen;                                               // (not a batch of the caller's stream)
+  h->pairs_seen = seen;
   URF_HIP(hipStreamSynchronize(st));
   if (h->h_rs_err && h->h_rs_err[0] != 0) {                           // the resident Sinkhorn gave up: nothing to measure against
     (void)pm_check_resident(h);
@@ -887,10 +906,11 @@ extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slo
   URF_HIP(hipMalloc((void **)&zf, zbytes));
   if (hipMalloc((void **)&acc, sizeof(int)) != hipSuccess) { (void)hipFree(zf); URF_CHECK(false, "urf_pm_calibrate_guard: out of device memory"); }
   int rc = hipMemcpyAsync(zf, h->Z, zbytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -1;
-  // the exact pass from the same encoded keypoints (h->x: the fast layers work on their own planes), lists to the redo buffers
+  // the exact pass from the same encoded keypoints (h->x: the fast layers work on their own planes), in this handle's own
+  // buffers (no batch is in flight; the device lists of the last fetched batch are overwritten)
   if (!rc) rc = pm_gnn_exact(h, 2 * P, false);
   if (!rc) rc = sg_linear(h, 2 * P, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr);
-  if (!rc) rc = pm_tail(h, P, true, false, false, false, true);
+  if (!rc) rc = pm_tail(h, P, true, false, false, false);
   float worst = 0.0f;
   if (!rc) rc = hipMemsetAsync(acc, 0, sizeof(int), st) == hipSuccess ? 0 : -1;
   if (!rc) rc = launch_guard_z_calib(h->counts, zf, h->Z, logf(0.1f), acc, P, st);
@@ -899,7 +919,7 @@ extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slo
   (void)hipFree(zf);
   (void)hipFree(acc);
   URF_CHECK(rc == 0, "urf_pm_calibrate_guard: a launch or copy failed");
-  const float need = 1.10f * (worst + kGuardSgDescNoise);
+  const float need = 1.10f * (worst + (h->strict ? 0.0f : kGuardSgDescNoise));   // (strict parity: exact slots, no descriptor noise)
   if (need > h->g_z) h->g_z = need;
   if (out) { out[0] = worst; out[1] = h->g_z; }
   return 0;
@@ -910,10 +930,7 @@ extern "C" int urf_pm_sinkhorn_fallbacks(const urf_pm *h) { return h ? h->rs_fal
 extern "C" int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n) {
   URF_CHECK(h && h->built && out && n >= 1, "urf_pm_near_tie_reruns: bad argument");
   unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (h->guarded) {
-    URF_HIP(hipSetDevice(h->device));
-    URF_HIP(hipMemcpy(v, h->g_stats, sizeof(v), hipMemcpyDeviceToHost));   // written by redo passes only, which are synchronous
-  }
+  v[0] = h->pairs_redone; v[2] = h->cause_thr; v[3] = h->cause_run;     // (host counters: the redo is driven from the host)
   v[1] = h->pairs_seen;
   v[4] = h->pairs_flagged;
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
@@ -942,7 +959,7 @@ extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nou
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
   {
-    const int redo = pm_after_wait(h, false);
+    const int redo = pm_after_wait(h);
     if (redo < 0) return -3;
     if (redo > 0) {   // the tail was redone (streaming Sinkhorn after a give-up, or flagged pairs in the exact mode): fetch the rewritten lists
       URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
@@ -1031,8 +1048,9 @@ extern "C" int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, co
 extern "C" int urf_pm_stage_ms(urf_pm *h, float *ms, int n) {
   URF_CHECK(h && ms, "urf_pm_stage_ms: null");
   URF_CHECK(h->ev_valid, "no timed call yet (urf_set_profiling(1) before the call)");
-  for (int i = 0; i < n && i <= PT_COUNT; ++i) ms[i] = h->stage_ms[i];
-  return PT_COUNT + 1;
+  h->stage_ms[PT_COUNT + 1] = h->redo_ms;
+  for (int i = 0; i < n && i <= PT_COUNT + 1; ++i) ms[i] = h->stage_ms[i];
+  return n < PT_COUNT + 2 ? n : PT_COUNT + 2;
 }
 
 // Put this matcher on the SuperPoint handle's stream: SP(b) -> match(b) -> SP(b+1)
@@ -1047,6 +1065,7 @@ extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
   if (h->own_stream) (void)hipStreamDestroy(h->st);
   h->st = (hipStream_t)st;
   h->own_stream = false;
+  if (h->redo) h->redo->st = h->st;
   return 0;
 }
 

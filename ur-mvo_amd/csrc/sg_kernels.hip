@@ -576,28 +576,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
   if (i == 0) nmatch[p] = total;
 }
 
-// ----------------------------------------------------------------- guard redo
-// counts of the pairs to redo in the exact mode (the others get 0: every kernel of the path skips them); stats: [0] pairs
-// redone, [1] pairs seen, [2] flagged by the threshold margin, [3] by the runner-up margin
-__global__ void guard_counts_kernel(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats) {
-  const int i = threadIdx.x;
-  if (i < 2 * P) counts_r[i] = gflags[i >> 1] ? counts[i] : 0;
-  if (i == 0) {
-    int n = 0, a = 0, b = 0;
-    for (int p = 0; p < P; ++p) { n += gflags[p] != 0; a += (gflags[p] & 1) != 0; b += (gflags[p] & 2) != 0; }
-    atomicAdd(&stats[0], (unsigned long long)n);
-    atomicAdd(&stats[2], (unsigned long long)a);
-    atomicAdd(&stats[3], (unsigned long long)b);
-  }
-}
-// the redone pairs' lists replace the fast ones
-__global__ void __launch_bounds__(256) guard_merge_kernel(const int *gflags, const DMatch *rm, const int *rn, DMatch *fm, int *fn) {
-  const int p = blockIdx.x;
-  if (!gflags[p]) return;
-  const int n = rn[p];
-  for (int i = threadIdx.x; i < n; i += 256) fm[(size_t)p * NP + i] = rm[(size_t)p * NP + i];
-  if (threadIdx.x == 0) fn[p] = n;
-}
+// ----------------------------------------------------------------- guard calibration
 // Calibration of the matcher's margin: the largest |Z_fast - Z_exact| over the entries of the log-assignment matrices (keypoint
 // rows and columns, no dustbins) that either pass holds above log_floor -- the entries a decision can rest on.
 __global__ void __launch_bounds__(256) guard_z_calib_kernel(const int *counts, const float *zf, const float *zx, float log_floor,
@@ -617,16 +596,6 @@ __global__ void __launch_bounds__(256) guard_z_calib_kernel(const int *counts, c
 }
 int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st) {
   hipLaunchKernelGGL(guard_z_calib_kernel, dim3(128, P), dim3(256), 0, st, counts, zf, zx, log_floor, out);
-  URF_HIP(hipGetLastError());
-  return 0;
-}
-int launch_guard_counts(const int *gflags, const int *counts, int *counts_r, int P, unsigned long long *stats, hipStream_t st) {
-  hipLaunchKernelGGL(guard_counts_kernel, dim3(1), dim3(256), 0, st, gflags, counts, counts_r, P, stats);
-  URF_HIP(hipGetLastError());
-  return 0;
-}
-int launch_guard_merge(const int *gflags, const void *rm, const int *rn, void *fm, int *fn, int P, hipStream_t st) {
-  hipLaunchKernelGGL(guard_merge_kernel, dim3(P), dim3(256), 0, st, gflags, (const DMatch *)rm, rn, (DMatch *)fm, fn);
   URF_HIP(hipGetLastError());
   return 0;
 }
@@ -656,7 +625,7 @@ int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u
   // 1 row/wave 1332 frames/s, 1024 workgroups 1385, 512 -> 1358, 256 -> 1319 in the 3-stream pipeline)
   static int target = -1;
   if (target < 0) {
-    const char *e = getenv("URF_SINKHORN_BLOCKS");   // tuning knob for A/B runs
+    const char *e = urf::exp_env("URF_SINKHORN_BLOCKS");   // tuning knob for A/B runs
     target = e ? atoi(e) : 1024;
     if (target < 1) target = 1024;
   }

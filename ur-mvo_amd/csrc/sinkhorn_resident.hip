@@ -753,7 +753,7 @@ size_t sinkhorn_resident_xbc_granules(int maxP) { return (size_t)maxP * RS_XBC; 
 int sinkhorn_resident_enabled() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("URF_SINKHORN_RESIDENT");
+    const char *e = urf::exp_env("URF_SINKHORN_RESIDENT");
     v = e ? (atoi(e) != 0) : 1;
   }
   return v;
@@ -798,15 +798,15 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // VGPRs without a spill, which leaves 240 registers of every SIMD lane to another stream's waves (measured against 1: 0.61 ->
   // 0.53 ms serialised, +1 % in the pipeline at 640x480, even at 1241x376)
   static int regs = -1;
-  if (regs < 0) { const char *e = getenv("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 3; if (regs < 0 || regs > 3) regs = 3; }
+  if (regs < 0) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 3; if (regs < 0 || regs > 3) regs = 3; }
   int group = d.cus / RS_WG;
   if (regs) {
-    const char *e = getenv("URF_SINKHORN_GROUP");
+    const char *e = urf::exp_env("URF_SINKHORN_GROUP");
     const int want = e ? atoi(e) : 0;
     if (want >= 1 && want < group) group = want;
   } else {
     static int knob = -1;
-    if (knob < 0) { const char *e = getenv("URF_SINKHORN_GROUP"); knob = e ? atoi(e) : 0; }
+    if (knob < 0) { const char *e = urf::exp_env("URF_SINKHORN_GROUP"); knob = e ? atoi(e) : 0; }
     const int want = knob >= 1 ? knob : (group >= 2 ? group / 2 : group);
     if (want < group) group = want;
   }
@@ -828,7 +828,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     a.salt = *salt; a.err = err;
     {
       static int near_knob = -1;
-      if (near_knob < 0) { const char *e = getenv("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 0; }
+      if (near_knob < 0) { const char *e = urf::exp_env("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 0; }
       a.allow_near = near_knob;
     }
     a.stamps = g_rs_stamps;

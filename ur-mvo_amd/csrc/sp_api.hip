@@ -167,8 +167,13 @@ extern "C" int urf_sp_create(const urf_sp_config *cfg, urf_sp **out) {
   h->maxB = cfg->max_batch > 0 ? cfg->max_batch : 1;
   h->maxH = cfg->max_height > 0 ? cfg->max_height : 1500;
   h->maxW = cfg->max_width > 0 ? cfg->max_width : 1500;
-  h->precision = cfg->precision;
-  URF_CHECK(h->precision >= 0 && h->precision <= 2, "precision must be 0 (exact fp32), 1 (fast split-f16) or 2 (fast, guarded)");
+  // precision 3 (strict parity) IS the exact mode for SuperPoint: slots bit-identical to the oracle (scores, order, descriptors)
+  h->precision = cfg->precision == 3 ? 0 : cfg->precision;
+  if (!(cfg->precision >= 0 && cfg->precision <= 3) || cfg->guard_delta < 0.0f || cfg->guard_ulps < 0.0f) {
+    delete h;
+    URF_CHECK(false, "precision must be 0 (exact fp32), 1 (fast split-f16), 2 (fast, guarded) or 3 (strict parity = exact here); "
+                     "guard_delta / guard_ulps must not be negative");
+  }
   *out = h;
   return 0;
 }
@@ -187,7 +192,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
   URF_HIP(hipSetDevice(h->device));
   {
     // URF_SP_PRIORITY (experiments): HIP stream priority of the handle's stream (hipDeviceGetStreamPriorityRange; lower = sooner)
-    const char *e = getenv("URF_SP_PRIORITY");
+    const char *e = urf::exp_env("URF_SP_PRIORITY");
     if (e) URF_HIP(hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, atoi(e)));
     else URF_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   }
@@ -332,7 +337,7 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     // guarded fast mode: a second arena for the frames redone in the exact mode (every frame of a batch can be), the guard
     // words and the redo list.  Error model of a fast-mode score (sp_kernels.hip): measured by tools/gpu_margins.py on
     // both bench streams (DESIGN.md "Guarded fast mode"), overridable for experiments.
-    const char *e2s = getenv("URF_SP_TWO_STREAMS");
+    const char *e2s = urf::exp_env("URF_SP_TWO_STREAMS");
     const bool two_streams = e2s && atoi(e2s) != 0;
     if (arena(h->R, false) || (two_streams && arena(h->A2, true))) return -1;
     URF_CHECK(B <= (size_t)kGateMax, "guarded fast mode: max_batch %zu above %d", B, kGateMax);
@@ -349,13 +354,13 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     // a second stream beside the next call's fast pass, with two alternating fast arenas.  Same box, 640x480, frames/s: unguarded
     // 1900-1940; guarded on one stream 1757; on two streams 1508 -- and 1619 even with nothing flagged (1921 on one stream): the
     // second arena set and the cross-stream events cost more than the chain's latency
-    if (const char *e2 = getenv("URF_SP_TWO_STREAMS"); e2 && atoi(e2) != 0) URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
+    if (const char *e2 = urf::exp_env("URF_SP_TWO_STREAMS"); e2 && atoi(e2) != 0) URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
     URF_HIP(hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[0], hipEventDisableTiming));
     URF_HIP(hipEventCreateWithFlags(&h->ev_tail[1], hipEventDisableTiming));
-    const char *e;
-    h->g_delta = (e = getenv("URF_GUARD_SP_DELTA")) ? (float)atof(e) : kGuardSpDelta;
-    h->g_ulps = (e = getenv("URF_GUARD_SP_ULPS")) ? (float)atof(e) : kGuardSpUlps;
+    // the error model's constants come from the configuration (urf_sp_config.guard_delta / guard_ulps), never from the environment
+    h->g_delta = h->cfg.guard_delta > 0.0f ? h->cfg.guard_delta : kGuardSpDelta;
+    h->g_ulps = h->cfg.guard_ulps > 0.0f ? h->cfg.guard_ulps : kGuardSpUlps;
   }
   if (dalloc(&h->d_feat, B * (size_t)kCap * 259)) return -1;
   if (dalloc(&h->d_slots, B * kSlotFloats)) return -1;

@@ -3,12 +3,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <string>
 
 namespace urf {
 
 void set_error(const char *fmt, ...);
+
+// The A/B knobs of the kernel experiments (URF_SINKHORN_*, URF_H2GEMM_*, URF_ATTN_VARIANT, ...) are read
+// from the environment only in a build made with `make EXTRA=-DURF_EXPERIMENTS`; the product build never reads the
+// environment -- what a handle computes and guarantees is decided by its configuration struct alone (include/urf.h).
+inline const char *exp_env(const char *name) {
+#ifdef URF_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // "once per device" guard for hipFuncSetAttribute: the attribute belongs to the (kernel, device) pair, and the library may
 // drive several devices from several host threads.  Doing the work twice is harmless (idempotent), skipping it is not.

@@ -54,10 +54,14 @@ class SuperGlueConfig:
 class SuperPoint:
     """SuperPoint (include/super_point.h:20-33)."""
 
-    def __init__(self, super_point_config, max_height=0, max_width=0, max_batch=1, device=0, precision=0):
+    def __init__(self, super_point_config, max_height=0, max_width=0, max_batch=1, device=0, precision=0,
+                 guard_delta=0.0, guard_ulps=0.0):
+        """precision: 0 exact, 1 fast, 2 guarded fast, 3 strict parity (= exact for SuperPoint); guard_delta / guard_ulps: the
+        guarded mode's error model (urf_sp_config; 0 = the built-in constants)"""
         self.cfg = super_point_config
         self._c = SPConfig(super_point_config.max_keypoints, super_point_config.keypoint_threshold,
-                           super_point_config.remove_borders, max_height, max_width, max_batch, device, precision)
+                           super_point_config.remove_borders, max_height, max_width, max_batch, device, precision,
+                           guard_delta, guard_ulps)
         self._h = C.c_void_p()
         self._built = False
         check(_lib.lib().urf_sp_create(C.byref(self._c), C.byref(self._h)), "urf_sp_create")
@@ -171,18 +175,21 @@ class SuperPoint:
 
 SP_STAGES = ["upload", "conv1a+1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa|Da",
              "convPb", "convDb", "softmax", "nms", "select", "desc_norm", "sample", "download"]
-PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac", "attn(in gnn)"]
+PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac", "attn(in gnn)", "exact redo of flagged pairs"]
 
 
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
-                 ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0):
+                 ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0,
+                 redo_flagged_pairs=0, guard_margin=0.0):
         """outlier stage: all-zero = the reference call's parameters (3 px, confidence 0.99, src/point_matching.cc:50);
-        ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count"""
+        ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count.
+        precision: 0 exact, 1 fast, 2 guarded fast (flagged pairs reported), 3 strict parity (flagged pairs redone in the
+        exact mode); redo_flagged_pairs / guard_margin: urf_sg_config (0 = the mode's defaults)"""
         self.cfg = cfg
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
                            max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision,
-                           ransac_threshold_px, ransac_confidence)
+                           ransac_threshold_px, ransac_confidence, redo_flagged_pairs, guard_margin)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 
@@ -448,13 +455,14 @@ class FrameStream:
 
     def __init__(self, sp_cfg, sg_cfg, batch=8, max_height=0, max_width=0, device=0, precision=0, matchers=2,
                  history_batches=0, outlier_rejection=True, sinkhorn_iterations=100, ransac_iterations=200,
-                 ransac_sigma=0.0, ransac_seed=0, ransac_threshold_px=0.0, ransac_confidence=0.0):
+                 ransac_sigma=0.0, ransac_seed=0, ransac_threshold_px=0.0, ransac_confidence=0.0,
+                 redo_flagged_pairs=0, guard_margin=0.0, guard_delta=0.0, guard_ulps=0.0):
         c = _lib.FEConfig()
         c.sp = SPConfig(sp_cfg.max_keypoints, sp_cfg.keypoint_threshold, sp_cfg.remove_borders, max_height, max_width,
-                        batch, device, precision)
+                        batch, device, precision, guard_delta, guard_ulps)
         c.sg = SGConfig(sg_cfg.image_width, sg_cfg.image_height, sg_cfg.matching_threshold, sinkhorn_iterations, batch,
                         device, ransac_iterations, ransac_sigma, ransac_seed, precision, ransac_threshold_px,
-                        ransac_confidence)
+                        ransac_confidence, redo_flagged_pairs, guard_margin)
         c.batch, c.matchers, c.history_batches, c.outlier_rejection = batch, matchers, history_batches, int(outlier_rejection)
         self.batch = batch
         self._h = C.c_void_p()
@@ -500,6 +508,10 @@ class FrameStream:
 
     def in_flight(self):
         return _lib.lib().urf_fe_in_flight(self._h)
+
+    def frame_resident(self, frame):
+        """may the next submit() name global frame `frame` as a reference? (its slot is still in the ring)"""
+        return check(_lib.lib().urf_fe_frame_resident(self._h, C.c_long(int(frame))), "urf_fe_frame_resident") == 1
 
 
 def SearchByProjection(camera_fxfycxcy, image_size, pose, features, mappoint_positions, mappoint_descriptors, thr,

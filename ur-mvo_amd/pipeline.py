@@ -28,20 +28,26 @@ from . import _lib
 
 class SlotRingPipeline:
     def __init__(self, sp, pms, d_frames, batch, H, W, *, device, rank=0, world=1, comm=None, gloo=False, overlap=2,
-                 outlier_rejection=True, keep_gathered=False):
+                 outlier_rejection=True, keep_gathered=False, sp_ahead=2):
         """sp / pms: built SuperPoint / PointMatching handles on `device` (max_batch = max_pairs = batch).
         d_frames: u8 tensor [NB * batch, H, W] on the device, this rank's frames of NB consecutive global batches
-        (cycled); NB >= len(pms) + 3.  comm: this rank's D.Comm (RCCL, world-of-one RCCL, or loopback) -- with it
-        the slots go through the exchange even in a world of one; gloo=True: host-staged torch.distributed rig."""
+        (cycled); NB >= len(pms) + 1 + sp_ahead.  comm: this rank's D.Comm (RCCL, world-of-one RCCL, or loopback) -- with it
+        the slots go through the exchange even in a world of one; gloo=True: host-staged torch.distributed rig.
+        sp_ahead: how many batches SuperPoint is enqueued ahead of the matcher (step b enqueues match(b) and SP(b + sp_ahead)).
+        2 (default): the host waits for the lists of batch b - len(pms) + 1 with TWO batches of SuperPoint work queued, so a
+        matcher that takes long over one batch (the strict mode's exact redo of a flagged pair: ~5 ms of dependent launches)
+        does not drain SuperPoint's stream -- the critical path -- while the host waits; 1 = the round-3 loop."""
         self.sp, self.pms = sp, list(pms)
         self.B, self.H, self.W = int(batch), int(H), int(W)
         self.dev, self.rank, self.world = device, int(rank), int(world)
         self.d_frames = d_frames
         self.NB = d_frames.shape[0] // self.B
-        # ring slot k is refilled by SuperPoint(b + NB), enqueued in step b + NB - 1; the last slot of batch b is read by match(b + 1),
-        # which the host has fetched by step b + M: NB >= M + 2
-        assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 2, "ring too short for the matchers"
         self.overlap = overlap if len(self.pms) == 1 else 2
+        self.ahead = int(sp_ahead) if self.overlap == 2 else 1
+        # ring slot k is refilled by SuperPoint(b + NB), enqueued in step b + NB - ahead; the last slot of batch b is read by
+        # match(b + 1), which the host has fetched by step b + M: NB >= M + 1 + ahead
+        assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 1 + self.ahead, "ring too short for the matchers"
+        assert 1 <= self.ahead <= 3
         self.outlier = bool(outlier_rejection)
         self.comm, self.gloo = comm, bool(gloo)
         self.exchange = comm is not None or self.gloo
@@ -68,6 +74,7 @@ class SlotRingPipeline:
             self.all_counts = [torch.zeros((self.world, self.B), dtype=torch.int32, device=device) for _ in range(M)]
             self.all_matches = [torch.zeros((self.world, self.B * 1024 * 3), dtype=torch.int32, device=device) for _ in range(M)]
             self.gathered_upto = -1       # last batch whose lists went to the root
+            self.sp_ev = [None] * self.NB
         torch.cuda.synchronize(device)
 
     # ------------------------------------------------------------------ enqueue
@@ -75,6 +82,15 @@ class SlotRingPipeline:
         self.sp_calls = b + 1
         k = b % self.NB
         self.sp.infer_device(self.d_frames[k * self.B].data_ptr(), self.B, self.H, self.W, self.ring[k].data_ptr())
+        # what waits for SP(b) is told so HERE, before any later batch is enqueued behind it on SuperPoint's stream: the
+        # all-gather of batch b (exchange), or the matcher that will take batch b (its stream is in order: the wait sits
+        # behind the batch it is still working on and in front of match(b))
+        if self.comm is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.sp_ext)
+            self.sp_ev[k] = ev
+        elif self.overlap == 2 and not self.gloo:
+            self.pms[b % len(self.pms)].wait_for_sp(self.sp)
 
     def slots_of(self, b):
         k = b % self.NB
@@ -133,9 +149,7 @@ class SlotRingPipeline:
                 assert all(pb != b - M for pb, _ in self.pending), "gather of a batch that was not fetched yet"
                 self._gather(b - M)
             k = b % self.NB
-            ev_sp = torch.cuda.Event()
-            ev_sp.record(self.sp_ext)                                   # tail of the SuperPoint stream = SP(b)
-            self.cs.wait_event(ev_sp)
+            self.cs.wait_event(self.sp_ev[k])                           # SP(b), not whatever was enqueued behind it
             self.comm.allgather_slots(self.ring[k].data_ptr(), self.B, self.gathered_buf[k].data_ptr(), self.cs.cuda_stream)
             self.gathered[k] = self.gathered_buf[k]
         elif self.gloo:                                                 # test rig: host-staged, synchronous
@@ -151,12 +165,12 @@ class SlotRingPipeline:
             ev_ag = torch.cuda.Event()
             ev_ag.record(self.cs)
             self.pm_ext[b % len(self.pms)].wait_event(ev_ag)
-        if self.overlap:
-            mt.wait_for_sp(self.sp)                 # match(b) needs SP(b)
+        if self.overlap == 1 or (self.overlap == 2 and self.gloo):
+            mt.wait_for_sp(self.sp)                 # match(b) needs SP(b)  (three-stream mode: told in sp_step)
         self.pm_step(b, mt)
         if self.overlap == 1:
             mt.let_sp_overlap_sinkhorn(self.sp)     # SP(b+1) starts when match(b) reaches Sinkhorn
-        self.sp_step(b + 1)
+        self.sp_step(b + self.ahead)
         self.pending.append((b, mt))
         out = []
         while len(self.pending) >= len(self.pms):   # keep len(pms)-1 batches in flight behind the host
@@ -194,7 +208,8 @@ class SlotRingPipeline:
 
     # ------------------------------------------------------------------ driving loops
     def prologue(self):
-        self.sp_step(0)      # so that the loop body is exactly one match + one SuperPoint per step
+        for b in range(self.ahead):      # so that the loop body is exactly one match + one SuperPoint per step
+            self.sp_step(b)
 
     def run(self, b0, steps, record=None):
         out = []
