@@ -108,6 +108,77 @@ def pmc_traffic(kernel_label, resolution, prec):
                                            f"Infinity-Cache hits; {os.path.basename(files[-1])}")
 
 
+def stream_run(U, spb, sgb, dev, device_index, prec, Hh, Ww, batch, steps, repeats, warmup=5, keep=False):
+    """One more configuration through the SAME loop as the headline (ur-mvo_amd/pipeline.py, two matcher handles, SuperPoint two
+    batches ahead): `repeats` timed regions of `steps` steps, median reported.  keep=True also returns every fetched list."""
+    import torch
+    F, synth, P = U.frontend, U.synth, U.pipeline
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=Hh, max_width=Ww, max_batch=batch, device=device_index,
+                      precision=prec)
+    assert sp.build(spb), U._lib.lib().urf_last_error()
+    pms = []
+    for _ in range(2):
+        m = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=batch, device=device_index, precision=prec)
+        assert m.build(sgb), U._lib.lib().urf_last_error()
+        pms.append(m)
+    NB_ = 5
+    fr = synth.shift_stream(100, NB_ * batch, Hh, Ww)
+    d_fr = torch.from_numpy(np.stack(fr)).to(dev)
+    pipe = P.SlotRingPipeline(sp, pms, d_fr, batch, Hh, Ww, device=dev)
+    kept = {}
+    rec = (lambda b, mt, res: kept.__setitem__(b, res)) if keep else None
+    pipe.prologue()
+    pipe.run(0, warmup)
+    pipe.drain()
+    sp.sync()
+    nb, regions = warmup, []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.run(nb, steps, rec)
+        pipe.drain(rec)
+        sp.sync()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+        nb += steps
+    dt = float(np.median(regions))
+    g = [m.near_tie_reruns() for m in pms]
+    out = {"frames_per_s": round(steps * batch / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": batch, "steps": steps,
+           "regions_frames_per_s": [round(steps * batch / r, 2) for r in regions],
+           "pairs": sum(x["pairs"] for x in g), "pairs_flagged": sum(x["flagged"] for x in g), "pairs_redone_exact": sum(x["redone"] for x in g),
+           "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms)}
+    del pipe, pms, sp, d_fr
+    return (out, kept) if keep else out
+
+
+def latency_runs(U, spb, sgb, device_index, prec, Hh, Ww, repeats=3):
+    """BASELINE configs[1] (SuperPoint only, batch 1, <= 1024 keypoints) and the per-call path of the UNPATCHED reference caller
+    (Tracking::ExtractFeatureAndMatch, src/tracking.cc:338-377: SuperPoint::infer on one frame, then MatchingPoints on host
+    features, one pair) through the very entry points the C++ shims call (urf_sp_infer, urf_match): host buffers in and out."""
+    F, synth = U.frontend, U.synth
+    fr = synth.shift_stream(100, 12, Hh, Ww)
+    sp1 = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=Hh, max_width=Ww, max_batch=1, device=device_index, precision=prec)
+    pm1 = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=1, device=device_index, precision=prec)
+    assert sp1.build(spb) and pm1.build(sgb)
+    feats = [sp1.infer(f) for f in fr]                      # warm-up; the features of the pairs below
+    pm1.MatchingPoints(feats[0], feats[1], True)
+    t_sp, t_pm = [], []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for f in fr:
+            sp1.infer(f)
+        t_sp.append((time.perf_counter() - t0) / len(fr) * 1e3)
+        t0 = time.perf_counter()
+        for j in range(len(fr) - 1):
+            pm1.MatchingPoints(feats[j], feats[j + 1], True)
+        t_pm.append((time.perf_counter() - t0) / (len(fr) - 1) * 1e3)
+    g = pm1.near_tie_reruns()
+    return {"superpoint_infer_ms_per_frame": round(float(np.median(t_sp)), 3), "matching_points_ms_per_pair": round(float(np.median(t_pm)), 3),
+            "frames_per_s_one_frame_at_a_time": round(1e3 / (float(np.median(t_sp)) + float(np.median(t_pm))), 1),
+            "keypoints": int(feats[0].shape[0]), "pairs_redone_exact": g["redone"], "pairs": g["pairs"],
+            "what": "urf_sp_infer (u8 frame on the host -> 259 x K f64 on the host) and urf_match (two host feature matrices -> DMatch list)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +197,9 @@ def main():
                          "arithmetic (keypoint SET exact, order not), near-tied pairs flagged and NOT redone; 1 = fast without any "
                          "guard; 0 = exact fp32 everywhere (every tensor bit-identical to the oracle)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-mode reference pass (N=1 only)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other single-GPU configurations measured after the headline (guarded fast mode, SuperPoint only at "
+                         "batch 1, the per-call path, the 1241x376 stream at batch 8 and 4)")
     ap.add_argument("--no-guard-calibration", action="store_true",
                     help="skip the check of the guard's error model before the timed region (counter-collection runs: its "
                          "exact-mode launches would be tallied with the step's)")
@@ -187,7 +261,7 @@ def main():
     OVERLAP = int(os.environ.get("URF_BENCH_OVERLAP", "2"))
     MATCHERS = int(os.environ.get("URF_BENCH_MATCHERS", "2")) if OVERLAP == 2 else 1
     AHEAD = int(os.environ.get("URF_BENCH_SP_AHEAD", "2")) if OVERLAP == 2 else 1   # batches SuperPoint is enqueued ahead of the matcher (pipeline.py)
-    NB = max(5, MATCHERS + 1 + AHEAD)      # the ring (and with it the 40-frame stream the parity tests hold oracle results for) stays at 5 batches for 2 matchers
+    NB = max(5, MATCHERS + 1 + AHEAD, int(os.environ.get("URF_BENCH_NB", "0")))      # the ring (and with it the 40-frame stream the parity tests hold oracle results for) stays at 5 batches for 2 matchers
     stream = synth.shift_stream(100, NB * BATCH * world, H, W)
     mine = [stream[(k * world + rank) * BATCH + j] for k in range(NB) for j in range(BATCH)]
     d_frames = torch.from_numpy(np.stack(mine)).to(dev)                       # [NB*8, H, W] u8
@@ -410,49 +484,40 @@ def main():
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
         exact = None
-        if world == 1 and FAST and not args.no_exact_check:
-            # reference pass in the exact fp32 mode (bit-identical to the oracle) on the SAME
-            # batches: its throughput and how far the fast mode's match lists are from it
-            sp2 = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
-                               device=local_rank, precision=0)
-            pm2 = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                                  device=local_rank, precision=0)
-            assert sp2.build(spb) and pm2.build(sgb)
-            pm2.share_stream(sp2)
-            ring2 = torch.zeros_like(ring)
-            nst = min(4, args.steps)
-            last = args_last_batch                       # last timed batch of the fast run
-            b0 = last - nst + 1
-            # the fast ring still holds batches last-3 .. last+1: batches last-2 .. last are comparable
-            cmp_batches = [b for b in range(last - 2, last + 1) if b >= b0 + 1 and b in kept]
-            fast_sets = {b: match_coords(kept[b], ring[b % NB], ring[(b - 1) % NB][-1]) for b in cmp_batches}
-            sp2.infer_device(d_frames[((b0 - 1) % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[(b0 - 1) % NB].data_ptr())
-            sp2.infer_device(d_frames[(b0 % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[b0 % NB].data_ptr())
-            sp2.sync()
-            res_exact = {}
-            te = time.perf_counter()
-            for b in range(b0, b0 + nst):
-                cur, prev = ring2[b % NB], ring2[(b - 1) % NB]
-                s0 = [(cur[j - 1] if j > 0 else prev[-1]).data_ptr() for j in range(BATCH)]
-                s1 = [cur[j].data_ptr() for j in range(BATCH)]
-                pm2.match_device_async(s0, s1, True)
-                sp2.infer_device(d_frames[((b + 1) % NB) * BATCH].data_ptr(), BATCH, H, W, ring2[(b + 1) % NB].data_ptr())
-                res_exact[b] = pm2.fetch(BATCH, as_arrays=True)
-            sp2.sync()
-            dte = time.perf_counter() - te
-            same_pairs = tot_pairs = same_m = tot_m = 0
-            for b in cmp_batches:
-                ex_sets = match_coords(res_exact[b], ring2[b % NB], ring2[(b - 1) % NB][-1])
-                for a_, b_ in zip(fast_sets[b], ex_sets):
-                    tot_pairs += 1
-                    same_pairs += int(a_ == b_)
-                    same_m += len(a_ & b_)
-                    tot_m += len(a_ | b_)
-            exact = {"value": round(nst * BATCH / dte, 2), "unit": "frames/s", "dtype": "f32",
-                     "ms_per_step": round(dte / nst * 1e3, 3),
-                     "pairs_with_identical_match_list": f"{same_pairs}/{tot_pairs}",
-                     "match_jaccard_fast_vs_exact": round(same_m / max(tot_m, 1), 6)}
-            del sp2, pm2
+        secondary = None
+        if world == 1 and not args.no_exact_check and NB == 5:
+            # The exact fp32 mode (every tensor bit-identical to the oracle) through the same loop on the same stream, >= 20 steps
+            # x 3 regions, and the headline's lists against its lists: in the strict-parity mode every pair's INDEX LIST must be
+            # equal, position for position (the GPU tests assert the same against the CPU oracle).
+            del pipe, pms, pm, sp
+            ex_run, ex_lists = stream_run(U, spb, sgb, dev, local_rank, 0, H, W, BATCH, 20, 3, warmup=args.warmup, keep=True)
+            cmp_b = [b for b in ex_lists if b in kept and b >= args.warmup]
+            same = tot = same_idx = 0
+            for b in cmp_b:
+                for a_, x_ in zip(kept[b], ex_lists[b]):
+                    tot += 1
+                    same_idx += int(len(a_) == len(x_) and np.array_equal(a_["queryIdx"], x_["queryIdx"]) and np.array_equal(a_["trainIdx"], x_["trainIdx"]))
+                    same += int(len(a_) == len(x_) and np.array_equal(a_["queryIdx"], x_["queryIdx"]) and np.array_equal(a_["trainIdx"], x_["trainIdx"])
+                                and (len(a_) == 0 or float(np.abs(a_["distance"] - x_["distance"]).max()) < 1e-3))
+            exact = {"value": ex_run["frames_per_s"], "unit": "frames/s", "dtype": "f32", "ms_per_step": ex_run["ms_per_step"],
+                     "regions_frames_per_s": ex_run["regions_frames_per_s"], "steps": 20,
+                     "pairs_with_identical_index_list": f"{same_idx}/{tot}",
+                     "pairs_with_identical_index_list_and_distance_within_1e-3": f"{same}/{tot}"}
+            if PREC == 3 and same != tot:
+                print(f"bench.py: STRICT PARITY VIOLATED: {tot - same} of {tot} pairs differ from the exact mode", file=sys.stderr)
+        if world == 1 and not args.no_secondary and args.resolution == "640x480" and BATCH == 8:
+            # every other single-GPU configuration of BASELINE.json, in the run the driver makes (>= 3 regions each)
+            secondary = {}
+            for name_, prec_ in (("guarded_fast_640x480_batch8", 2), ("fast_unguarded_640x480_batch8", 1)):
+                if prec_ != PREC:
+                    secondary[name_] = stream_run(U, spb, sgb, dev, local_rank, prec_, 480, 640, 8, 30, 3)
+            if PREC != 3:
+                secondary["strict_parity_640x480_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 480, 640, 8, 30, 3)
+            secondary["strict_parity_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 8, 20, 3)
+            secondary["strict_parity_1241x376_batch4"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 4, 20, 3)
+            secondary["guarded_fast_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 2, 376, 1241, 8, 20, 3)
+            secondary["configs1_and_per_call_path_strict_parity_640x480"] = latency_runs(U, spb, sgb, local_rank, 3, 480, 640)
+            secondary["configs1_and_per_call_path_guarded_fast_640x480"] = latency_runs(U, spb, sgb, local_rank, 2, 480, 640)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
@@ -497,6 +562,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "exact_mode": exact,
+            "secondary": secondary,
             "stage_ms_per_step": stage_means,
             "superpoint_stages_in_timed_region_ms": sp_stage_insitu,
             "matches_per_step": round(float(np.mean(n_matches)), 1),

@@ -208,6 +208,14 @@ int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *
 int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0,
                            const void *const *d_slots1, int outlier_rejection);
 int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
+/* urf_pm_fetch in two halves, for callers that keep the GPU busy across a redo (strict parity, precision 3; in the other
+ * modes begin never returns 1).  begin: waits for the batch's fast pass, reads the guard words and STARTS the exact redo of
+ * the flagged pairs on the redo engine's own stream; returns 1 when a redo is running, 0 when the lists are final, <0 on
+ * error.  Between the halves the caller may enqueue this handle's NEXT batch (urf_match_device_async): it runs beside the
+ * redo (one batch at most: its own fetch_begin wants this batch ended first).  end: waits for the redo and hands the lists
+ * out.  urf_pm_fetch = begin + end. */
+int urf_pm_fetch_begin(urf_pm *h, int P);
+int urf_pm_fetch_end(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
 int urf_pm_sync(urf_pm *h);
 /* Run this matcher on the SuperPoint handle's stream (same device): SP(b),
  * match(b), SP(b+1) ... then execute in order on one HIP stream, the host only
@@ -303,8 +311,9 @@ int urf_comm_gather(urf_comm *c, const void *d_send, size_t bytes, void *d_recv,
  * slots (global frame g = rank * per_rank + j against g - 1); first[0] == -1 on rank 0 = the last frame of the
  * previous step, carried by the caller.  Host-only. */
 int urf_comm_plan_pairs(int world, int rank, int per_rank, int *first, int *second);
-/* device buffers holding the last batch of a matcher: matches [max_pairs][URF_MAX_KEYPOINTS] urf_dmatch and
- * counts [max_pairs] int (valid after the batch's kernels; order with urf_pm_stream) */
+/* device buffers holding the batch of a matcher that was handed out last (urf_pm_fetch / urf_pm_fetch_end): matches
+ * [max_pairs][URF_MAX_KEYPOINTS] urf_dmatch and counts [max_pairs] int, final (redone pairs included).  Two sets alternate
+ * between consecutive batches: ask again after every fetch; a set is rewritten by the handle's batch after next. */
 int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts);
 /* How often this handle's LDS-resident Sinkhorn launch (fast mode) gave up -- its 32 workgroups per pair did not become
  * co-resident within 0.25 s, e.g. another process holds CUs -- and the batch was redone with the streaming kernels before its

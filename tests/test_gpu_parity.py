@@ -384,7 +384,7 @@ def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
     for force in ("0", "1"):
         env = dict(os.environ, URF_BENCH_FORCE_DIST=force, MASTER_PORT="29541")
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
-                                       "--repeats", "2", "--no-cpu-baseline", "--no-exact-check"], env=env, text=True, stderr=subprocess.DEVNULL)
+                                       "--repeats", "2", "--no-cpu-baseline", "--no-exact-check", "--no-secondary"], env=env, text=True, stderr=subprocess.DEVNULL)
         res.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
     assert res[0]["matches_per_step"] == res[1]["matches_per_step"] > 8 * 600
     # (a 4-step region: the three RCCL calls of a step and the end-of-region gathers weigh far more here than in a real run)
@@ -425,7 +425,20 @@ def test_bench_json_line_follows_the_contract():
     assert r["kernel"] == max(lost, key=lost.get)                      # the family that loses the most time against its roof
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and 0 < c["value"] < 50 and 1 <= c["cores"] <= 32 and c["sample"]
-    assert d["exact_mode"]["value"] > 100 and d["exact_mode"]["match_jaccard_fast_vs_exact"] > 0.99
+    # the line times the strict-parity mode; its lists against the exact mode's on the same batches: every pair, index for index
+    assert d["config"]["precision"] == "strict parity"
+    x = d["exact_mode"]
+    assert x["value"] > 100 and x["steps"] == 20
+    same, tot = x["pairs_with_identical_index_list_and_distance_within_1e-3"].split("/")
+    assert same == tot and int(tot) >= 8 * 10
+    # ... and every other single-GPU configuration of BASELINE.json is measured in the same run
+    sec = d["secondary"]
+    for k in ("guarded_fast_640x480_batch8", "fast_unguarded_640x480_batch8", "strict_parity_1241x376_batch8", "strict_parity_1241x376_batch4",
+              "guarded_fast_1241x376_batch8"):
+        assert sec[k]["frames_per_s"] > 100 and len(sec[k]["regions_frames_per_s"]) == 3, k
+    assert sec["strict_parity_1241x376_batch8"]["pairs_redone_exact"] == sec["strict_parity_1241x376_batch8"]["pairs_flagged"]
+    for k in ("configs1_and_per_call_path_strict_parity_640x480", "configs1_and_per_call_path_guarded_fast_640x480"):
+        assert 0.1 < sec[k]["superpoint_infer_ms_per_frame"] < 50 and 0.5 < sec[k]["matching_points_ms_per_pair"] < 100, k
 
 
 @pytest.mark.parametrize("kw,its", [(dict(seed=0, noise=0.0, outliers=40), 200), (dict(seed=2, noise=0.3, outliers=40), 200),

@@ -47,32 +47,36 @@ def rec(b, mt, res):
         sp_stage[b] = sum(sp.stage_ms(age=age)[1:16])
 
 
+wait = [0.0]
+for m_ in pms:      # time spent blocked in the two halves of fetch
+    for name in ("fetch_begin", "fetch_end"):
+        def wrap(f):
+            def g(*a_, **k_):
+                t_ = time.perf_counter()
+                r_ = f(*a_, **k_)
+                wait[0] += time.perf_counter() - t_
+                return r_
+            return g
+        setattr(m_, name, wrap(getattr(m_, name)))
 torch.cuda.synchronize()
 T0 = time.perf_counter()
 for b in range(6, 6 + steps):
     t0 = time.perf_counter()
-    pipe.step_exchange(b)
-    mt = pipe.pms[b % M]
-    pipe.pm_step(b, mt)
-    t1 = time.perf_counter()
-    pipe.sp_step(b + pipe.ahead)
-    t2 = time.perf_counter()
-    pipe.pending.append((b, mt))
-    while len(pipe.pending) >= M:
-        pipe.collect(rec)
+    wait[0] = 0.0
+    pipe.one_step(b, rec)
     t3 = time.perf_counter()
-    rows.append((b, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - T0) * 1e3))
+    rows.append((b, (t3 - t0 - wait[0]) * 1e3, 0.0, wait[0] * 1e3, (t3 - T0) * 1e3))
 pipe.drain(rec)
 sp.sync()
 torch.cuda.synchronize()
 total = (time.perf_counter() - T0) * 1e3
 print(f"precision {prec}, {steps} steps, sp_ahead {ahead}, {M} matchers: {total / steps:.3f} ms/step = {steps * B / total * 1e3:.1f} frames/s")
-print("step  enqueue-match  enqueue-SP  wait+fetch   t_end | GPU: SP(b) ms  match(b) fast ms  redo ms  flagged pairs")
+print("step  enqueue  -  wait-in-fetch   t_end | GPU: SP(b) ms  match(b) fast ms  redo ms  flagged pairs")
 for b, a, c, w, t in rows[:40]:
     ps = pm_stage.get(b, (0, 0))
     print(f"{b:4d}  {a:8.3f}  {c:8.3f}  {w:8.3f}  {t:8.2f} | {sp_stage.get(b, 0):6.2f}  {ps[0]:6.2f}  {ps[1]:6.2f}  {flagged.get(b, 0)}")
 a = np.array([r[1:4] for r in rows])
-print("mean host ms per step: enqueue match %.3f, enqueue SP %.3f, wait+fetch %.3f" % tuple(a.mean(0)))
+print("mean host ms per step: enqueue %.3f, (unused %.3f), blocked in fetch %.3f" % tuple(a.mean(0)))
 print("mean GPU ms per batch: SuperPoint %.2f, matcher fast pass %.2f, redo %.2f (batches with a flagged pair: %d of %d)" % (
     np.mean(list(sp_stage.values())), np.mean([v[0] for v in pm_stage.values()]), np.mean([v[1] for v in pm_stage.values()]),
     sum(1 for v in flagged.values() if v), len(flagged)))

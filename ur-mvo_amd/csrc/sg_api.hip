@@ -136,9 +136,21 @@ struct urf_pm {
   // pass enqueued unconditionally behind every fast pass over all 8 pairs, unflagged ones masked to zero counts on the
   // device -- at 4 ms of stream time per batch for ~300 launches that do nothing and 12 ms when one pair of eight was
   // flagged, against 4.5 ms for the pair alone: DESIGN.md section 12.)
+  // The engine runs on ITS OWN stream: urf_pm_fetch_begin() starts the redo of a batch and returns, the caller enqueues this
+  // handle's next batch, and the two run side by side (the redo is a chain of small dependent launches that uses a few per cent
+  // of the chip for milliseconds; serialised in front of the handle's next batch it cost 2.7 ms of step time per flagged pair).
+  // For that the result buffers exist twice (fm_set / nf_set on the device, hm_set / hn_set pinned): consecutive batches
+  // alternate, `fmatches` / `nfinal` / `h_matches` / `h_n` alias the set of the batch enqueued last.
   urf_pm *redo = nullptr;
+  urf_dmatch *fm_set[2] = {nullptr, nullptr}, *hm_set[2] = {nullptr, nullptr};
+  int *nf_set[2] = {nullptr, nullptr}, *hn_set[2] = {nullptr, nullptr};
+  int cur_set = 0, begun_set = 0, fetched_set = 0;
+  int begun_P = 0;                 // pairs of the batch whose fetch has begun (urf_pm_fetch_begin) and not ended
+  struct { bool active = false; int set = 0, n = 0; std::chrono::steady_clock::time_point t0; } rd;
+  hipEvent_t ev_rd_in = nullptr, ev_rd_done = nullptr;   // the redo has taken its inputs out of this handle's buffers / has delivered
+  int idx_rd[64];                  // the pairs of the running redo (slot k of the engine = pair idx_rd[k] of the batch)
   unsigned long long pairs_redone = 0, cause_thr = 0, cause_run = 0;
-  float redo_ms = 0.0f;            // host time of the last batch's redo (enqueue + wait), profiling
+  float redo_ms = 0.0f;            // time from the start of the last redo until its results were waited for, profiling
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
   bool flags_recorded = false;
   unsigned long long pairs_flagged = 0;
@@ -392,9 +404,11 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->ms0, P * NP)) return -1;
   if (dalloc(&h->ms1, P * NP)) return -1;
   if (dalloc(&h->matches, P * NP)) return -1;
-  if (dalloc(&h->fmatches, P * NP)) return -1;
+  if (dalloc(&h->fm_set[0], P * NP) || dalloc(&h->fm_set[1], P * NP)) return -1;
+  h->fmatches = h->fm_set[0];
   if (dalloc(&h->nmatch, P)) return -1;
-  if (dalloc(&h->nfinal, P)) return -1;
+  if (dalloc(&h->nf_set[0], P) || dalloc(&h->nf_set[1], P)) return -1;
+  h->nfinal = h->nf_set[0];
   if (dalloc(&h->pts0, P * NP * 2)) return -1;
   if (dalloc(&h->pts1, P * NP * 2)) return -1;
   if (dalloc(&h->ps0, P * NP * 2)) return -1;
@@ -410,8 +424,13 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->best_score, P)) return -1;
   if (dalloc(&h->inliers, P * NP)) return -1;
   if (dalloc(&h->d_slotptrs, NI)) return -1;
-  URF_HIP(hipHostMalloc((void **)&h->h_matches, P * NP * sizeof(urf_dmatch), hipHostMallocDefault));
-  URF_HIP(hipHostMalloc((void **)&h->h_n, P * sizeof(int), hipHostMallocDefault));
+  for (int k = 0; k < 2; ++k) {
+    URF_HIP(hipHostMalloc((void **)&h->hm_set[k], P * NP * sizeof(urf_dmatch), hipHostMallocDefault));
+    URF_HIP(hipHostMalloc((void **)&h->hn_set[k], P * sizeof(int), hipHostMallocDefault));
+  }
+  h->h_matches = h->hm_set[0]; h->h_n = h->hn_set[0];
+  URF_HIP(hipEventCreateWithFlags(&h->ev_rd_in, hipEventDisableTiming));
+  URF_HIP(hipEventCreateWithFlags(&h->ev_rd_done, hipEventDisableTiming));
   URF_HIP(hipHostMalloc((void **)&h->h_slotptrs, NI * sizeof(float *), hipHostMallocDefault));
   for (int i = 0; i <= PT_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
   for (int i = 0; i < 18; ++i) { URF_HIP(hipEventCreate(&h->ev_attn[i][0])); URF_HIP(hipEventCreate(&h->ev_attn[i][1])); }
@@ -425,9 +444,11 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
     if (urf_pm_create(&rc, &h->redo)) return -1;
     if (urf_pm_build(h->redo, blob, n_floats)) return -1;
-    (void)hipStreamDestroy(h->redo->st);
-    h->redo->st = h->st;
-    h->redo->own_stream = false;
+    if (const char *e = urf::exp_env("URF_REDO_PRIORITY")) {   // experiments build: the engine's stream at another priority
+      (void)hipStreamDestroy(h->redo->st);
+      URF_HIP(hipStreamCreateWithPriority(&h->redo->st, hipStreamNonBlocking, atoi(e)));
+    }
+
   }
   return 0;
 }
@@ -441,7 +462,8 @@ extern "C" int urf_pm_build_file(urf_pm *h, const char *path) {
 extern "C" void urf_pm_destroy(urf_pm *h) {
   if (!h) return;
   if (h->built && h->st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->st); }
-  urf_pm_destroy(h->redo);      // (runs on this handle's stream: before that stream goes)
+  if (h->built && h->rd.active) (void)hipEventSynchronize(h->ev_rd_done);
+  urf_pm_destroy(h->redo);
   h->redo = nullptr;
   if (h->built) {
     (void)hipSetDevice(h->device);
@@ -449,13 +471,13 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->hh, h->hl,
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
-                    h->matches, h->fmatches, h->nmatch, h->nfinal, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
+                    h->matches, h->fm_set[0], h->fm_set[1], h->nmatch, h->nf_set[0], h->nf_set[1], h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
                     h->g_flags};
     for (void *p : bufs) (void)hipFree(p);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
-    (void)hipHostFree(h->h_matches);
-    (void)hipHostFree(h->h_n);
+    for (int k = 0; k < 2; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
+    (void)hipEventDestroy(h->ev_rd_in); (void)hipEventDestroy(h->ev_rd_done);
     (void)hipHostFree(h->h_rs_err);
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -480,7 +502,10 @@ static int sg_linear(urf_pm *h, int nimg, const float *in, int in_ld, int cin, c
   a.res = res; a.res_ld = out_ld; a.res_bstride = (long)NP * out_ld;
   a.relu = relu ? 1 : 0;
   a.counts = h->counts;
-  if ((cout % 128) == 0 && cout >= 512 && (cin % 64) == 0 && !res) return launch_gemm128(a, nimg, h->st);
+  // (one or two pairs -- the per-pair host API, the redo engine of a strict-parity handle: the 128 x 128 tiles of gemm128 would
+  // be 64 - 96 workgroups for 256 CUs; the 128 x 64 tiles below are twice as many and half as long.  Same fma chains.)
+  static const int small_nimg = [] { const char *e = urf::exp_env("URF_GEMM128_MIN_IMAGES"); return e ? atoi(e) : 5; }();
+  if ((cout % 128) == 0 && cout >= 512 && (cin % 64) == 0 && !res && nimg >= small_nimg) return launch_gemm128(a, nimg, h->st);
   return launch_conv(a, 1, false, false, nimg, h->st);
 }
 
@@ -604,6 +629,10 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
   h->flags_recorded = false;
+  // this batch's lists go to the other result set (the previous batch's may still be waiting for its redo / its fetch_end)
+  h->cur_set ^= 1;
+  h->fmatches = h->fm_set[h->cur_set]; h->nfinal = h->nf_set[h->cur_set];
+  h->h_matches = h->hm_set[h->cur_set]; h->h_n = h->hn_set[h->cur_set];
   h->pairs_seen += (unsigned long long)P;
   return pm_tail(h, P, want_Z, ransac, prof, h->fast);
 }
@@ -644,10 +673,11 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
 // The redo of a batch's flagged pairs, once the host holds the guard words (h->h_gflags: the batch's fast pass has been waited
 // for).  The flagged pairs' encoded keypoints (h->x after pm_kenc: fp32 in every mode, and untouched by the fast layers, which
 // work on their own f16 planes), counts and pixel coordinates go to slots 0 .. n - 1 of the redo engine; its exact pipeline
-// runs over those n pairs; its lists -- and, for the one-pair host calls, its index vectors, scores and log-assignment --
-// replace the fast ones in this handle's buffers.  Returns 1 when results were rewritten (the caller repeats its copies), 0
-// when there was nothing to do.
-static int pm_guard_redo(urf_pm *h) {
+// runs over those n pairs on its own stream; its lists replace the fast ones in the batch's result set (device and pinned
+// mirror) -- and, for the one-pair host calls, its index vectors, scores and log-assignment those of this handle.
+// pm_redo_start returns 1 when a redo was started (pm_redo_finish waits for it), 0 when there was nothing to do.
+static int pm_redo_tail(urf_pm *h);
+static int pm_redo_start(urf_pm *h) {
   if (!h->guarded || h->last_P < 1) return 0;
   const int P = h->last_P;
   if (!h->flags_recorded) {             // (a second call after a redo finds the pinned words cleared: keep the recorded ones)
@@ -661,9 +691,11 @@ static int pm_guard_redo(urf_pm *h) {
   for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
   if (!h->redo_pairs || n == 0) return 0;
   urf_pm *r = h->redo;
-  URF_CHECK(r && r->built && r->st == h->st, "the redo engine of this handle is not built");
-  const auto t0 = std::chrono::steady_clock::now();
-  hipStream_t st = h->st;
+  URF_CHECK(r && r->built, "the redo engine of this handle is not built");
+  URF_CHECK(!h->rd.active, "a redo of this handle is still running (urf_pm_fetch_end the previous batch first)");
+  h->rd.t0 = std::chrono::steady_clock::now();
+  const int set = h->cur_set;
+  hipStream_t st = r->st;               // (this handle's stream is idle: the host has waited for the batch's fast pass)
   for (int k = 0; k < n; ++k) {
     const int p = idx[k];
     h->cause_thr += (h->last_flags[p] & 1) != 0;
@@ -672,27 +704,51 @@ static int pm_guard_redo(urf_pm *h) {
     URF_HIP(hipMemcpyAsync(r->kxy + (size_t)2 * k * NP * 2, h->kxy + (size_t)2 * p * NP * 2, (size_t)2 * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(r->x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
+  URF_HIP(hipEventRecord(h->ev_rd_in, st));   // this handle's next batch may overwrite counts / kxy / x behind this point
   // the exact layers, the final projection and the tail over n pairs (grids sized for n, not for the batch)
   if (pm_gnn_exact(r, 2 * n, false)) return -1;
   if (sg_linear(r, 2 * n, r->x, 256, 256, nullptr, 0, 0, r->wf, r->bf, 256, r->mdesc, 256, false, nullptr)) return -1;
   r->last_P = n; r->last_Z = h->last_Z; r->last_ransac = h->last_ransac;
+  for (int k = 0; k < n; ++k) h->idx_rd[k] = idx[k];
+  h->rd.active = true; h->rd.set = set; h->rd.n = n;
+  return pm_redo_tail(h) ? -1 : 1;
+}
+// the engine's tail (scores, Sinkhorn, decode, outlier stage) over the rd.n pairs it holds, and the delivery of its lists
+static int pm_redo_tail(urf_pm *h) {
+  urf_pm *r = h->redo;
+  hipStream_t st = r->st;
+  const int n = h->rd.n, set = h->rd.set;
   if (pm_tail(r, n, h->last_Z, h->last_ransac, false, false)) return -1;
   for (int k = 0; k < n; ++k) {
-    const int p = idx[k];
-    URF_HIP(hipMemcpyAsync(h->nfinal + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->fmatches + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
+    const int p = h->idx_rd[k];
+    URF_HIP(hipMemcpyAsync(h->nf_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->fm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
+    URF_HIP(hipMemcpyAsync(h->hn_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToHost, st));
+    URF_HIP(hipMemcpyAsync(h->hm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, st));
   }
-  if (P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
+  if (h->last_P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
     URF_HIP(hipMemcpyAsync(h->idx0, r->idx0, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->idx1, r->idx1, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->ms0, r->ms0, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->ms1, r->ms1, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (h->last_Z) URF_HIP(hipMemcpyAsync(h->Z, r->Z, (size_t)(NP + 1) * LDC * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  URF_HIP(hipStreamSynchronize(st));
-  h->pairs_redone += (unsigned long long)n;
-  h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  URF_HIP(hipEventRecord(h->ev_rd_done, st));
+  return 0;
+}
+static int pm_redo_finish(urf_pm *h) {
+  if (!h->rd.active) return 0;
+  URF_HIP(hipEventSynchronize(h->ev_rd_done));
+  h->rd.active = false;
+  h->pairs_redone += (unsigned long long)h->rd.n;
+  h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->rd.t0).count();
   return 1;
+}
+// the synchronous form (host calls): > 0 when results were rewritten (the caller repeats its copies)
+static int pm_guard_redo(urf_pm *h) {
+  const int rc = pm_redo_start(h);
+  if (rc <= 0) return rc;
+  return pm_redo_finish(h) < 0 ? -1 : 1;
 }
 
 // After the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?  (Its workgroups spin on
@@ -850,7 +906,10 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   URF_CHECK(P >= 1 && P <= h->maxP, "pairs %d outside [1, %d]", P, h->maxP);
   URF_CHECK(d_slots0 && d_slots1, "urf_match_device: null pointer");
   URF_HIP(hipSetDevice(h->device));
-  URF_HIP(hipEventSynchronize(h->ev_done));  // previous batch (pinned pointer table, result buffers) consumed
+  URF_CHECK(!(h->begun_P && h->cur_set != h->begun_set),
+            "urf_match_device_async: two batches are waiting for their urf_pm_fetch_end / urf_pm_fetch already");
+  URF_HIP(hipEventSynchronize(h->ev_done));  // previous batch (pinned pointer table) consumed
+  if (h->rd.active) URF_HIP(hipStreamWaitEvent(h->st, h->ev_rd_in, 0));   // the running redo has taken its inputs out of counts / kxy / x
   for (int p = 0; p < P; ++p) {
     h->h_slotptrs[2 * p] = (const float *)d_slots0[p];
     h->h_slotptrs[2 * p + 1] = (const float *)d_slots1[p];
@@ -951,31 +1010,56 @@ extern "C" int urf_pm_sync(urf_pm *h) {
   return 0;
 }
 
-extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
+// urf_pm_fetch in two halves.  begin: waits for the batch's fast pass, handles a resident-Sinkhorn give-up, reads the guard
+// words and STARTS the exact redo of the flagged pairs (strict parity) on the redo engine's stream; returns 1 when a redo is
+// running, 0 when the lists are final already.  The caller may now enqueue this handle's next batch (urf_match_device_async):
+// it runs beside the redo.  end: waits for the redo (if any) and hands the lists out.
+extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(h->pending_P > 0, "urf_pm_fetch: no batch in flight (urf_match_device_async first)");
   URF_CHECK(P == h->pending_P, "urf_pm_fetch: %d pairs asked, the batch in flight has %d", P, h->pending_P);
+  URF_CHECK(h->begun_P == 0, "urf_pm_fetch_begin: the previous batch has not been handed out yet (urf_pm_fetch_end first)");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
-  {
-    const int redo = pm_after_wait(h);
-    if (redo < 0) return -3;
-    if (redo > 0) {   // the tail was redone (streaming Sinkhorn after a give-up, or flagged pairs in the exact mode): fetch the rewritten lists
-      URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
-      URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
-      URF_HIP(hipStreamSynchronize(h->st));
-    }
+  const int r1 = pm_check_resident(h);
+  if (r1 < 0) return -3;
+  if (r1 > 0) {   // the tail was redone with the streaming Sinkhorn after a give-up: fetch the rewritten lists
+    URF_HIP(hipMemcpyAsync(h->h_n, h->nfinal, P * sizeof(int), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
+    URF_HIP(hipStreamSynchronize(h->st));
   }
-  URF_CHECK(P >= 1 && P <= h->maxP && out && nout, "urf_pm_fetch: bad argument");
-  for (int p = 0; p < P; ++p) {
-    const int n = h->h_n[p];
-    URF_CHECK(n >= 0 && n <= cap, "match buffer too small: %d > cap %d", n, cap);
-    nout[p] = n;
-    memcpy(out + (size_t)p * cap, h->h_matches + (size_t)p * NP, (size_t)n * sizeof(urf_dmatch));
-  }
+  const int r2 = pm_redo_start(h);
+  if (r2 < 0) return -3;
+  h->begun_P = P; h->begun_set = h->cur_set;
   h->pending_P = 0;
+  return r2;
+}
+
+extern "C" int urf_pm_fetch_end(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(h->begun_P > 0, "urf_pm_fetch_end: no fetch has begun (urf_pm_fetch_begin first)");
+  URF_CHECK(P == h->begun_P, "urf_pm_fetch_end: %d pairs asked, the batch being handed out has %d", P, h->begun_P);
+  URF_CHECK(out && nout, "urf_pm_fetch: bad argument");
+  URF_HIP(hipSetDevice(h->device));
+  if (pm_redo_finish(h) < 0) return -3;
+  const urf_dmatch *hm = h->hm_set[h->begun_set];
+  const int *hn = h->hn_set[h->begun_set];
+  for (int p = 0; p < P; ++p) URF_CHECK(hn[p] >= 0 && hn[p] <= cap, "match buffer too small: %d > cap %d", hn[p], cap);
+  for (int p = 0; p < P; ++p) {
+    nout[p] = hn[p];
+    memcpy(out + (size_t)p * cap, hm + (size_t)p * NP, (size_t)hn[p] * sizeof(urf_dmatch));
+  }
+  h->fetched_set = h->begun_set;
+  h->begun_P = 0;
   return 0;
+}
+
+extern "C" int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
+  URF_CHECK(out && nout, "urf_pm_fetch: bad argument");
+  const int rc = urf_pm_fetch_begin(h, P);
+  if (rc < 0) return rc;
+  return urf_pm_fetch_end(h, P, out, cap, nout);
 }
 
 extern "C" int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1,
@@ -1040,8 +1124,8 @@ extern "C" int urf_sg_debug_couplings(urf_pm *h, int n0, int n1, float *out) {
 
 extern "C" int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d_counts) {
   URF_CHECK(h && h->built && d_matches && d_counts, "urf_pm_device_results: bad argument");
-  *d_matches = h->fmatches;
-  *d_counts = h->nfinal;
+  *d_matches = h->fm_set[h->fetched_set];     // the set of the batch handed out last (urf_pm_fetch / urf_pm_fetch_end)
+  *d_counts = h->nf_set[h->fetched_set];
   return 0;
 }
 
@@ -1065,7 +1149,6 @@ extern "C" int urf_pm_share_stream(urf_pm *h, urf_sp *sp) {
   if (h->own_stream) (void)hipStreamDestroy(h->st);
   h->st = (hipStream_t)st;
   h->own_stream = false;
-  if (h->redo) h->redo->st = h->st;
   return 0;
 }
 

@@ -379,6 +379,33 @@ __global__ void __launch_bounds__(256) ot_init_kernel(const int *counts, float a
 // reduced.  The launch is sized to about four 4-wave workgroups per CU instead of one wave per
 // row: a half-iteration is latency-bound, and 32 resident waves per CU would only keep the
 // MFMA-bound kernels of the other streams (GNN of the next batch, SuperPoint) off the CUs.
+// The arithmetic of one row (every lane ends with the same value): x = M + add over the columns below Cn, the maximum by
+// the butterfly, the canonical wave-strided-by-4 sum of exp(x - max), and max + log(sum).
+template <bool FAST>
+__device__ __forceinline__ float sinkhorn_row_lse(const f32x4 (&cur)[5], const f32x4 (&av)[5], int lane, int Cn) {
+  f32x4 x[5];
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int c = 256 * t + 4 * lane;
+    x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < Cn) { x[t][r] = cur[t][r] + av[t][r]; m = fmaxf(m, x[t][r]); }
+  }
+  m = bfly64_max(m);
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int c = 256 * t + 4 * lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
+  }
+  s = bfly64_sum(s);
+  return m + (FAST ? __logf(s) : log_c(s));
+}
+
 template <bool ROWPASS, bool FAST>
 __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, const float *M, const float *add,
                                                             float *out) {
@@ -414,30 +441,11 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
   const float norm = -log_c((float)(n0 + n1));
   for (; row < R; row += nw) {
     if (row + nw < R) load_row(row + nw, nxt);
-    f32x4 x[5];
-    float m = -FLT_MAX;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int c = 256 * t + 4 * lane;
-      x[t] = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (c + r < Cn) { x[t][r] = cur[t][r] + av[t][r]; m = fmaxf(m, x[t][r]); }
-    }
-    m = bfly64_max(m);
-    float s = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int c = 256 * t + 4 * lane;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
-    }
-    s = bfly64_sum(s);
+    const float lse = sinkhorn_row_lse<FAST>(cur, av, lane, Cn);
     if (lane == 0) {
       const int last = R - 1;
       const float lm = (row < last) ? norm : (log_c((float)(ROWPASS ? n1 : n0)) + norm);
-      out[(size_t)p * LDC + row] = lm - (m + (FAST ? __logf(s) : log_c(s)));
+      out[(size_t)p * LDC + row] = lm - lse;
     }
 #pragma unroll
     for (int t = 0; t < 5; ++t) cur[t] = nxt[t];

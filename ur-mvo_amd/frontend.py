@@ -300,6 +300,21 @@ class PointMatching(_PM):
             return [out[p, :n[p]] for p in range(P)]
         return [[(int(m[0]), int(m[1]), float(m[2])) for m in out[p, :n[p]]] for p in range(P)]
 
+    def fetch_begin(self, P):
+        """first half of fetch(): waits for the batch's fast pass and starts the exact redo of its flagged pairs (strict
+        parity) on the redo engine's stream.  Returns 1 when a redo is running (the handle may take its next batch meanwhile),
+        0 when the lists are final."""
+        return check(_lib.lib().urf_pm_fetch_begin(self._h, P), "urf_pm_fetch_begin")
+
+    def fetch_end(self, P, as_arrays=False):
+        """second half of fetch(): waits for the redo, if any, and returns the lists"""
+        out = np.zeros((P, CAP), dtype=MATCH_DTYPE)
+        n = (C.c_int * P)()
+        check(_lib.lib().urf_pm_fetch_end(self._h, P, _p(out), CAP, n), "urf_pm_fetch_end")
+        if as_arrays:
+            return [out[p, :n[p]] for p in range(P)]
+        return [[(int(m[0]), int(m[1]), float(m[2])) for m in out[p, :n[p]]] for p in range(P)]
+
     def sync(self):
         check(_lib.lib().urf_pm_sync(self._h), "urf_pm_sync")
 

@@ -55,7 +55,9 @@ class SlotRingPipeline:
         self.ring = torch.zeros((self.NB, self.B, sf), dtype=torch.float32, device=device)
         self.gathered = [None] * self.NB
         self.sp_calls = 0
-        self.pending = []                 # (batch, matcher) enqueued and not fetched yet
+        self.pending = []                 # [batch, matcher, fetch begun?] enqueued and not handed out yet, oldest first
+        self._late = []                   # batches handed out outside step_compute (exchange: before the gather that ships them)
+        self._record = None
         self.on_collect = None            # optional callback(batch index, matcher, results)
         self.keep_gathered = keep_gathered
         self.gather_log = {}              # rank 0, keep_gathered: batch -> (counts [world, B], matches [world, B, 1024] struct)
@@ -146,7 +148,9 @@ class SlotRingPipeline:
         if self.comm is not None:
             M = len(self.pms)
             if b - M > self.gathered_upto:
-                assert all(pb != b - M for pb, _ in self.pending), "gather of a batch that was not fetched yet"
+                if self.pending and self.pending[0][0] == b - M and self.pending[0][2]:
+                    self._late.append(self._hand_out(self._record))        # its redo has had a step's time: finish it, then ship
+                assert all(e[0] != b - M for e in self.pending), "gather of a batch that was not fetched yet"
                 self._gather(b - M)
             k = b % self.NB
             self.cs.wait_event(self.sp_ev[k])                           # SP(b), not whatever was enqueued behind it
@@ -171,25 +175,43 @@ class SlotRingPipeline:
         if self.overlap == 1:
             mt.let_sp_overlap_sinkhorn(self.sp)     # SP(b+1) starts when match(b) reaches Sinkhorn
         self.sp_step(b + self.ahead)
-        self.pending.append((b, mt))
-        out = []
-        while len(self.pending) >= len(self.pms):   # keep len(pms)-1 batches in flight behind the host
-            out.append(self.collect(record))
+        self.pending.append([b, mt, False])
+        self._record = record
+        out, self._late = self._late, []
+        # keep len(pms) - 1 batches in flight behind the host -- one more while the oldest one's flagged pairs are being redone
+        # (strict parity): its fetch has begun, the redo runs on the engine's stream beside this handle's next batch, and the
+        # lists are handed out a step later, in order
+        while len(self.pending) >= len(self.pms):
+            head = self.pending[0]
+            if not head[2] and head[1].fetch_begin(self.B) == 1 and len(self.pending) == len(self.pms):
+                head[2] = True
+                break
+            head[2] = True
+            out.append(self._hand_out(record))
         return out
 
     def one_step(self, b, record=None):
         self.step_exchange(b)
         return self.step_compute(b, record)
 
-    def collect(self, record=None):
-        b, mt = self.pending.pop(0)
-        res = mt.fetch(self.B, as_arrays=True)      # waits (event) for that batch's match lists only
+    def _hand_out(self, record=None):
+        """the oldest batch, whose fetch has begun: wait for its redo (if one is running) and deliver"""
+        b, mt, begun = self.pending.pop(0)
+        assert begun
+        res = mt.fetch_end(self.B, as_arrays=True)
         if record is not None:
             record(b, mt, res)
         return b, res
 
+    def collect(self, record=None):
+        head = self.pending[0]
+        if not head[2]:
+            head[1].fetch_begin(self.B)             # waits (event) for that batch's fast pass only; starts the redo of flagged pairs
+            head[2] = True
+        return self._hand_out(record)
+
     def drain(self, record=None):
-        out = []
+        out, self._late = self._late, []
         while self.pending:
             out.append(self.collect(record))
         return out
