@@ -16,8 +16,8 @@ struct SuperPointConfig {
   int dla_core;                                  // ignored (Jetson DLA)
   std::vector<std::string> input_tensor_names;   // ignored (TensorRT bindings)
   std::vector<std::string> output_tensor_names;  // ignored
-  std::string onnx_file;                         // ignored (no ONNX parser here)
-  std::string engine_file;                       // URFW weight container (urf_weights_save)
+  std::string onnx_file;                         // read (initialisers only) when engine_file does not exist yet
+  std::string engine_file;                       // URFW weight container: the cache build() writes, like the reference's TensorRT plan
 };
 
 struct SuperGlueConfig {

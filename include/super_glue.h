@@ -34,7 +34,12 @@ class SuperGlue {
   bool build() {  // src/super_glue.cpp:21-147
     if (h_) return true;
     if (!create()) return false;
-    if (!deserialize_engine()) { urf_pm_destroy(h_); h_ = nullptr; return false; }
+    // deserialize_engine() when engine_file exists, else onnx_file -> build -> save_engine(), like the reference
+    if (urf_pm_build_config(h_, engine_path_.c_str(), superglue_config_.onnx_file.c_str()) != 0) {
+      report("build");
+      urf_pm_destroy(h_); h_ = nullptr;
+      return false;
+    }
     return true;
   }
   bool build(const float *blob, size_t n_floats) {
@@ -61,7 +66,7 @@ class SuperGlue {
     return true;
   }
 
-  void save_engine() {}
+  void save_engine() {}  // (build() has written the engine_file cache already when it had to start from onnx_file)
   bool deserialize_engine() {
     if (!h_) return false;
     if (urf_pm_build_file(h_, engine_path_.c_str()) != 0) { report("deserialize_engine"); return false; }

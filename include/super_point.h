@@ -36,8 +36,9 @@ class SuperPoint {
   SuperPoint(const SuperPoint &) = delete;
   SuperPoint &operator=(const SuperPoint &) = delete;
 
-  // build(): src/super_point.cpp:18-102.  Loads the weight container named by
-  // engine_file (deserialize_engine first, exactly like the reference).
+  // build(): src/super_point.cpp:18-102, the reference's flow: deserialize_engine() when engine_file exists; otherwise the
+  // initialisers of onnx_file are read (urf_sp_build_config: no ONNX library involved), the handle is built from them and the
+  // engine_file cache is written -- the next start deserialises.
   bool build() {
     if (h_) return true;
     urf_sp_config c{};
@@ -47,7 +48,11 @@ class SuperPoint {
     c.max_height = 1500; c.max_width = 1500;  // TensorRT profile maximum, :55-60
     c.max_batch = 1; c.device = 0; c.precision = precision_;
     if (urf_sp_create(&c, &h_) != 0) { report("create"); return false; }
-    if (!deserialize_engine()) { urf_sp_destroy(h_); h_ = nullptr; return false; }
+    if (urf_sp_build_config(h_, engine_path_.c_str(), super_point_config_.onnx_file.c_str()) != 0) {
+      report("build");
+      urf_sp_destroy(h_); h_ = nullptr;
+      return false;
+    }
     return true;
   }
   // build from an in-memory container (tests, synthetic weights)
@@ -125,7 +130,7 @@ class SuperPoint {
 #endif
   }
 
-  void save_engine() {}  // the weight container is written by tooling (urf_weights_save)
+  void save_engine() {}  // (build() has written the engine_file cache already when it had to start from onnx_file)
   bool deserialize_engine() {
     if (!h_) return false;
     if (urf_sp_build_file(h_, engine_path_.c_str()) != 0) { report("deserialize_engine"); return false; }

@@ -74,6 +74,14 @@ int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats);
  * weight file "URFW" + kind + count + f32 payload. */
 int urf_sp_build_file(urf_sp *h, const char *path);
 int urf_weights_save(const char *path, int kind /*1=SP,2=SG*/, const float *blob, size_t n_floats);
+/* build() from the reference's own configuration, src/super_point.cpp:18-32,99-101 (and src/super_glue.cpp:21-33,145-146):
+ * deserialize_engine() if `engine_file` exists; otherwise read the initialisers of `onnx_file` (a dependency-free protobuf
+ * wire-format reader: parameter names of superpoint/SP/model.py / of the public SuperGlue module when the exporter kept them,
+ * else the Conv nodes in graph order), build from them, and save_engine(): write the URFW container to `engine_file`. */
+int urf_sp_build_config(urf_sp *h, const char *engine_file, const char *onnx_file);
+/* the ONNX half alone: kind 1 = SuperPoint (URF_SP_BLOB_FLOATS), 2 = SuperGlue (URF_SG_BLOB_FLOATS; BatchNorm folded, attention
+ * channels head-major); the packed blob is what urf_sp_build / urf_pm_build take and urf_weights_save writes */
+int urf_onnx_import(const char *onnx_file, int kind, float *blob, size_t n_floats);
 void urf_sp_destroy(urf_sp *h);
 
 /* SuperPoint::infer(image, mask, features), src/super_point.cpp:121-156.
@@ -176,6 +184,7 @@ typedef struct urf_pm urf_pm;
 int urf_pm_create(const urf_sg_config *cfg, urf_pm **out);
 int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats);
 int urf_pm_build_file(urf_pm *h, const char *path);
+int urf_pm_build_config(urf_pm *h, const char *engine_file, const char *onnx_file);   /* as urf_sp_build_config */
 void urf_pm_destroy(urf_pm *h);
 
 /* PointMatching::NormalizeKeypoints, src/point_matching.cc:63-76 (host, f64). */

@@ -1,7 +1,8 @@
 // test_shim.cpp -- the reference's C++ API (super_point.h / point_matching.h)
 // driven exactly like Tracking::ExtractFeatureAndMatch (src/tracking.cc:338-377)
 // on two synthetic frames; prints K and the match count so the Python test can
-// compare with the ctypes path.  Usage: test_shim sp.urfw sg.urfw f0.raw f1.raw H W
+// compare with the ctypes path.  Usage: test_shim sp.urfw sg.urfw f0.raw f1.raw H W [vis|-] [sp.onnx sg.onnx]
+// (with the two ONNX files and engine files that do not exist yet: build() starts from onnx_file and writes the caches)
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -29,6 +30,7 @@ int main(int argc, char **argv) {
   SuperGlueConfig sgc{};
   sgc.image_width = 640; sgc.image_height = 512; sgc.matching_threshold = 0.5; sgc.dla_core = -1;
   sgc.engine_file = argv[2];
+  if (argc > 9) { spc.onnx_file = argv[8]; sgc.onnx_file = argv[9]; }
   SuperPointPtr superpoint = SuperPointPtr(new SuperPoint(spc));
   if (!superpoint->build()) { std::cout << "Error in SuperPoint building" << std::endl; return 1; }   // tracking.cc:39-43
   PointMatchingPtr point_matching = PointMatchingPtr(new PointMatching(sgc));                          // tracking.cc:45
@@ -52,7 +54,7 @@ int main(int argc, char **argv) {
   std::thread t1(extract_point_and_match);
   t1.join();
   if (!ok0 || !ok1) return 1;
-  if (argc > 7) superpoint->visualization(argv[7], image1);      // SuperPoint::visualization, src/super_point.cpp:388-400
+  if (argc > 7 && argv[7][0] != '-') superpoint->visualization(argv[7], image1);      // SuperPoint::visualization, src/super_point.cpp:388-400
   printf("K0=%ld K1=%ld matches=%d\n", (long)features0.cols(), (long)features1.cols(), n);
   for (int i = 0; i < n; ++i) printf("%d %d %.9g\n", matches[i].queryIdx, matches[i].trainIdx, matches[i].distance);
   // EpipolarGeometry compiles against the same handle (mono init, src/tracking.cc:52-55,559)

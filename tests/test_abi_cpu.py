@@ -180,6 +180,76 @@ def test_superglue_state_dict_import_folds_batchnorm_and_reorders_heads(U, tmp_p
         W.superglue_from_onnx(p2)
 
 
+def test_cpp_onnx_import_equals_the_python_packer(U, tmp_path):
+    """build() from the reference's configuration alone (src/super_point.cpp:18-102, src/super_glue.cpp:21-147): when
+    engine_file does not exist the library reads the initialisers of onnx_file itself (urf_onnx_import: a protobuf
+    wire-format reader in C++, no ONNX runtime) and packs them.  The blob must be the Python packer's, float for float
+    -- by parameter name (raw_data and float_data encodings, BatchNorm folded and heads re-ordered for SuperGlue) and by
+    Conv order for an exporter that renamed the initialisers -- and the container urf_weights_save writes from it the
+    same bytes as weights_io.save_container's."""
+    import ctypes as C
+    import hashlib
+    W, L = U.weights_io, U._lib.lib()
+
+    def cpp(path, kind, n):
+        out = np.zeros(n, np.float32)
+        rc = L.urf_onnx_import(path.encode(), kind, out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        assert rc == 0, L.urf_last_error()
+        return out
+
+    # SuperPoint
+    w = U.synth.sp_weights(0)
+    blob = U.synth.pack_sp(w)
+    sd = {}
+    for name, (Wt, b) in w.items():
+        sd[name + ".weight"], sd[name + ".bias"] = Wt, b
+    nodes = [("Conv", [f"x{i}", n + ".weight", n + ".bias"], [f"x{i + 1}"]) for i, (n, *_r) in enumerate(U.synth.SP_CONVS)]
+    for raw in (True, False):
+        p = str(tmp_path / f"sp_{raw}.onnx")
+        W.write_onnx(p, sd, nodes, raw=raw)
+        assert np.array_equal(cpp(p, 1, blob.size), blob)
+    anon = {f"onnx::Conv_{100 + 2 * i}": sd[n + ".weight"] for i, (n, *_r) in enumerate(U.synth.SP_CONVS)}
+    anon.update({f"onnx::Conv_{101 + 2 * i}": sd[n + ".bias"] for i, (n, *_r) in enumerate(U.synth.SP_CONVS)})
+    nodes2 = [("Conv", [f"x{i}", f"onnx::Conv_{100 + 2 * i}", f"onnx::Conv_{101 + 2 * i}"], [f"x{i + 1}"]) for i in range(12)]
+    p = str(tmp_path / "sp_anon.onnx")
+    W.write_onnx(p, anon, nodes2)
+    assert np.array_equal(cpp(p, 1, blob.size), blob)
+    a, b = str(tmp_path / "a.urfw"), str(tmp_path / "b.urfw")
+    got = cpp(p, 1, blob.size)
+    assert L.urf_weights_save(a.encode(), 1, got.ctypes.data_as(C.c_void_p), C.c_size_t(got.size)) == 0
+    W.save_container(b, W.KIND_SP, blob)
+    assert hashlib.sha256(open(a, "rb").read()).hexdigest() == hashlib.sha256(open(b, "rb").read()).hexdigest()
+    # SuperGlue, parameter names kept (BatchNorm present as initialisers: folded by the importer)
+    wg = U.synth.sg_weights(0)
+    gblob = U.synth.pack_sg(wg)
+    sdg = W.superglue_to_state_dict(wg)
+    p = str(tmp_path / "sg_named.onnx")
+    W.write_onnx(p, {k: v for k, v in sdg.items()}, [("Conv", ["x", "final_proj.weight", "final_proj.bias"], ["y"])])
+    assert np.array_equal(W.superglue_from_onnx(p), gblob)
+    assert np.array_equal(cpp(p, 2, gblob.size), gblob)
+    # ... and folded + renamed: the distinct Conv weights in graph order, every weight used by both images
+    seq = [U.synth._fold_bn(Wt, b_, bnp) for (Wt, b_, bnp) in wg["kenc"]]
+    for Lr in wg["layers"]:
+        seq += [Lr["q"], Lr["k"], Lr["v"], Lr["merge"], U.synth._fold_bn(*Lr["mlp0"]), Lr["mlp1"]]
+    seq.append(wg["final"])
+    folded, nodes3 = {}, []
+    for i, (Wt, b_) in enumerate(seq):
+        folded[f"onnx::Conv_{2 * i}"], folded[f"onnx::Conv_{2 * i + 1}"] = Wt[:, :, None], b_
+    for img in ("a", "b"):
+        nodes3 += [("Conv", [img, f"onnx::Conv_{2 * i}", f"onnx::Conv_{2 * i + 1}"], [img + "'"]) for i in range(len(seq))]
+    folded["bin_score"] = np.array(wg["bin_score"], np.float32)
+    p = str(tmp_path / "sg_folded.onnx")
+    W.write_onnx(p, folded, nodes3)
+    assert np.array_equal(cpp(p, 2, gblob.size), gblob)
+    # errors: a BatchNormalization node with renamed initialisers, a wrong kind, a missing file
+    p2 = str(tmp_path / "sg_bn.onnx")
+    W.write_onnx(p2, folded, nodes3[:3] + [("BatchNormalization", ["a'", "s", "b", "m", "v"], ["a''"])] + nodes3[3:])
+    out = np.zeros(gblob.size, np.float32)
+    assert L.urf_onnx_import(p2.encode(), 2, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)) < 0 and b"BatchNormalization" in L.urf_last_error()
+    assert L.urf_onnx_import(p.encode(), 1, out.ctypes.data_as(C.c_void_p), C.c_size_t(blob.size)) < 0
+    assert L.urf_onnx_import(str(tmp_path / "none.onnx").encode(), 2, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)) < 0
+
+
 def test_minimal_sets_glibc_stream_equals_the_c_library(U, O):
     """urf_minimal_sets(URF_SAMPLER_GLIBC): the product restates glibc's rand() (TYPE_3 additive feedback generator)
     to draw the reference's minimal sets (src/epipolar_geometry.cc:56-71,100-117); the oracle calls the C

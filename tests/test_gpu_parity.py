@@ -330,6 +330,24 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
         # same counts; keypoint INDICES may differ where near-tied scores swap places in the score-sorted list
         same = sum(a.split()[:2] == b.split()[:2] for a, b in zip(fast[1:], out[1:]))
         assert fast[0] == out[0] and same >= 0.95 * (len(out) - 1)
+    # build() from the reference's configuration alone (src/super_point.cpp:18-102): engine files that do not exist yet, ONNX
+    # files beside them -> the shims read the initialisers, build, and write the caches; the next start deserialises them
+    import hashlib
+    Wio = U.weights_io
+    w_sp = U.synth.sp_weights(0)
+    sd_sp = {}
+    for name, (Wt, b_) in w_sp.items():
+        sd_sp[name + ".weight"], sd_sp[name + ".bias"] = Wt, b_
+    sp_onnx, sg_onnx = str(tmp_path / "superpoint_v1.onnx"), str(tmp_path / "superglue.onnx")
+    Wio.write_onnx(sp_onnx, sd_sp, [("Conv", [f"x{i}", n + ".weight", n + ".bias"], [f"x{i + 1}"]) for i, (n, *_r) in enumerate(U.synth.SP_CONVS)])
+    Wio.write_onnx(sg_onnx, Wio.superglue_to_state_dict(U.synth.sg_weights(0)), [("Conv", ["x", "final_proj.weight", "final_proj.bias"], ["y"])])
+    spc, sgc = str(tmp_path / "cache_sp.engine"), str(tmp_path / "cache_sg.engine")
+    first = subprocess.check_output([exe, spc, sgc, f0p, f1p, str(H), str(W), "-", sp_onnx, sg_onnx], text=True).strip().split("\n")
+    assert first == strict
+    sha = lambda pth: hashlib.sha256(open(pth, "rb").read()).hexdigest()    # noqa: E731
+    assert sha(spc) == sha(spw) and sha(sgc) == sha(sgw)                      # save_engine(): the Python packer's container, byte for byte
+    os.remove(sp_onnx); os.remove(sg_onnx)
+    assert subprocess.check_output([exe, spc, sgc, f0p, f1p, str(H), str(W), "-", sp_onnx, sg_onnx], text=True).strip().split("\n") == strict
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=400, engine_file=spw), max_height=H, max_width=W)
     assert sp.build()                                     # engine_file path (deserialize_engine)
     f0, f1 = sp.infer(fr[0]), sp.infer(fr[1])

@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("URF_LIB") or os.path.join(_HERE, "liburf_front.so")
 
 # every symbol include/urf.h declares
 SYMBOLS = [
-    "urf_last_error", "urf_build_info", "urf_device_count", "urf_sp_create", "urf_sp_build", "urf_sp_build_file",
+    "urf_last_error", "urf_build_info", "urf_device_count", "urf_sp_create", "urf_sp_build", "urf_sp_build_file", "urf_sp_build_config", "urf_pm_build_config", "urf_onnx_import",
     "urf_weights_save", "urf_sp_destroy", "urf_sp_infer", "urf_sp_infer_batch", "urf_slot_bytes",
     "urf_sp_infer_device", "urf_sp_sync", "urf_slot_to_host", "urf_sp_debug_tensor", "urf_pm_create",
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",

@@ -72,8 +72,8 @@ class SuperPoint:
         if blob is not None:
             blob = np.ascontiguousarray(blob, np.float32)
             rc = L.urf_sp_build(self._h, _p(blob), C.c_size_t(blob.size))
-        else:
-            rc = L.urf_sp_build_file(self._h, self.cfg.engine_file.encode())
+        else:      # the reference's flow: the cached engine_file if it exists, else onnx_file -> build -> write the cache
+            rc = L.urf_sp_build_config(self._h, self.cfg.engine_file.encode(), self.cfg.onnx_file.encode())
         self._built = rc == 0
         return self._built
 
@@ -199,7 +199,7 @@ class _PM:
             blob = np.ascontiguousarray(blob, np.float32)
             rc = L.urf_pm_build(self._h, _p(blob), C.c_size_t(blob.size))
         else:
-            rc = L.urf_pm_build_file(self._h, self.cfg.engine_file.encode())
+            rc = L.urf_pm_build_config(self._h, self.cfg.engine_file.encode(), self.cfg.onnx_file.encode())
         return rc == 0
 
     def sinkhorn_fallbacks(self):
