@@ -371,6 +371,7 @@ def main():
               "frames_redone_exact": sp_g["redone"], "frames": sp_g["frames"], "cuts_resolved": sp_g["cut_resolved"],
               "pairs_redone_exact": sum(g_["redone"] for g_ in pm_g), "pairs": sum(g_["pairs"] for g_ in pm_g),
               "pairs_flagged": sum(g_["flagged"] for g_ in pm_g),
+              "comm_world": (U._lib.lib().urf_comm_world(comm._h) if comm is not None else None),   # ranks of this rank's RCCL communicator
               "region_s": [round(time_r, 4) for time_r in region_local],
               "superpoint_ms": round(float(np.mean(sp_ms)), 3) if sp_ms else None,
               "matching_ms": round(float(np.mean(pm_ms)), 3) if pm_ms else None}
@@ -378,6 +379,8 @@ def main():
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, health)
+        if async_exchange:     # every rank really sits in ONE RCCL communicator of `world` ranks
+            assert all(h_["comm_world"] == world for h_ in per_rank), [h_["comm_world"] for h_ in per_rank]
     # SuperPoint stage by stage inside the timed region (guarded mode: the exact pass over the redo list and the resolution of
     # the top-k cuts run between "select" and "desc_norm" and are counted under "select")
     sp_stage_insitu = ({n_: round(float(v_), 3) for n_, v_ in zip(F.SP_STAGES, np.mean(np.array(sp_stages), axis=0))} if sp_stages else None)

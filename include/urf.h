@@ -301,6 +301,11 @@ int urf_comm_unique_id(void *id);
 int urf_comm_init(int world, int rank, int device, const void *id, urf_comm **out);
 /* one process driving ndev devices: out[i] is the communicator of devices[i] (ncclCommInitAll) */
 int urf_comm_init_all(int ndev, const int *devices, urf_comm **out);
+/* a host thread that drives SEVERAL devices' communicators (urf_comm_init_all) brackets the collective calls it makes for
+ * them with these (ncclGroupStart / ncclGroupEnd): issued one by one, the first rank's call would wait for peers the thread
+ * has not called yet.  Not needed with one rank per process; no-ops while RCCL is not loaded. */
+int urf_comm_group_start(void);
+int urf_comm_group_end(void);
 /* one process acting as `world` logical ranks on ONE device (single-GPU rigs and tests of the N > 1 data path): out[r] is
  * rank r's communicator.  Device copies instead of RCCL; a collective completes when every rank has made the call (any
  * rank order, from one host thread), with the stream semantics of the real thing: results are ordered behind every rank's

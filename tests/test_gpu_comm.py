@@ -139,3 +139,110 @@ def test_sharded_pipeline_in_a_loopback_world_vs_oracle(U, sp_blob, sg_blob, wor
                 m = fetched[r][b][j]
                 assert cnt[r, j] == len(m) and np.array_equal(mt[r, j, :len(m)], m), (b, r, j)
     assert sum(m.sinkhorn_fallbacks() for p in pipes for m in p.pms) == 0
+
+
+# ------------------------------------------------------------------ real RCCL worlds (boxes with >= 2 GPUs; skipped on the 1-GPU pool)
+def _loopback_reference(U, sp_blob, sg_blob, world, H, W, steps, prec, B=4, M=2):
+    """the same sharded run in a loopback world on device 0: (counts, matches) per rank, gathered slots, rank 0's gather log"""
+    import torch
+    F, D, P = U.frontend, U.dist, U.pipeline
+    frames = U.synth.shift_stream(100, 40, H, W)
+    n, NB = len(frames), M + 3
+    dev = torch.device("cuda", 0)
+    comms = D.Comm.loopback(world, 0)
+    pipes = []
+    for r in range(world):
+        sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B, precision=prec)
+        assert sp.build(sp_blob)
+        pms = []
+        for _ in range(M):
+            pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B, precision=prec)
+            assert pm.build(sg_blob)
+            pms.append(pm)
+        idx = [((k * world + r) * B + j) % n for k in range(NB) for j in range(B)]
+        d_frames = torch.from_numpy(np.stack([frames[i] for i in idx])).to(dev)
+        pipes.append(P.SlotRingPipeline(sp, pms, d_frames, B, H, W, device=dev, rank=r, world=world, comm=comms[r], keep_gathered=(r == 0)))
+    for p in pipes:
+        p.prologue()
+    got = P.run_lockstep(pipes, 0, steps)
+    fin = P.finish_lockstep(pipes, steps - 1)
+    torch.cuda.synchronize()
+    fetched = [dict(a + b) for a, b in zip(got, fin)]
+    gathered = np.stack([pipes[0].gathered_buf[k].cpu().numpy() for k in range(steps)])
+    return fetched, gathered, pipes[0].gather_log
+
+
+def test_two_real_rccl_ranks_equal_the_loopback_world(U, sp_blob, sg_blob, tmp_path):
+    """urf_comm_init with world = 2 and real RCCL over xGMI: two PROCESSES, one GPU each, the sharded step loop for three steps
+    (exact mode: everything is bit-comparable) -- every rank's fetched lists, the all-gathered slots and rank 0's gathered
+    lists must equal what two logical ranks of a loopback world produce on one GPU (which the tests above compare with the
+    CPU oracle).  Skipped on a one-GPU box: this is the test that lights up on the driver's 8-GPU node."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    F = U.frontend
+    if U._lib.lib().urf_device_count() < 2:
+        pytest.skip("needs two GPUs (a real RCCL world)")
+    world, H, W, steps, prec = 2, 376, 1241, 3, 0
+    idfile = str(tmp_path / "rccl.id")
+    procs = []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.npz")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), str(r), str(world), idfile, out,
+                                             str(H), str(W), str(steps), str(prec)], env=env)))
+    for out, p in procs:
+        assert p.wait(timeout=600) == 0
+    ref_fetched, ref_gathered, ref_log = _loopback_reference(U, sp_blob, sg_blob, world, H, W, steps, prec)
+    for r, (out, _) in enumerate(procs):
+        d = np.load(out)
+        assert list(d["comm_world"]) == [world, r]
+        assert np.array_equal(d["gathered"], ref_gathered)                          # the RCCL all-gather = the loopback copies
+        for b in range(steps):
+            for j in range(4):
+                m = ref_fetched[r][b][j]
+                assert d["counts"][b, j] == len(m), (r, b, j)
+                assert np.array_equal(d["matches"][b, j, :len(m)].view(F.MATCH_DTYPE).reshape(-1), m), (r, b, j)
+        if r == 0:
+            for b in range(steps):
+                cnt, mt = ref_log[b]
+                assert np.array_equal(d["root_counts"][b], cnt)
+                for rr in range(world):
+                    for j in range(4):
+                        k = cnt[rr, j]
+                        assert np.array_equal(d["root_matches"][b, rr, j, :k].view(F.MATCH_DTYPE).reshape(-1), mt[rr, j, :k])
+
+
+def test_comm_init_all_two_devices_of_one_process(U):
+    """urf_comm_init_all (ncclCommInitAll): ONE process, one host thread, two devices; the collective calls made for both ranks
+    are bracketed by urf_comm_group_start / _end.  Skipped on a one-GPU box."""
+    import torch
+    L = U._lib.lib()
+    if L.urf_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    D = U.dist
+    comms = D.Comm.init_all([0, 1])
+    assert [L.urf_comm_world(c._h) for c in comms] == [2, 2] and [L.urf_comm_rank(c._h) for c in comms] == [0, 1]
+    sf, n = L.urf_slot_bytes() // 4, 2
+    local, allb, streams = [], [], []
+    for r in range(2):
+        with torch.cuda.device(r):
+            local.append(torch.full((n, sf), float(r + 1), device=f"cuda:{r}") + torch.arange(n, device=f"cuda:{r}")[:, None] * 0.25)
+            allb.append(torch.zeros((2 * n, sf), device=f"cuda:{r}"))
+            streams.append(torch.cuda.Stream(device=r))
+    root = torch.zeros((2, 1000), device="cuda:0")
+    for r in range(2):
+        torch.cuda.synchronize(r)
+    with D.Comm.group():
+        for r in range(2):
+            comms[r].allgather_slots(local[r].data_ptr(), n, allb[r].data_ptr(), streams[r].cuda_stream)
+    with D.Comm.group():
+        for r in range(2):
+            comms[r].gather(local[r].data_ptr(), 4000, root.data_ptr() if r == 0 else 0, 0, streams[r].cuda_stream)
+    for r in range(2):
+        streams[r].synchronize()
+    want = torch.cat([local[0].cpu(), local[1].cpu()])
+    for r in range(2):
+        assert torch.equal(allb[r].cpu(), want)
+        assert torch.equal(root[r].cpu(), local[r].cpu().reshape(-1)[:1000])

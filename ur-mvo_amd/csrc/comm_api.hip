@@ -149,6 +149,20 @@ extern "C" int urf_comm_init_all(int ndev, const int *devices, urf_comm **out) {
   return 0;
 }
 
+// One host thread that drives several devices' communicators (urf_comm_init_all) brackets the collective calls of a step with
+// these: RCCL then launches them together (ncclGroupStart / ncclGroupEnd) -- issued one by one, the first rank's call would wait
+// for peers the thread has not called yet.  Not needed with one rank per process, nor in a loopback world (no-ops without RCCL).
+extern "C" int urf_comm_group_start(void) {
+  if (!g_rccl.lib) return 0;
+  URF_NCCL(g_rccl.GroupStart());
+  return 0;
+}
+extern "C" int urf_comm_group_end(void) {
+  if (!g_rccl.lib) return 0;
+  URF_NCCL(g_rccl.GroupEnd());
+  return 0;
+}
+
 extern "C" int urf_comm_init_loopback(int world, int device, urf_comm **out) {
   URF_CHECK(out && world >= 1 && world <= 64, "urf_comm_init_loopback: world %d outside [1, 64]", world);
   int ndev = 0;

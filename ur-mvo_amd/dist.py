@@ -41,6 +41,30 @@ class Comm:
             out.append(c)
         return out
 
+    @classmethod
+    def init_all(cls, devices):
+        """one process driving several devices (urf_comm_init_all = ncclCommInitAll): a list of Comm, rank i on devices[i].
+        Bracket the collective calls made for them by one thread with Comm.group()."""
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        devs = (C.c_int * n)(*[int(d) for d in devices])
+        check(_lib.lib().urf_comm_init_all(n, devs, hs), "urf_comm_init_all")
+        out = []
+        for r in range(n):
+            c = cls.__new__(cls)
+            c.world, c.rank, c.device, c._h = n, r, int(devices[r]), C.c_void_p(hs[r])
+            out.append(c)
+        return out
+
+    class group:
+        """with Comm.group(): ... -- ncclGroupStart / ncclGroupEnd around the calls one thread makes for several ranks"""
+
+        def __enter__(self):
+            check(_lib.lib().urf_comm_group_start(), "urf_comm_group_start")
+
+        def __exit__(self, *a):
+            check(_lib.lib().urf_comm_group_end(), "urf_comm_group_end")
+
     @staticmethod
     def unique_id():
         buf = C.create_string_buffer(128)
