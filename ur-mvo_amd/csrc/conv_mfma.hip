@@ -29,14 +29,20 @@ constexpr int W_STRIDE = 80;
 // MB = 16-channel output blocks per workgroup: 4 (the tile above), or 1 for the redo pass of the guarded fast mode, whose
 // launches hold a few tiles each and are bound by the length of one wave's MFMA chain -- a quarter of the channels per
 // workgroup, four times the workgroups, the weights fetched two taps ahead.  The chain of every output is the same.
-template <int TAPS, bool POOL, bool FUSE1A, int MB = 4>
+// WDMA (round 4; the full-frame 3x3 launches of the exact mode): a (chunk, tap)'s 64 x 64 weights arrive by LDS-DMA
+// (global_load_lds_dwordx4) in two alternating 16-KiB stages instead of through registers: no weight VGPRs, no LDS writes by
+// the waves, ONE barrier per tap instead of two.  The stage is unpadded (a DMA piece is 1 KiB of consecutive LDS: 4 rows of 64
+// floats); the bank spread the padded layout got from its stride of 80 comes from a swizzle instead -- row k keeps its four
+// 16-float blocks in the order block ^ (k & 3), applied to the SOURCE address of the DMA and to the fragment read.  Every
+// output's fma chain is unchanged.
+template <int TAPS, bool POOL, bool FUSE1A, int MB = 4, bool WDMA = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PH = (TAPS == 9) ? TH + 2 : TH;
   constexpr int PW = (TAPS == 9) ? TW + 2 : TW;
   float *in_tile = smem;                          // [PH*PW][IN_STRIDE]
-  float *w_tile = smem + PH * PW * IN_STRIDE;     // [64][W_STRIDE]  (offset is a multiple of 4 floats)
-  float *patch = w_tile + 64 * W_STRIDE;          // FUSE1A: [12][20]
+  float *w_tile = smem + PH * PW * IN_STRIDE;     // [64][W_STRIDE]  (offset is a multiple of 4 floats); WDMA: [2][64][64]
+  float *patch = w_tile + (WDMA ? 2 * 64 * 64 : 64 * W_STRIDE);   // FUSE1A: [12][20]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -293,6 +299,36 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
     }
 
   };
+  auto compute_tap_dma = [&](int tap, int stage) {
+    // WDMA: fragment reads from the swizzled stage: lane (px, g) of block m reads row k + g, physical block m ^ g
+    const int toff = ((tap / 3) * PW + (tap % 3)) * IN_STRIDE;
+    const float *bp0 = in_tile + bpix[0] + toff;
+    const float *bp1 = in_tile + bpix[1] + toff;
+    const float *wb = w_tile + stage * (64 * 64) + g * 64 + px;
+    const float *apm[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) apm[m] = wb + 16 * (m ^ g);
+    float pa[2][4], pb[2][2];
+#define URF_LOADD(set, k)                                                    \
+  {                                                                          \
+    pb[set][0] = bp0[k]; pb[set][1] = bp1[k];                                \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) pa[set][m] = apm[m][(k) * 64]; \
+  }
+    URF_LOADD(0, 0)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < 16) URF_LOADD(cur ^ 1, 4 * (ks + 1))
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][r2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][m], pb[cur][r2], acc[m][r2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef URF_LOADD
+  };
   auto compute_tap = [&](int tap, int kc) {
       const int toff = (TAPS == 9) ? ((tap / 3) * PW + (tap % 3)) * IN_STRIDE : 0;
       const float *bp0 = in_tile + bpix[0] + toff;
@@ -338,7 +374,40 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
 #undef URF_KSTEP
   };
 
-  if constexpr (MB == 4) {
+  if constexpr (WDMA) {
+    static_assert(MB == 4 && TAPS == 9, "WDMA is the full-tile 3x3 path");
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    // a stage = 16 pieces of 1 KiB (4 weight rows each); wave w issues pieces 4 w .. 4 w + 3.  Lane L of a piece: row r = L >> 4,
+    // 16-byte slot s = L & 15 = physical block s >> 2 -> logical block (s >> 2) ^ r (the piece's first row is a multiple of 4)
+    const int dr = lane >> 4, dsl = lane & 15;
+    const int dcol = cout_base + 16 * ((dsl >> 2) ^ dr) + 4 * (dsl & 3);
+    auto dma_w = [&](int ch, int tap, int stage) {
+      const int cin_all = FUSE1A ? 64 : a.Cin;
+      const float *wsrc = a.w + ((size_t)tap * cin_all + ch * 64) * a.Cout + dcol;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * wave + u;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(wsrc + (size_t)(4 * i + dr) * a.Cout),
+                                         (lds_void *)(w_tile + stage * (64 * 64) + i * 256), 16, 0, 0);
+      }
+    };
+    dma_w(0, 0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (ch > 0) __syncthreads();   // slower waves may still read the input tile for the previous chunk's last tap
+      stage_input(ch);
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int s2 = ch * TAPS + tap;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        __syncthreads();                                    // everybody's have (and the input tile), and everybody is done with the other stage
+        {
+          const int nt = tap + 1 < TAPS ? tap + 1 : 0, nc = tap + 1 < TAPS ? ch : ch + 1;
+          if (nc < nchunks) dma_w(nc, nt, (s2 + 1) & 1);
+        }
+        compute_tap_dma(tap, s2 & 1);
+      }
+    }
+  } else if constexpr (MB == 4) {
     issue_w(0, 0, wpf);
     if (TAPS == 1) issue_in(0);
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -446,9 +515,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   }
 }
 
-static size_t conv_lds_bytes(int taps, bool fuse) {
+static size_t conv_lds_bytes(int taps, bool fuse, bool wdma = false) {
   const int PH = taps == 9 ? TH + 2 : TH, PW = taps == 9 ? TW + 2 : TW;
-  return sizeof(float) * ((size_t)PH * PW * IN_STRIDE + 64 * W_STRIDE + (fuse ? 12 * 20 : 0));
+  return sizeof(float) * ((size_t)PH * PW * IN_STRIDE + (wdma ? 2 * 64 * 64 : 64 * W_STRIDE) + (fuse ? 12 * 20 : 0));
 }
 
 // host launcher.  batch = grid.z
@@ -464,7 +533,10 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   const bool split = split_env && taps == 9 && !fuse1a && a.gate && a.t_scale > 0;   // (conv1: its fused first layer would be redone per quarter)
   grid.y = split ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
   grid.z = batch;
-  const size_t lds = conv_lds_bytes(taps, fuse1a);
+  // full-frame 3x3 launches with whole 64-channel tiles: the weights by LDS-DMA (URF_CONV_WDMA=0 in an experiments build: through registers)
+  static const bool wdma_on = [] { const char *e = urf::exp_env("URF_CONV_WDMA"); return !e || atoi(e) != 0; }();
+  const bool wdma = wdma_on && taps == 9 && !a.gate && (a.Cout % 64) == 0 && (fuse1a || (a.Cin % 64) == 0) && (a.Cout % 4) == 0;
+  const size_t lds = conv_lds_bytes(taps, fuse1a, wdma);
   static DeviceOnce attr_done;
   if (attr_done.need()) {  // > 64 KiB of dynamic LDS needs the opt-in
     const int mx = 72 * 1024;
@@ -475,9 +547,19 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    const int mxd = 80 * 1024;
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
     attr_done.mark();
   }
-  if (split && fuse1a && pool) {
+  if (wdma && fuse1a && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, true, 4, true>), grid, block, lds, st, a);
+  } else if (wdma && pool) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, true, false, 4, true>), grid, block, lds, st, a);
+  } else if (wdma) {
+    hipLaunchKernelGGL((conv_mfma_kernel<9, false, false, 4, true>), grid, block, lds, st, a);
+  } else if (split && fuse1a && pool) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, true, 1>), grid, block, lds, st, a);
   } else if (split && pool) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, false, 1>), grid, block, lds, st, a);
