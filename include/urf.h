@@ -173,6 +173,14 @@ typedef struct {
    *   default (2: 5e-4, 3: 2.2e-4).  urf_pm_calibrate_guard() widens it where a deployment's pairs need it. */
   int redo_flagged_pairs;
   float guard_margin;
+  /* outlier_stage (appended; 0 = default): 0 = the in-tree 8-point search configured above; 1 = the reference's own call,
+   * cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, ransac_threshold_px (3), ransac_confidence (0.99), mask), as
+   * OpenCV 4.2.0 publishes it (7-point minimal sets drawn by cv::RNG((uint64)-1), up to three models per set, at most 1000
+   * iterations shrunk by RANSACUpdateNumIters, the mask of the best hypothesis, LMedS below 15 matches; DESIGN.md section
+   * 13).  Restated, NOT verified against an OpenCV binary (there is none in this image; the reference holds no vector);
+   * ransac_iterations / ransac_sigma / ransac_seed are unused.  The matches are walked in list order, as the reference's
+   * points0 / points1 are. */
+  int outlier_stage;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */

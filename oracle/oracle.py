@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "liburf_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cam_oracle.c", "map_oracle.c", "pnp_oracle.c",
+    srcs = [os.path.join(_HERE, f) for f in ("sp_oracle.c", "sg_oracle.c", "ransac_oracle.c", "cvransac_oracle.c", "cam_oracle.c", "map_oracle.c", "pnp_oracle.c",
                                               "urf_oracle.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -33,7 +33,8 @@ class SGConfig(C.Structure):
 
 class RansacConfig(C.Structure):
     """(iterations, sigma, seed, confidence): confidence <= 0 (default) = every hypothesis counts"""
-    _fields_ = [("iterations", C.c_int), ("sigma", C.c_float), ("seed", C.c_uint32), ("confidence", C.c_float)]
+    _fields_ = [("iterations", C.c_int), ("sigma", C.c_float), ("seed", C.c_uint32), ("confidence", C.c_float),
+                ("stage", C.c_int)]      # stage 1 = the restatement of OpenCV 4.2's cv::findFundamentalMat (cvransac_oracle.c)
 
 
 SIGMA_3PX = float(np.float32(3.0 / np.sqrt(3.841)))   # the 3 px gate of the reference's cv::findFundamentalMat call
@@ -207,6 +208,21 @@ def sg_infer(blob, cfg, f0, f1):
     rc = lib().osg_infer(_p(blob), C.byref(cfg), _p(f0), n0, _p(f1), n1, _p(i0), _p(i1), _p(m0), _p(m1), _p(Z))
     assert rc == 0, rc
     return i0, i1, m0, m1, Z
+
+
+def opencv42_ransac():
+    """the outlier stage as the reference's own call: cv::findFundamentalMat(..., cv::FM_RANSAC, 3, 0.99, mask) restated"""
+    return RansacConfig(0, 0.0, 0, 0.99, 1)
+
+
+def cv_find_fundamental_mask(p0, p1, thresh=3.0, confidence=0.99):
+    """OpenCV 4.2's findFundamentalMat(FM_RANSAC) restated: -> inlier mask [n] (uint8)"""
+    p0 = np.ascontiguousarray(p0, np.float32)
+    p1 = np.ascontiguousarray(p1, np.float32)
+    n = p0.shape[0]
+    mask = np.zeros(max(n, 1), np.uint8)
+    lib().ocv_find_fundamental_mask(_p(p0), _p(p1), n, C.c_double(thresh), C.c_double(confidence), _p(mask))
+    return mask[:n]
 
 
 def ransac_find_F(p0, p1, cfg):

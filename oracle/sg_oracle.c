@@ -361,7 +361,16 @@ int omatch_points(const float *sg_blob, const osg_config *cfg, const oransac_con
     }
     /* :48-58, cv::findFundamentalMat replaced by the in-tree 8-point RANSAC.
        Fewer than 8 matches cannot seed a hypothesis: all are kept. */
-    if (outlier_rejection && nm >= 8) {
+    if (outlier_rejection && rcfg->stage == 1) {
+      /* the call the reference makes (:50), restated from OpenCV 4.2 (cvransac_oracle.c) */
+      uint8_t *inl = (uint8_t *)malloc((size_t)(nm > 0 ? nm : 1));
+      ocv_find_fundamental_mask(p0, p1, nm, 3.0, rcfg->confidence > 0 ? (double)rcfg->confidence : 0.99, inl);
+      int j = 0;
+      for (int i = 0; i < nm; ++i)
+        if (inl[i]) out[j++] = out[i];
+      nm = j;
+      free(inl);
+    } else if (outlier_rejection && nm >= 8) {
       uint8_t *inl = (uint8_t *)malloc(nm);
       float F[9];
       oransac_find_F(p0, p1, nm, rcfg, inl, F);

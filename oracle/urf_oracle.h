@@ -97,6 +97,8 @@ typedef struct {
   float confidence; /* <= 0: every hypothesis counts (_find_F); else the sequential loop of cv::findFundamentalMat's
                      * 4th argument: hypotheses walked in order, each new best shrinks the count to the smallest k with
                      * (1 - w^8)^k <= 1 - confidence (OpenCV RANSACUpdateNumIters, 8 model points) */
+  int stage;        /* 0 = the in-tree 8-point search above (default); 1 = the restatement of OpenCV 4.2's
+                     * cv::findFundamentalMat(..., FM_RANSAC, 3, confidence, mask) (cvransac_oracle.c; sigma / iterations / seed unused) */
 } oransac_config;
 
 /* minimal sets: sampler 0 = the build's counter hash, 1 = the reference's stream, i.e. the C library's own
@@ -111,6 +113,10 @@ float oransac_find_F_sets(const float *pts0, const float *pts1, int n, const ora
  * pairs.  inliers: n bytes.  F21: 9 floats row-major.  Returns best score. */
 float oransac_find_F(const float *pts0, const float *pts1, int n,
                      const oransac_config *cfg, uint8_t *inliers, float *F21);
+
+/* cv::findFundamentalMat(m1, m2, cv::FM_RANSAC, thresh, confidence, mask) of OpenCV 4.2.0 restated (cvransac_oracle.c; parity
+ * unpinned: no OpenCV binary to check against).  m1 / m2: n x (x, y) floats; mask: n bytes; returns the inlier count. */
+int ocv_find_fundamental_mask(const float *m1, const float *m2, int n, double thresh, double confidence, uint8_t *mask);
 
 /* PointMatching::MatchingPoints src/point_matching.cc:14-61; the
  * cv::findFundamentalMat call (:50) is replaced by oransac_find_F.

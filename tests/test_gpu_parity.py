@@ -744,6 +744,40 @@ def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg
     assert not fs.frame_resident(-1) and not fs.frame_resident(9)
 
 
+# ------------------------------------------------------------------ the reference's own outlier call (a21, opt-in)
+def test_opencv42_outlier_stage_equals_the_oracle(U, F, O, sp_blob, sg_blob, sp640):
+    """urf_sg_config.outlier_stage = 1: cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask) restated from
+    OpenCV 4.2 (cvransac.hip) against the oracle's restatement of the same written arithmetic (oracle/cvransac_oracle.c),
+    bit for bit: through MatchingPoints on frame pairs of a stream (host API and device batch), and on the golden scenes
+    through the matcher's own buffers (a match list whose keypoints are the scene's points)."""
+    import torch
+    frames = U.synth.shift_stream(41, 5, 480, 640)
+    feats = [sp640.infer(f) for f in frames]
+    pm_cv = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, outlier_stage=1)
+    assert pm_cv.build(sg_blob)
+    rc = O.opencv42_ransac()
+    want = [O.match_points(sg_blob, O.SGConfig(640, 512, 0.5, 100), rc, feats[j], feats[j + 1], True) for j in range(4)]
+    plain = [O.match_points(sg_blob, O.SGConfig(640, 512, 0.5, 100), rc, feats[j], feats[j + 1], False) for j in range(4)]
+    for j in range(4):
+        assert pm_cv.MatchingPoints(feats[j], feats[j + 1], True) == want[j], j
+        assert 300 < len(want[j]) <= len(plain[j])
+    assert any(len(want[j]) < len(plain[j]) for j in range(4))          # the stage does reject something on this stream
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    slots = torch.zeros((5, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp640.infer_device(d[0].data_ptr(), 1, 480, 640, slots[0].data_ptr())
+    sp640.infer_device(d[1].data_ptr(), 4, 480, 640, slots[1].data_ptr())
+    sp640.sync()
+    pm_cv.match_device_async([slots[j].data_ptr() for j in range(4)], [slots[j + 1].data_ptr() for j in range(4)], True)
+    assert pm_cv.fetch(4) == want
+    # few matches: the LMedS branch (8 .. 14), exactly 7, fewer than 7
+    for n in (13, 7, 4):
+        got = pm_cv.MatchingPoints(feats[0][:n], feats[0][:n], True)
+        assert got == O.match_points(sg_blob, O.SGConfig(640, 512, 0.5, 100), rc, feats[0][:n], feats[0][:n], True), n
+    with pytest.raises(RuntimeError, match="outlier_stage"):
+        F.PointMatching(F.SuperGlueConfig(), outlier_stage=2)
+
+
 # ------------------------------------------------------------------ error behaviour of the boundary
 def test_c_abi_errors_are_negative_codes_with_text_and_leave_outputs_untouched(U, F, sp_blob, sg_blob, pm):
     """reference contract: bool/count returns, no exceptions, outputs untouched on failure

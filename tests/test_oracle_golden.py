@@ -563,3 +563,34 @@ def test_pose_stage_vs_the_independent_numpy_restatement(O, name):
         check_pose_golden(g, fs)
         R = _quat_to_R(fs[1])
         assert np.abs(R - g["R_true"]).max() < 2e-3 and np.abs(fs[2] - g["p_true"]).max() < 3e-2
+
+
+# ------------------------------------------------------------------ the reference's own outlier call, restated (a21)
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_opencv42_find_fundamental_mask_vs_the_independent_numpy_restatement(O, name):
+    """cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask) (src/point_matching.cc:50) as OpenCV 4.2.0
+    publishes it: the C restatement (oracle/cvransac_oracle.c: cv::RNG stream, 7-point sets, null space by Gauss-Jordan,
+    cubic by bisection, RANSACUpdateNumIters without libm) against an independent numpy restatement of the same algorithm
+    (tests/golden/make_cvransac_golden.py: numpy.linalg.svd, numpy.roots, math.log).  Same generator stream, different
+    numerics: the masks agree on every correspondence of the four scenes (a borderline point could legitimately differ; none
+    does).  PARITY UNPINNED: neither side has been compared with an OpenCV binary."""
+    g = golden(f"cvransac_{name}.npz")
+    m = O.cv_find_fundamental_mask(g["m0"], g["m1"], 3.0, 0.99)
+    assert m.shape == g["mask"].shape
+    assert int((m != g["mask"]).sum()) <= max(1, len(m) // 100), (int(m.sum()), int(g["mask"].sum()))
+    truth = g["truth"].astype(bool)
+    assert m[truth].mean() > 0.9                                       # it does separate the planted motion from the clutter
+    assert (~truth).sum() < 20 or m[~truth].mean() < 0.25
+
+
+def test_opencv42_find_fundamental_small_counts(O):
+    """the dispatch of cv::findFundamentalMat on the point count: fewer than 7 -> no model (the reference then reads an empty
+    mask; here nothing is rejected), exactly 7 -> the 7-point solution, every point an inlier, 8..14 -> LMedS"""
+    g = golden("cvransac_a.npz")
+    keep = np.nonzero(g["truth"])[0]
+    for n in (0, 3, 7):
+        m = O.cv_find_fundamental_mask(g["m0"][keep[:n]], g["m1"][keep[:n]])
+        assert m.shape == (n,) and m.all()
+    idx = np.r_[keep[:11], np.nonzero(g["truth"] == 0)[0][:2]]           # 11 inliers + 2 outliers: the LMedS branch
+    m = O.cv_find_fundamental_mask(g["m0"][idx], g["m1"][idx])
+    assert m.shape == (13,) and 7 <= m.sum() <= 13      # (a least-median threshold is tight: 2.5 x 1.4826 x (1 + 5 / 6) x sqrt(median))

@@ -43,7 +43,7 @@ class SGConfig(C.Structure):
                 ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
                 ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
-                ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float)]
+                ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int)]
 
 
 class EpiConfig(C.Structure):

@@ -13,6 +13,8 @@
 #include <vector>
 
 namespace urf {
+int launch_cv_ransac(const int *nmatch, const float *pts0, const float *pts1, double thresh, double confidence, int enable,
+                     const void *matches, void *out, int *nout, uint8_t *inliers, uint8_t *scratch, int P, hipStream_t st);
 extern int g_profiling;
 int weights_load(const char *path, int kind, std::vector<float> &out);
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);
@@ -108,7 +110,7 @@ struct urf_pm {
   float *ps0 = nullptr, *ps1 = nullptr;   // RANSAC: correspondences in canonical (sorted) order
   float *pts0 = nullptr, *pts1 = nullptr, *pn0 = nullptr, *pn1 = nullptr, *T = nullptr, *F = nullptr, *score = nullptr,
         *Fbest = nullptr, *best_score = nullptr;
-  uint8_t *inliers = nullptr;
+  uint8_t *inliers = nullptr, *cv_scratch = nullptr;   // (cv_scratch: the current hypothesis' mask of the OpenCV-form outlier stage)
   const float **d_slotptrs = nullptr;
   // pinned host
   urf_dmatch *h_matches = nullptr;
@@ -197,6 +199,7 @@ extern "C" int urf_pm_create(const urf_sg_config *cfg, urf_pm **out) {
     URF_CHECK(false, "precision 3 (strict parity) without the exact redo of flagged pairs is not strict: redo_flagged_pairs must be 0 or 1");
   }
   if (cfg->guard_margin < 0.0f) { delete h; URF_CHECK(false, "guard_margin must not be negative"); }
+  if (cfg->outlier_stage != 0 && cfg->outlier_stage != 1) { delete h; URF_CHECK(false, "outlier_stage must be 0 (in-tree 8-point search) or 1 (OpenCV 4.2's findFundamentalMat restated)"); }
   *out = h;
   return 0;
 }
@@ -423,6 +426,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->Fbest, P * 9)) return -1;
   if (dalloc(&h->best_score, P)) return -1;
   if (dalloc(&h->inliers, P * NP)) return -1;
+  if (h->cfg.outlier_stage == 1 && dalloc(&h->cv_scratch, P * NP)) return -1;
   if (dalloc(&h->d_slotptrs, NI)) return -1;
   for (int k = 0; k < 2; ++k) {
     URF_HIP(hipHostMalloc((void **)&h->hm_set[k], P * NP * sizeof(urf_dmatch), hipHostMallocDefault));
@@ -472,7 +476,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fm_set[0], h->fm_set[1], h->nmatch, h->nf_set[0], h->nf_set[1], h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
-                    h->score, h->Fbest, h->best_score, h->inliers, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
+                    h->score, h->Fbest, h->best_score, h->inliers, h->cv_scratch, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
                     h->g_flags};
     for (void *p : bufs) (void)hipFree(p);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
@@ -662,7 +666,13 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
     return -1;
   if (guard) URF_HIP(hipMemcpyAsync(h->h_gflags, h->g_flags, P * sizeof(int), hipMemcpyDeviceToHost, st));
   mark(PT_RANSAC);
-  if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
+  if (h->cfg.outlier_stage == 1) {
+    // the reference's own call, cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask), restated (cvransac.hip)
+    const double px = h->cfg.ransac_threshold_px > 0 ? (double)h->cfg.ransac_threshold_px : 3.0;
+    if (launch_cv_ransac(h->nmatch, h->pts0, h->pts1, px, h->r_conf > 0.0 ? h->r_conf : 0.99, ransac ? 1 : 0, h->matches, h->fmatches,
+                         h->nfinal, h->inliers, h->cv_scratch, P, st))
+      return -1;
+  } else if (launch_ransac(h->nmatch, h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F, h->score, h->ninl,
                     h->cfg.ransac_seed, h->r_iters, h->r_sigma, h->r_conf, nullptr, ransac ? 1 : 0, h->matches,
                     h->fmatches, h->nfinal, h->inliers, h->Fbest, h->best_score, P, st))
     return -1;
