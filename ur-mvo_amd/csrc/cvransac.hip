@@ -6,9 +6,11 @@
 // epipolar distance against (float)9, "strictly more inliers and at least 7", the iteration count shrunk by
 // RANSACUpdateNumIters, at most 1000 iterations, no refit; LMedS below 15 points; the mask of the best hypothesis.
 // PARITY UNPINNED (no OpenCV binary to compare with).  Where OpenCV calls its numerical library (SVD, solveCubic, log / pow) a
-// fixed libm-free arithmetic is used instead -- written down in oracle/cvransac_oracle.c, which implements it a second
-// time; the two agree bit for bit (tests/test_gpu_parity.py), and the oracle agrees with an independent numpy / LAPACK
-// restatement (tests/golden/make_cvransac_golden.py).
+// fixed libm-free arithmetic is used instead, written down in DESIGN.md section 13: the null space of the 7 x 9 system by
+// Gauss-Jordan elimination with complete pivoting, the cubic's real roots by bracketing between the critical points and
+// bisection to the last bit, RANSACUpdateNumIters by a multiplication chain.  The CPU checker of the tests implements the same
+// text a second time and agrees bit for bit (tests/test_gpu_parity.py); it agrees in turn with an independent numpy / LAPACK
+// restatement of the algorithm over the same generator stream (tests/golden/make_cvransac_golden.py).
 //
 // The loop is sequential by construction (the generator's stream, and an iteration count that depends on every earlier
 // result): ONE wave per pair walks it; lane 0 draws the set and solves the 7-point system in f64, all 64 lanes count the
