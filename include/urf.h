@@ -527,7 +527,8 @@ int urf_probe_sinkhorn_fault(int launches);
 int urf_probe_sinkhorn_backoff(int batches);
 /* roof probe: the split-f16 MFMA inner loop, `waves_per_cu` in {4, 8, 16}: PFLOP/s of MFMA issue and the in-kernel clock the
  * chip holds under that load.  mode 0 = register-resident operands, no memory; 1 = plus the linear-layer kernel's fragment reads
- * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM */
+ * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM;
+ * 5 = the fp32 matrix core (v_mfma_f32_16x16x4_f32, the exact mode's instruction) on register operands */
 int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float *pflops, float *ghz);
 /* diagnostics of the linear-layer kernel for tools/gpu_h2fixed.py: 1 = non-temporal stores, 2 = no stores, 4 = one K chunk only
  * (2 and 4 give wrong results: timing only); 0 restores the product behaviour */

@@ -17,3 +17,9 @@ for mode in range(5):
             assert L.urf_probe_mfma_roof(0, waves, iters, mode, C.byref(pf), C.byref(ghz)) == 0, L.urf_last_error()
             print(f"mode {mode} ({MODES[mode]:28s}) {waves:2d} waves/CU, {iters:6d} x 24 MFMA per wave: {pf.value:.3f} PFLOP/s of MFMA "
                   f"issue ({pf.value / 3:.3f} logical), in-kernel clock {ghz.value:.2f} GHz", flush=True)
+for waves in (4, 8, 16):
+    for iters in (2000, 20000):
+        pf, ghz = C.c_float(0), C.c_float(0)
+        assert L.urf_probe_mfma_roof(0, waves, iters, 5, C.byref(pf), C.byref(ghz)) == 0, L.urf_last_error()
+        print(f"mode 5 (fp32 MFMA 16x16x4, registers only) {waves:2d} waves/CU, {iters:6d} x 24 MFMA per wave: {pf.value * 1e3:.1f} TFLOP/s "
+              f"(nominal peak 157.3), in-kernel clock {ghz.value:.2f} GHz", flush=True)

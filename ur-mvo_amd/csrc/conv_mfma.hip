@@ -22,6 +22,15 @@ namespace urf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef URF_CONV32_STAMPS   // diagnostic build only (make BUILD=build_st OUT=../liburf_front_st.so EXTRA=-DURF_CONV32_STAMPS; tools/gpu_conv32_stamps.py)
+__device__ long long g_conv32_stamps[2][10];   // [8], [9]: s_memrealtime (100 MHz) at the tile's entry and exit -> the shader clock
+#define C32_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#define C32_ON(POOL_, FUSE_) ((POOL_) == (URF_CONV32_STAMPS == 1) && (FUSE_) == (URF_CONV32_STAMPS == 1) && bx == 300 && by == 0 && bz == 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 2))
+#else
+#define C32_NOW() 0ll
+#define C32_ON(POOL_, FUSE_) false
+#endif
+
 constexpr int TH = 8, TW = 16;
 constexpr int IN_STRIDE = 66;
 constexpr int W_STRIDE = 80;
@@ -35,9 +44,8 @@ constexpr int W_STRIDE = 80;
 // floats); the bank spread the padded layout got from its stride of 80 comes from a swizzle instead -- row k keeps its four
 // 16-float blocks in the order block ^ (k & 3), applied to the SOURCE address of the DMA and to the fragment read.  Every
 // output's fma chain is unchanged.
-template <int TAPS, bool POOL, bool FUSE1A, int MB = 4, bool WDMA = false>
-__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int TAPS, bool POOL, bool FUSE1A, int MB, bool WDMA>
+__device__ __forceinline__ void conv_mfma_tile(const ConvArgs &a, float *smem, const int bx, const int by, const int bz) {
   constexpr int PH = (TAPS == 9) ? TH + 2 : TH;
   constexpr int PW = (TAPS == 9) ? TW + 2 : TW;
   float *in_tile = smem;                          // [PH*PW][IN_STRIDE]
@@ -47,17 +55,21 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z;
+  [[maybe_unused]] const long long st_entry = C32_NOW();
+#ifdef URF_CONV32_STAMPS
+  if (WDMA && C32_ON(POOL, FUSE1A)) g_conv32_stamps[(threadIdx.x >> 6) != 0][8] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  const int b = bz;
   if (a.gate && b >= a.gate[0]) return;
-  const int cout_base = blockIdx.y * (16 * MB);
+  const int cout_base = by * (16 * MB);
 
   int y0 = 0, x0 = 0;
   if (TAPS == 9) {
     const int tiles_x = (a.W + TW - 1) / TW;
-    y0 = (blockIdx.x / tiles_x) * TH;
-    x0 = (blockIdx.x % tiles_x) * TW;
+    y0 = (bx / tiles_x) * TH;
+    x0 = (bx % tiles_x) * TW;
   } else {
-    x0 = blockIdx.x * (TH * TW);
+    x0 = bx * (TH * TW);
     if (a.counts && x0 >= a.counts[b]) return;  // rows beyond this item's count
   }
   if (a.gate && a.t_scale != 0) {
@@ -392,21 +404,35 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
                                          (lds_void *)(w_tile + stage * (64 * 64) + i * 256), 16, 0, 0);
       }
     };
+    [[maybe_unused]] const bool st_on = C32_ON(POOL, FUSE1A);
+    [[maybe_unused]] long long st_t0 = C32_NOW(), st_stage = 0, st_wait = 0, st_sync = 0, st_mma = 0;
     dma_w(0, 0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
       if (ch > 0) __syncthreads();   // slower waves may still read the input tile for the previous chunk's last tap
+      const long long q0 = C32_NOW();
       stage_input(ch);
+      st_stage += C32_NOW() - q0;
       for (int tap = 0; tap < TAPS; ++tap) {
         const int s2 = ch * TAPS + tap;
+        const long long w0 = C32_NOW();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        const long long w1 = C32_NOW();
         __syncthreads();                                    // everybody's have (and the input tile), and everybody is done with the other stage
+        const long long w2 = C32_NOW();
         {
           const int nt = tap + 1 < TAPS ? tap + 1 : 0, nc = tap + 1 < TAPS ? ch : ch + 1;
           if (nc < nchunks) dma_w(nc, nt, (s2 + 1) & 1);
         }
         compute_tap_dma(tap, s2 & 1);
+        st_wait += w1 - w0; st_sync += w2 - w1; st_mma += C32_NOW() - w2;
       }
     }
+#ifdef URF_CONV32_STAMPS
+    if (st_on) {
+      long long *o = g_conv32_stamps[(threadIdx.x >> 6) != 0];
+      o[0] = st_t0; o[1] = st_stage; o[2] = st_wait; o[3] = st_sync; o[4] = st_mma; o[5] = C32_NOW(); o[6] = st_entry;
+    }
+#endif
   } else if constexpr (MB == 4) {
     issue_w(0, 0, wpf);
     if (TAPS == 1) issue_in(0);
@@ -513,6 +539,19 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
       }
     }
   }
+#ifdef URF_CONV32_STAMPS
+  if (WDMA && C32_ON(POOL, FUSE1A)) { g_conv32_stamps[(threadIdx.x >> 6) != 0][7] = C32_NOW(); g_conv32_stamps[(threadIdx.x >> 6) != 0][9] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+template <int TAPS, bool POOL, bool FUSE1A, int MB = 4, bool WDMA = false>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // (round 4, measured and not kept: a persistent form -- two workgroups per CU walking the launch's tiles -- and the same with
+  // the CU's second workgroup started half a tile late, picked by HW_ID.WAVE_ID: 1548 vs 1547 us for conv1 either way.  The
+  // stamps of tools/gpu_conv32_stamps.py say why there is nothing to win from slot turnover or phase: the chip holds 2.13 GHz
+  // inside this kernel, not the 2.4 GHz of the nominal peak, so 119 TFLOP/s is 85 % of what the matrix pipe delivers here.)
+  conv_mfma_tile<TAPS, POOL, FUSE1A, MB, WDMA>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 static size_t conv_lds_bytes(int taps, bool fuse, bool wdma = false) {
@@ -579,3 +618,9 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
 }
 
 }  // namespace urf
+
+#ifdef URF_CONV32_STAMPS
+extern "C" int urf_probe_conv32_stamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_conv32_stamps), sizeof(long long) * 20) == hipSuccess ? 0 : -1;
+}
+#endif

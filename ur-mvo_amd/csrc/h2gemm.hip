@@ -22,7 +22,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 
 constexpr int BK = 32;  // K chunk = one 32-deep MFMA step: small LDS/VGPR footprint -> 2 workgroups (16 waves) per CU
-constexpr int HS = 48;  // LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
+[[maybe_unused]] constexpr int HS = 48;  // (register-staged kernels, experiments build) LDS row stride in halfs: 96 B keeps the ds_read_b128 fragment reads conflict-free
 
 // accumulators -> outputs.  acc[m][r]: cout tile m (16) x token tile r (16) of wave (wc, wr)
 // R = token tiles (of 16) per wave: 2 for the 128-row workgroup tile, 1 for the 64-row one
@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(512, 4) h2gemm_glds_kernel(H2Args a) {
   else h2gemm_glds_body<false>(a, hsm);
 }
 
+#ifdef URF_EXPERIMENTS   // measured and not kept: only the experiments build carries it
 // MODE 3: the fused Q | K | V^T projection of a GNN layer (768 couts = 6 cout tiles, t_from = 512) on a grid of FOUR cout
 // slots per row tile: workgroup (x, j) computes the full Q|K tile j and then the 64-row half (j & 1) of the V^T tile 4 + (j >> 1).
 // 1.5 tiles per workgroup, 4 x rows/128 workgroups per image: 512 workgroups for 16 images = the resident set of the chip,
@@ -256,6 +257,8 @@ __global__ void __launch_bounds__(512, 4) h2gemm_glds_qkv_kernel(H2Args a) {
   h2gemm_glds_tile<true, 1>(a, hsm, b, 512 + (j >> 1) * 128, hrow0, false);
 }
 
+#endif
+
 // MODE 4: 64-row tiles (token-major outputs): launches with few cout tiles (Cout = 256: 2) fill the chip's resident set with
 // twice the workgroups of half the size
 __global__ void __launch_bounds__(512, 4) h2gemm_glds_half_kernel(H2Args a) {
@@ -265,6 +268,7 @@ __global__ void __launch_bounds__(512, 4) h2gemm_glds_half_kernel(H2Args a) {
   h2gemm_glds_tile<false, 1>(a, hsm, b, blockIdx.y * 128, row0, true);
 }
 
+#ifdef URF_EXPERIMENTS   // the register-staged kernels of round 1 (superseded by the LDS-DMA kernel): experiments build only
 template <bool TOUT, int WC, int WR>
 __global__ void __launch_bounds__(64 * WC * WR, (WC * WR >= 8) ? 4 : 3) h2gemm_kernel(H2Args a) {
   constexpr int NT = 64 * WC * WR;      // threads
@@ -384,6 +388,8 @@ static int launch_h2gemm_t(const H2Args &a, int batch, hipStream_t st) {
   return 0;
 }
 
+#endif
+
 int g_h2gemm_xflags = 0;
 int g_h2gemm_variant = -1;  // probe override: 0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 (default)
 
@@ -392,11 +398,15 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
 
   // measured (tools/gpu_h2probe.py, 16384 rows): LDS-DMA 128x128 174-276 TFLOP/s logical > register-staged 128x128
   // 155-251 > register-staged 64x128 140-193 at every shape of the path
+#ifdef URF_EXPERIMENTS
   if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
     const char *e = urf::exp_env("URF_H2GEMM_VARIANT");
     g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
   }
   const int variant = g_h2gemm_variant;
+#else
+  const int variant = 2;         // the product carries the LDS-DMA kernel only
+#endif
   URF_CHECK(a.t_from == 0 || (variant == 2 && (a.t_from % 128) == 0 && a.ohT),
             "h2gemm: the dual epilogue needs the LDS-DMA kernel and a 128-aligned split");
   if (variant == 2) {
@@ -411,7 +421,9 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef URF_EXPERIMENTS
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
       URF_HIP(hipFuncSetAttribute((const void *)h2gemm_glds_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set.mark();
     }
@@ -426,9 +438,14 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     if (nt < 0) { const char *e = urf::exp_env("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;
     b.xflags = g_h2gemm_xflags | nt;
-    if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768)
+#ifdef URF_EXPERIMENTS
+    if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768) {
       hipLaunchKernelGGL(h2gemm_glds_qkv_kernel, dim3((a.rows + 127) / 128, 4, batch), dim3(512), lds, st, b);
-    else if (!a.ohT && (((balance & 2) && a.Cout <= 256) || (balance & 4)))
+      URF_HIP(hipGetLastError());
+      return 0;
+    }
+#endif
+    if (!a.ohT && (((balance & 2) && a.Cout <= 256) || (balance & 4)))
       hipLaunchKernelGGL(h2gemm_glds_half_kernel, dim3((a.rows + 63) / 64, a.Cout / 128, batch), dim3(512), lds, st, b);
     else if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, b);
     else if (a.ohT) hipLaunchKernelGGL((h2gemm_glds_kernel<1>), grid, dim3(512), lds, st, b);
@@ -436,8 +453,12 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     URF_HIP(hipGetLastError());
     return 0;
   }
+#ifdef URF_EXPERIMENTS
   if (a.ohT) return variant ? launch_h2gemm_t<true, 1, 4>(a, batch, st) : launch_h2gemm_t<true, 2, 4>(a, batch, st);
   return variant ? launch_h2gemm_t<false, 1, 4>(a, batch, st) : launch_h2gemm_t<false, 2, 4>(a, batch, st);
+#else
+  URF_CHECK(false, "h2gemm: kernel variant %d exists in the experiments build only", variant);
+#endif
 }
 
 // fp32 [n] -> (hi, lo) f16 planes

@@ -16,6 +16,8 @@
 // h2gemm_glds_kernel) + 64 KB hidden half = 144 KB -> one workgroup per CU, two waves per SIMD.
 // Wave (wc, wr) owns 64 output channels x 32 tokens in every phase: 8 accumulators, 12 ds_read_b128 and 24 MFMAs per
 // 32-deep chunk -- the inner loop of h2gemm_glds_kernel.
+// (measured slower than the two GEMM launches it replaces, DESIGN.md section 8: compiled into the experiments build only)
+#ifdef URF_EXPERIMENTS
 #include <cstdlib>
 
 #include "h2.h"
@@ -223,3 +225,5 @@ int launch_h2mlp(_Float16 *xh, _Float16 *xl, const _Float16 *oh, const _Float16 
 }
 
 }  // namespace urf
+
+#endif  // URF_EXPERIMENTS

@@ -221,12 +221,72 @@ __global__ void __launch_bounds__(512, 4) probe_mfma_roof_kernel(const _Float16 
   sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
 }
+// mode 5: the fp32 matrix core alone (v_mfma_f32_16x16x4_f32 on register operands, 8 accumulators per wave as in conv_mfma_kernel):
+// what the chip sustains on the exact mode's inner loop, and the clock it holds while doing so
+__global__ void __launch_bounds__(256, 2) probe_mfma32_roof_kernel(const float *seed, float *sink, int iters, long long *clocks) {
+  const int lane = threadIdx.x & 63;
+  float a[4], b[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a[m] = seed[lane + 64 * m];
+  b[0] = seed[lane + 256]; b[1] = seed[lane + 320];
+  pf32x4 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { acc[m][0] = pf32x4{0, 0, 0, 0}; acc[m][1] = pf32x4{0, 0, 0, 0}; }
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[r], acc[m][r], 0, 0, 0);
+  }
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+  float t = 0.0f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t += acc[m][0][q] + acc[m][1][q];
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = t;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
+}
+
 }  // namespace urf
 
 // returns PFLOP/s of MFMA issue (every MFMA counted) in *pflops and the in-kernel clock (GHz) in *ghz
 extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float *pflops, float *ghz) {
-  URF_CHECK(pflops && ghz && iters > 0 && (waves_per_cu == 4 || waves_per_cu == 8 || waves_per_cu == 16) && mode >= 0 && mode <= 4,
+  URF_CHECK(pflops && ghz && iters > 0 && (waves_per_cu == 4 || waves_per_cu == 8 || waves_per_cu == 16) && mode >= 0 && mode <= 5,
             "probe_mfma_roof: bad argument");
+  if (mode == 5) {   // fp32 MFMA: 256-thread workgroups, waves_per_cu / 4 of them per CU
+    URF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop5;
+    URF_HIP(hipGetDeviceProperties(&prop5, device));
+    const int blocks5 = prop5.multiProcessorCount * (waves_per_cu / 4);
+    float *seed5, *sink5; long long *clk5;
+    URF_HIP(hipMalloc((void **)&seed5, 384 * 4));
+    URF_HIP(hipMalloc((void **)&sink5, (size_t)blocks5 * 256 * 4));
+    URF_HIP(hipMalloc((void **)&clk5, 16));
+    float h5[384];
+    uint32_t x5 = 777u;
+    for (auto &v : h5) { x5 = x5 * 1664525u + 1013904223u; v = ((float)(x5 >> 8) / 16777216.0f - 0.5f) * 0.25f; }
+    URF_HIP(hipMemcpy(seed5, h5, sizeof(h5), hipMemcpyHostToDevice));
+    hipEvent_t a0, a1;
+    URF_HIP(hipEventCreate(&a0)); URF_HIP(hipEventCreate(&a1));
+    hipLaunchKernelGGL(urf::probe_mfma32_roof_kernel, dim3(blocks5), dim3(256), 0, 0, seed5, sink5, iters / 10 + 1, clk5);
+    URF_HIP(hipEventRecord(a0, 0));
+    hipLaunchKernelGGL(urf::probe_mfma32_roof_kernel, dim3(blocks5), dim3(256), 0, 0, seed5, sink5, iters, clk5);
+    URF_HIP(hipEventRecord(a1, 0));
+    URF_HIP(hipDeviceSynchronize());
+    float ms5 = 0.0f;
+    (void)hipEventElapsedTime(&ms5, a0, a1);
+    long long c5[2] = {0, 1};
+    URF_HIP(hipMemcpy(c5, clk5, 16, hipMemcpyDeviceToHost));
+    *pflops = (float)((double)blocks5 * 4.0 * (double)iters * 24.0 * 2048.0 / (ms5 * 1e-3) / 1e15);
+    *ghz = (float)((double)c5[0] / (double)c5[1] * 0.1);
+    (void)hipFree(seed5); (void)hipFree(sink5); (void)hipFree(clk5);
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+    return 0;
+  }
   URF_CHECK(mode == 0 || waves_per_cu >= 8, "probe_mfma_roof: modes 1-4 model the 8-wave GEMM workgroup");
   URF_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;

@@ -551,6 +551,7 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
     if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
     if (launch_attn_h2(h->qkh, h->qkl, h->vth, h->vtl, h->counts, l & 1, h->oh, h->ol, NI, st)) return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
+#ifdef URF_EXPERIMENTS
     // URF_GNN_FUSED=1: the layer's MLP as ONE launch with the hidden activations in LDS (h2mlp.hip; bit-identical
     // results).  Measured and NOT the default: it needs 144 KB of LDS, i.e. one workgroup per CU with two waves per
     // SIMD, and loses against two h2gemm launches at four waves per SIMD -- 1.87 vs 1.77 ms per 8 pairs serialised,
@@ -564,6 +565,7 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
         return -1;
       continue;
     }
+#endif
     // merge + first MLP layer in one GEMM over [x ; o] (weights folded at build())
     if (h2_linear(h, NI, h->xh, h->xl, 256, 512, h->oh, h->ol, 256, 256, h->H[l].w1, h->L[l].b1f, 512, nullptr, h->hh,
                   h->hl, 512, true, nullptr, false))

@@ -45,7 +45,7 @@ constexpr int RS_NP = kCap;          // 1024 keypoints per image at most
 constexpr int RS_LDC = 1028;         // leading dimension of C in HBM (sg_kernels.hip)
 constexpr int RS_WG = 32;            // workgroups (CUs) per pair
 constexpr int RS_ROWS = 32;          // plan rows per workgroup
-constexpr int RS_T = 1024;           // threads per workgroup: thread t owns column t
+[[maybe_unused]] constexpr int RS_T = 1024;           // threads per workgroup: thread t owns column t
 constexpr int RS_XIN = RS_WG * RS_WG * 32 + RS_WG;   // hop-1 granules per pair: [reducer][source][32 columns] + column 1024 [source]
 constexpr int RS_XBC = 1056 + 32;            // hop-2 granules per pair (1025 used) + the 32 placement granules
 constexpr u64 RS_TIMEOUT_TICKS = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
@@ -163,6 +163,8 @@ __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lane
   return v;
 }
 
+#define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#ifdef URF_EXPERIMENTS   // the LDS-resident form of round 2 (superseded by the register-resident kernel): experiments build only
 __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Pt = lds;                      // [32][1024] plan rows of this workgroup
@@ -274,7 +276,6 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
 
   int next_absorb = 1;
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
-#define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   for (int k = 1; k <= a.iters; ++k) {
     const unsigned tag = (a.salt << 12) | (unsigned)k;
     // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust)
@@ -403,6 +404,7 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Register-resident variant (URF_SINKHORN_REGS=1).  Same recurrence, same exchange, but the plan tile lives in VGPRs:
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
 // to the vectors (7 KB) and the workgroup to two waves per SIMD, so a CU that hosts one can still take an h2gemm or an
 // h2conv workgroup of another stream -- the 144 KB kernel above keeps its CUs to itself.  The price: every row sum is
 // a reduction across the 512 threads (32 DPP wave sums per iteration instead of 2).
-constexpr int RG_T = 512;
+[[maybe_unused]] constexpr int RG_T = 512;
 
 // wave-wide sum whose total is only valid in lane 63 (wave_sum_dpp without the broadcast)
 __device__ __forceinline__ float wave_sum_dpp_l63(float v) {
@@ -782,7 +784,9 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     hipDeviceProp_t prop;
     URF_HIP(hipGetDeviceProperties(&prop, device));
     d.cus = prop.multiProcessorCount;
+#ifdef URF_EXPERIMENTS
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }
@@ -833,10 +837,15 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     }
     a.stamps = g_rs_stamps;
     URF_HIP(hipStreamWaitEvent(st, d.last, 0));
+#ifdef URF_EXPERIMENTS
     if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);
     else if (regs == 2) hipLaunchKernelGGL((sinkhorn_regs_kernel<4, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else if (regs) hipLaunchKernelGGL((sinkhorn_regs_kernel<3, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
+#else
+    (void)lds;
+    hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);   // the product carries this form only
+#endif
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
   }
