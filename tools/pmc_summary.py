@@ -74,7 +74,9 @@ def main():
                   "FETCH_SIZE_KiB_per_launch_raw": round(v["fetch_kib"] / n, 1),
                   "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
                   "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
-    pm_calls = max(fam.get("decode_kernel", {"launches": 0})["launches"], 1)      # one decode_kernel launch per matcher call
+    # matcher calls: one resident-Sinkhorn launch per fast-mode call (the strict mode's redo engine launches decode_kernel too,
+    # so that one would over-count there); the exact mode has no resident launch: one decode_kernel launch per call
+    pm_calls = max(fam.get("sinkhorn_regs_kernel", fam.get("decode_kernel", {"launches": 0}))["launches"], 1)
     # one topk_kernel launch per SuperPoint call -- two in the guarded fast mode (the gated redo pass), which also launches
     # one guard_compact_kernel per call
     sp_calls = max(fam.get("guard_compact_kernel", fam.get("topk_kernel", {"launches": 0}))["launches"], 1)
