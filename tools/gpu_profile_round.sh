@@ -30,6 +30,9 @@ pmc _1241x376 --resolution 1241x376
 pmc _guarded --precision 2
 pmc _exact --precision 0
 stats strict
+# the same command with everything on ONE in-order stream: the serialised kernel durations that bench.py's roofline pass
+# measures with HIP events (with three streams the tracer records every kernel's begin -> end while the others co-run)
+URF_BENCH_OVERLAP=0 stats strict_serial
 stats strict_1241x376 --resolution 1241x376
 stats guarded --precision 2
 stats exact --precision 0
