@@ -298,7 +298,8 @@ def main():
             dist.broadcast_object_list(ids, src=0)
         comm = D.Comm(world, rank, local_rank, ids[0])
     pipe = P.SlotRingPipeline(sp, pms, d_frames, BATCH, H, W, device=dev, rank=rank, world=world, comm=comm,
-                              gloo=exchange and not async_exchange, overlap=OVERLAP, sp_ahead=AHEAD)
+                              gloo=exchange and not async_exchange, overlap=OVERLAP, sp_ahead=AHEAD,
+                              defer=int(os.environ.get("URF_BENCH_DEFER", "2")))
     ring = pipe.ring
     if CALIBRATE:
         # ... and the matcher's margin against the exact matcher, on the first pairs of the stream (urf_pm_calibrate_guard)

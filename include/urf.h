@@ -228,10 +228,13 @@ int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
 /* urf_pm_fetch in two halves, for callers that keep the GPU busy across a redo (strict parity, precision 3; in the other
  * modes begin never returns 1).  begin: waits for the batch's fast pass, reads the guard words and STARTS the exact redo of
  * the flagged pairs on the redo engine's own stream; returns 1 when a redo is running, 0 when the lists are final, <0 on
- * error.  Between the halves the caller may enqueue this handle's NEXT batch (urf_match_device_async): it runs beside the
- * redo (one batch at most: its own fetch_begin wants this batch ended first).  end: waits for the redo and hands the lists
+ * error.  Between the halves the caller may enqueue this handle's NEXT batches (urf_match_device_async): they run beside
+ * the redo.  A handle holds at most TWO begun batches (three result sets: two begun, one being computed); they are handed
+ * out in the order they were begun.  ready: 1 when end would not block (the oldest begun batch needed no redo, or its redo
+ * has delivered), 0 when it would; never blocks.  end: waits for the redo of the oldest begun batch and hands its lists
  * out.  urf_pm_fetch = begin + end. */
 int urf_pm_fetch_begin(urf_pm *h, int P);
+int urf_pm_fetch_ready(urf_pm *h);
 int urf_pm_fetch_end(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
 int urf_pm_sync(urf_pm *h);
 /* Run this matcher on the SuperPoint handle's stream (same device): SP(b),

@@ -304,6 +304,58 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
     assert sp2.near_tie_reruns()["frames"] == 4 and sp2.near_tie_reruns()["redone"] <= 1
 
 
+@pytest.mark.gpu
+def test_a_handle_holds_two_begun_batches_and_hands_them_out_in_order(U, F, sp_blob, sg_blob):
+    """urf_pm_fetch_begin / _ready / _end (include/urf.h): with every pair flagged (absurd margin) three batches of ONE handle
+    are in flight -- two begun, their exact redos queued on the engine, the third computing -- and come out in order, each with
+    its own lists and guard words; a third begin, an end without a begin and a fetch for another pair count
+    are refused."""
+    import torch
+    H, W = 480, 640
+    frames, ofeats, olists = bench_stream_oracle(H, W)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=7, precision=0)
+    assert sp.build(sp_blob)
+    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=2, precision=3, guard_margin=50.0)
+    assert pm.build(sg_blob)
+    d = torch.from_numpy(np.stack(frames[:7])).cuda()
+    slots = torch.zeros((7, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp.infer_device(d.data_ptr(), 7, H, W, slots.data_ptr())
+    sp.sync()
+    ptr = lambda j: slots[j].data_ptr()
+    with pytest.raises(RuntimeError):
+        pm.fetch_end(2)                                       # nothing begun
+    pm.match_device_async([ptr(0), ptr(1)], [ptr(1), ptr(2)], True)     # pairs (0,1) (1,2)
+    with pytest.raises(RuntimeError):
+        pm.fetch_begin(1)                                     # another pair count
+    assert pm.fetch_begin(2) == 1
+    pm.match_device_async([ptr(2), ptr(3)], [ptr(3), ptr(4)], True)     # pairs (2,3) (3,4): beside the first redo
+    assert pm.fetch_begin(2) == 1
+    pm.match_device_async([ptr(4), ptr(5)], [ptr(5), ptr(6)], True)     # pairs (4,5) (5,6): the third result set
+    with pytest.raises(RuntimeError):
+        pm.fetch_begin(2)                                     # two begun batches already
+    import time
+    t0 = time.time()
+    while not pm.fetch_ready() and time.time() - t0 < 5.0:
+        time.sleep(0.001)
+    assert pm.fetch_ready()
+    got = [pm.fetch_end(2)]
+    assert all(pm.near_tie_flags(2))
+    got.append(pm.fetch_end(2))
+    assert pm.fetch_begin(2) == 1
+    got.append(pm.fetch_end(2))
+    with pytest.raises(RuntimeError):
+        pm.fetch_end(2)
+    for k in range(3):
+        for j in range(2):
+            assert got[k][j] == olists["ref"][2 * k + j + 1], (k, j)
+    st = pm.near_tie_reruns()
+    assert st["redone"] == 6 and st["pairs"] == 6 and st["flagged"] == 6
+    # the handle is reusable afterwards, and the one-call form still works
+    pm.match_device_async([ptr(0)], [ptr(1)], True)
+    assert pm.fetch(1)[0] == olists["ref"][1]
+
+
 @pytest.mark.parametrize("H,W", [(480, 640), (376, 1241)])
 def test_guarded_mode_resolves_the_top_k_cut_with_exact_scores(U, F, sp_blob, H, W, monkeypatch):
     """the per-candidate resolution of the top-k cut: with a widened error band (about five candidates at the cut of every

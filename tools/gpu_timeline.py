@@ -1,6 +1,6 @@
 """Where does a pipelined step go?  Host-side timestamps of the bench loop (ur-mvo_amd/pipeline.py) next to the GPU stage times
 of every batch: how long the host spends enqueueing the matcher call / the SuperPoint call, how long it waits in fetch, and how
-busy each stream is.    python tools/gpu_timeline.py [precision=3] [steps=60] [sp_ahead=2] [matchers=2]"""
+busy each stream is.    python tools/gpu_timeline.py [precision=3] [steps=60] [sp_ahead=2] [matchers=2] [defer=2]"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 ahead = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 M = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+defer = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 H, W, B = 480, 640, 8
 print(U._lib.lib().urf_build_info().decode())
 spb, sgb = synth.pack_sp(synth.sp_weights(0)), synth.pack_sg(synth.sg_weights(0))
@@ -31,7 +32,7 @@ NB = max(5, M + 1 + ahead)
 dev = torch.device("cuda", 0)
 d_frames = torch.from_numpy(np.stack(synth.shift_stream(100, NB * B, H, W))).to(dev)
 F.set_profiling(True)
-pipe = P.SlotRingPipeline(sp, pms, d_frames, B, H, W, device=dev, sp_ahead=ahead)
+pipe = P.SlotRingPipeline(sp, pms, d_frames, B, H, W, device=dev, sp_ahead=ahead, defer=defer)
 pipe.prologue()
 pipe.run(0, 6)
 rows = []
@@ -70,7 +71,7 @@ pipe.drain(rec)
 sp.sync()
 torch.cuda.synchronize()
 total = (time.perf_counter() - T0) * 1e3
-print(f"precision {prec}, {steps} steps, sp_ahead {ahead}, {M} matchers: {total / steps:.3f} ms/step = {steps * B / total * 1e3:.1f} frames/s")
+print(f"precision {prec}, {steps} steps, sp_ahead {ahead}, {M} matchers, hand-out lag <= {defer}: {total / steps:.3f} ms/step = {steps * B / total * 1e3:.1f} frames/s")
 print("step  enqueue  -  wait-in-fetch   t_end | GPU: SP(b) ms  match(b) fast ms  redo ms  flagged pairs")
 for b, a, c, w, t in rows[:40]:
     ps = pm_stage.get(b, (0, 0))

@@ -141,16 +141,27 @@ struct urf_pm {
   // The engine runs on ITS OWN stream: urf_pm_fetch_begin() starts the redo of a batch and returns, the caller enqueues this
   // handle's next batch, and the two run side by side (the redo is a chain of small dependent launches that uses a few per cent
   // of the chip for milliseconds; serialised in front of the handle's next batch it cost 2.7 ms of step time per flagged pair).
-  // For that the result buffers exist twice (fm_set / nf_set on the device, hm_set / hn_set pinned): consecutive batches
-  // alternate, `fmatches` / `nfinal` / `h_matches` / `h_n` alias the set of the batch enqueued last.
+  // For that the result buffers exist three times (fm_set / nf_set on the device, hm_set / hn_set pinned): a handle may hold
+  // TWO batches whose fetch has begun (their redos run, in order, on the engine) while a third is being computed; `fmatches` /
+  // `nfinal` / `h_matches` / `h_n` alias the set of the batch enqueued last.
   urf_pm *redo = nullptr;
-  urf_dmatch *fm_set[2] = {nullptr, nullptr}, *hm_set[2] = {nullptr, nullptr};
-  int *nf_set[2] = {nullptr, nullptr}, *hn_set[2] = {nullptr, nullptr};
-  int cur_set = 0, begun_set = 0, fetched_set = 0;
-  int begun_P = 0;                 // pairs of the batch whose fetch has begun (urf_pm_fetch_begin) and not ended
-  struct { bool active = false; int set = 0, n = 0; std::chrono::steady_clock::time_point t0; } rd;
-  hipEvent_t ev_rd_in = nullptr, ev_rd_done = nullptr;   // the redo has taken its inputs out of this handle's buffers / has delivered
-  int idx_rd[64];                  // the pairs of the running redo (slot k of the engine = pair idx_rd[k] of the batch)
+  static constexpr int kSets = 3, kBegun = 2;
+  urf_dmatch *fm_set[kSets] = {nullptr, nullptr, nullptr}, *hm_set[kSets] = {nullptr, nullptr, nullptr};
+  int *nf_set[kSets] = {nullptr, nullptr, nullptr}, *hn_set[kSets] = {nullptr, nullptr, nullptr};
+  int cur_set = 0, fetched_set = 0;
+  // batches whose fetch has begun (urf_pm_fetch_begin) and not ended, oldest first
+  struct Begun {
+    int P = 0, set = 0, n = 0;       // pairs, result set, pairs being redone (0: the lists were final at begin)
+    int idx[64];                     // slot k of the engine = pair idx[k] of the batch
+    int flags[64];                   // the batch's guard words and stage times: what urf_pm_near_tie_flags / urf_pm_stage_ms
+    float stage[PT_COUNT + 2];       //   report once the batch has been handed out (a younger batch may have begun meanwhile)
+    hipEvent_t ev_in = nullptr;      // the flagged pairs' inputs are in this entry's staging buffers
+    hipEvent_t ev_done = nullptr;    // the redo has delivered
+    int *counts = nullptr;           // staging (strict handles): counts / pixel coordinates / encoded keypoints of the flagged pairs,
+    float *kxy = nullptr, *x = nullptr;   // copied on THIS handle's stream, so that its next batch never waits for the engine
+    std::chrono::steady_clock::time_point t0;
+  } bq[kBegun];
+  int bq_head = 0, bq_n = 0;
   unsigned long long pairs_redone = 0, cause_thr = 0, cause_run = 0;
   float redo_ms = 0.0f;            // time from the start of the last redo until its results were waited for, profiling
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
@@ -407,10 +418,10 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->ms0, P * NP)) return -1;
   if (dalloc(&h->ms1, P * NP)) return -1;
   if (dalloc(&h->matches, P * NP)) return -1;
-  if (dalloc(&h->fm_set[0], P * NP) || dalloc(&h->fm_set[1], P * NP)) return -1;
+  for (int k = 0; k < urf_pm::kSets; ++k)
+    if (dalloc(&h->fm_set[k], P * NP) || dalloc(&h->nf_set[k], P)) return -1;
   h->fmatches = h->fm_set[0];
   if (dalloc(&h->nmatch, P)) return -1;
-  if (dalloc(&h->nf_set[0], P) || dalloc(&h->nf_set[1], P)) return -1;
   h->nfinal = h->nf_set[0];
   if (dalloc(&h->pts0, P * NP * 2)) return -1;
   if (dalloc(&h->pts1, P * NP * 2)) return -1;
@@ -428,13 +439,15 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   if (dalloc(&h->inliers, P * NP)) return -1;
   if (h->cfg.outlier_stage == 1 && dalloc(&h->cv_scratch, P * NP)) return -1;
   if (dalloc(&h->d_slotptrs, NI)) return -1;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < urf_pm::kSets; ++k) {
     URF_HIP(hipHostMalloc((void **)&h->hm_set[k], P * NP * sizeof(urf_dmatch), hipHostMallocDefault));
     URF_HIP(hipHostMalloc((void **)&h->hn_set[k], P * sizeof(int), hipHostMallocDefault));
   }
   h->h_matches = h->hm_set[0]; h->h_n = h->hn_set[0];
-  URF_HIP(hipEventCreateWithFlags(&h->ev_rd_in, hipEventDisableTiming));
-  URF_HIP(hipEventCreateWithFlags(&h->ev_rd_done, hipEventDisableTiming));
+  for (int k = 0; k < urf_pm::kBegun; ++k) {
+    URF_HIP(hipEventCreateWithFlags(&h->bq[k].ev_in, hipEventDisableTiming));
+    URF_HIP(hipEventCreateWithFlags(&h->bq[k].ev_done, hipEventDisableTiming));
+  }
   URF_HIP(hipHostMalloc((void **)&h->h_slotptrs, NI * sizeof(float *), hipHostMallocDefault));
   for (int i = 0; i <= PT_COUNT; ++i) URF_HIP(hipEventCreate(&h->ev[i]));
   for (int i = 0; i < 18; ++i) { URF_HIP(hipEventCreate(&h->ev_attn[i][0])); URF_HIP(hipEventCreate(&h->ev_attn[i][1])); }
@@ -448,6 +461,9 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
     if (urf_pm_create(&rc, &h->redo)) return -1;
     if (urf_pm_build(h->redo, blob, n_floats)) return -1;
+    for (int k = 0; k < urf_pm::kBegun; ++k)
+      if (dalloc(&h->bq[k].counts, NI) || dalloc(&h->bq[k].kxy, NI * NP * 2) || dalloc(&h->bq[k].x, NI * NP * 256)) return -1;
+    URF_HIP(hipDeviceSynchronize());
     if (const char *e = urf::exp_env("URF_REDO_PRIORITY")) {   // experiments build: the engine's stream at another priority
       (void)hipStreamDestroy(h->redo->st);
       URF_HIP(hipStreamCreateWithPriority(&h->redo->st, hipStreamNonBlocking, atoi(e)));
@@ -466,7 +482,7 @@ extern "C" int urf_pm_build_file(urf_pm *h, const char *path) {
 extern "C" void urf_pm_destroy(urf_pm *h) {
   if (!h) return;
   if (h->built && h->st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->st); }
-  if (h->built && h->rd.active) (void)hipEventSynchronize(h->ev_rd_done);
+  if (h->built && h->redo && h->redo->built) (void)hipStreamSynchronize(h->redo->st);   // (a redo still running)
   urf_pm_destroy(h->redo);
   h->redo = nullptr;
   if (h->built) {
@@ -475,13 +491,14 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     void *bufs[] = {h->d_wh, h->d_wl, h->xh, h->xl, h->qkh, h->qkl, h->vth, h->vtl, h->oh, h->ol, h->hh, h->hl,
                     h->d_w, h->counts, h->kin, h->kxy, h->x, h->tA, h->tB, h->qkv, h->o, h->msg, h->hid, h->mdesc, h->C,
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
-                    h->matches, h->fm_set[0], h->fm_set[1], h->nmatch, h->nf_set[0], h->nf_set[1], h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
+                    h->matches, h->fm_set[0], h->fm_set[1], h->fm_set[2], h->nmatch, h->nf_set[0], h->nf_set[1], h->nf_set[2], h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, h->cv_scratch, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
                     h->g_flags};
     for (void *p : bufs) (void)hipFree(p);
+    for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipFree(h->bq[k].counts); (void)hipFree(h->bq[k].kxy); (void)hipFree(h->bq[k].x); }
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
-    for (int k = 0; k < 2; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
-    (void)hipEventDestroy(h->ev_rd_in); (void)hipEventDestroy(h->ev_rd_done);
+    for (int k = 0; k < urf_pm::kSets; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
+    for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipEventDestroy(h->bq[k].ev_in); (void)hipEventDestroy(h->bq[k].ev_done); }
     (void)hipHostFree(h->h_rs_err);
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -636,7 +653,15 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
   h->flags_recorded = false;
   // this batch's lists go to the other result set (the previous batch's may still be waiting for its redo / its fetch_end)
-  h->cur_set ^= 1;
+  {   // a set that no begun batch holds (at most two do)
+    int s2 = (h->cur_set + 1) % urf_pm::kSets;
+    for (int t = 0; t < urf_pm::kSets; ++t, s2 = (s2 + 1) % urf_pm::kSets) {
+      bool used = false;
+      for (int k = 0; k < h->bq_n; ++k) used = used || h->bq[(h->bq_head + k) % urf_pm::kBegun].set == s2;
+      if (!used) break;
+    }
+    h->cur_set = s2;
+  }
   h->fmatches = h->fm_set[h->cur_set]; h->nfinal = h->nf_set[h->cur_set];
   h->h_matches = h->hm_set[h->cur_set]; h->h_n = h->hn_set[h->cur_set];
   h->pairs_seen += (unsigned long long)P;
@@ -687,80 +712,96 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
 // work on their own f16 planes), counts and pixel coordinates go to slots 0 .. n - 1 of the redo engine; its exact pipeline
 // runs over those n pairs on its own stream; its lists replace the fast ones in the batch's result set (device and pinned
 // mirror) -- and, for the one-pair host calls, its index vectors, scores and log-assignment those of this handle.
-// pm_redo_start returns 1 when a redo was started (pm_redo_finish waits for it), 0 when there was nothing to do.
-static int pm_redo_tail(urf_pm *h);
-static int pm_redo_start(urf_pm *h) {
-  if (!h->guarded || h->last_P < 1) return 0;
+// pm_begin_batch pushes the batch onto the begun queue and returns 1 when a redo was started for it, 0 when its lists are final.
+static int pm_begin_batch(urf_pm *h) {
+  URF_CHECK(h->bq_n < urf_pm::kBegun, "two batches of this handle are waiting for their urf_pm_fetch_end already");
+  urf_pm::Begun &e = h->bq[(h->bq_head + h->bq_n) % urf_pm::kBegun];
   const int P = h->last_P;
+  e.P = P; e.set = h->cur_set; e.n = 0;
+  e.t0 = std::chrono::steady_clock::now();
+  h->bq_n += 1;
+  memcpy(e.stage, h->stage_ms, sizeof(e.stage));
+  memset(e.flags, 0, sizeof(e.flags));
+  if (!h->guarded || P < 1) return 0;
   if (!h->flags_recorded) {             // (a second call after a redo finds the pinned words cleared: keep the recorded ones)
     for (int p = 0; p < P && p < 64; ++p) { h->last_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
     h->flags_recorded = true;
   }
   h->redo_ms = 0.0f;
-  int idx[64], n = 0;
+  memcpy(e.flags, h->last_flags, sizeof(e.flags));
+  memcpy(e.stage, h->stage_ms, sizeof(e.stage));
+  int n = 0;
   for (int p = 0; p < P; ++p)
-    if (h->h_gflags[p]) idx[n++] = p;
+    if (h->h_gflags[p]) e.idx[n++] = p;
   for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
   if (!h->redo_pairs || n == 0) return 0;
   urf_pm *r = h->redo;
   URF_CHECK(r && r->built, "the redo engine of this handle is not built");
-  URF_CHECK(!h->rd.active, "a redo of this handle is still running (urf_pm_fetch_end the previous batch first)");
-  h->rd.t0 = std::chrono::steady_clock::now();
-  const int set = h->cur_set;
-  hipStream_t st = r->st;               // (this handle's stream is idle: the host has waited for the batch's fast pass)
+  const int set = e.set;
+  // the inputs leave this handle's buffers on its OWN stream (idle: the host has waited for the batch's fast pass), into the
+  // entry's staging: the handle's next batch, in order behind these copies, never waits for the engine -- where an earlier redo
+  // of this handle may still be running; this one queues behind it
   for (int k = 0; k < n; ++k) {
-    const int p = idx[k];
-    h->cause_thr += (h->last_flags[p] & 1) != 0;
-    h->cause_run += (h->last_flags[p] & 2) != 0;
-    URF_HIP(hipMemcpyAsync(r->counts + 2 * k, h->counts + 2 * p, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(r->kxy + (size_t)2 * k * NP * 2, h->kxy + (size_t)2 * p * NP * 2, (size_t)2 * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(r->x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const int p = e.idx[k];
+    h->cause_thr += (e.flags[p] & 1) != 0;
+    h->cause_run += (e.flags[p] & 2) != 0;
+    URF_HIP(hipMemcpyAsync(e.counts + 2 * k, h->counts + 2 * p, 2 * sizeof(int), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.kxy + (size_t)2 * k * NP * 2, h->kxy + (size_t)2 * p * NP * 2, (size_t)2 * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   }
-  URF_HIP(hipEventRecord(h->ev_rd_in, st));   // this handle's next batch may overwrite counts / kxy / x behind this point
+  URF_HIP(hipEventRecord(e.ev_in, h->st));
+  hipStream_t st = r->st;
+  URF_HIP(hipStreamWaitEvent(st, e.ev_in, 0));
+  URF_HIP(hipMemcpyAsync(r->counts, e.counts, (size_t)2 * n * sizeof(int), hipMemcpyDeviceToDevice, st));
+  URF_HIP(hipMemcpyAsync(r->kxy, e.kxy, (size_t)2 * n * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  URF_HIP(hipMemcpyAsync(r->x, e.x, (size_t)2 * n * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
   // the exact layers, the final projection and the tail over n pairs (grids sized for n, not for the batch)
   if (pm_gnn_exact(r, 2 * n, false)) return -1;
   if (sg_linear(r, 2 * n, r->x, 256, 256, nullptr, 0, 0, r->wf, r->bf, 256, r->mdesc, 256, false, nullptr)) return -1;
   r->last_P = n; r->last_Z = h->last_Z; r->last_ransac = h->last_ransac;
-  for (int k = 0; k < n; ++k) h->idx_rd[k] = idx[k];
-  h->rd.active = true; h->rd.set = set; h->rd.n = n;
-  return pm_redo_tail(h) ? -1 : 1;
-}
-// the engine's tail (scores, Sinkhorn, decode, outlier stage) over the rd.n pairs it holds, and the delivery of its lists
-static int pm_redo_tail(urf_pm *h) {
-  urf_pm *r = h->redo;
-  hipStream_t st = r->st;
-  const int n = h->rd.n, set = h->rd.set;
   if (pm_tail(r, n, h->last_Z, h->last_ransac, false, false)) return -1;
   for (int k = 0; k < n; ++k) {
-    const int p = h->idx_rd[k];
+    const int p = e.idx[k];
     URF_HIP(hipMemcpyAsync(h->nf_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->fm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->hn_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToHost, st));
     URF_HIP(hipMemcpyAsync(h->hm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, st));
   }
-  if (h->last_P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
+  if (P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
     URF_HIP(hipMemcpyAsync(h->idx0, r->idx0, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->idx1, r->idx1, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->ms0, r->ms0, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
     URF_HIP(hipMemcpyAsync(h->ms1, r->ms1, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (h->last_Z) URF_HIP(hipMemcpyAsync(h->Z, r->Z, (size_t)(NP + 1) * LDC * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  URF_HIP(hipEventRecord(h->ev_rd_done, st));
-  return 0;
-}
-static int pm_redo_finish(urf_pm *h) {
-  if (!h->rd.active) return 0;
-  URF_HIP(hipEventSynchronize(h->ev_rd_done));
-  h->rd.active = false;
-  h->pairs_redone += (unsigned long long)h->rd.n;
-  h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->rd.t0).count();
+  URF_HIP(hipEventRecord(e.ev_done, st));
+  e.n = n;
   return 1;
+}
+// the oldest begun batch: wait for its redo (if one was started) and pop it; *set = its result set, *P its pair count
+static int pm_end_batch(urf_pm *h, int *set, int *P) {
+  URF_CHECK(h->bq_n > 0, "no fetch has begun");
+  urf_pm::Begun &e = h->bq[h->bq_head];
+  h->redo_ms = 0.0f;
+  if (e.n > 0) {
+    URF_HIP(hipEventSynchronize(e.ev_done));
+    h->pairs_redone += (unsigned long long)e.n;
+    h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e.t0).count();
+  }
+  memcpy(h->last_flags, e.flags, sizeof(e.flags));
+  memcpy(h->stage_ms, e.stage, sizeof(e.stage));
+  if (set) *set = e.set;
+  if (P) *P = e.P;
+  h->bq_head = (h->bq_head + 1) % urf_pm::kBegun;
+  h->bq_n -= 1;
+  return e.n > 0 ? 1 : 0;
 }
 // the synchronous form (host calls): > 0 when results were rewritten (the caller repeats its copies)
 static int pm_guard_redo(urf_pm *h) {
-  const int rc = pm_redo_start(h);
-  if (rc <= 0) return rc;
-  return pm_redo_finish(h) < 0 ? -1 : 1;
+  URF_CHECK(h->bq_n == 0, "a device batch of this handle is waiting for its urf_pm_fetch_end");
+  const int rc = pm_begin_batch(h);
+  if (rc < 0) { h->bq_n = 0; return rc; }
+  return pm_end_batch(h, nullptr, nullptr) < 0 ? -1 : rc;
 }
 
 // After the stream (or the batch's event) has been waited for: did the resident Sinkhorn give up?  (Its workgroups spin on
@@ -918,10 +959,8 @@ extern "C" int urf_match_device_async(urf_pm *h, int P, const void *const *d_slo
   URF_CHECK(P >= 1 && P <= h->maxP, "pairs %d outside [1, %d]", P, h->maxP);
   URF_CHECK(d_slots0 && d_slots1, "urf_match_device: null pointer");
   URF_HIP(hipSetDevice(h->device));
-  URF_CHECK(!(h->begun_P && h->cur_set != h->begun_set),
-            "urf_match_device_async: two batches are waiting for their urf_pm_fetch_end / urf_pm_fetch already");
+  URF_CHECK(h->pending_P == 0 || h->bq_n < urf_pm::kBegun, "urf_match_device_async: three batches of this handle are in flight (fetch one first)");
   URF_HIP(hipEventSynchronize(h->ev_done));  // previous batch (pinned pointer table) consumed
-  if (h->rd.active) URF_HIP(hipStreamWaitEvent(h->st, h->ev_rd_in, 0));   // the running redo has taken its inputs out of counts / kxy / x
   for (int p = 0; p < P; ++p) {
     h->h_slotptrs[2 * p] = (const float *)d_slots0[p];
     h->h_slotptrs[2 * p + 1] = (const float *)d_slots1[p];
@@ -1030,7 +1069,7 @@ extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(h->pending_P > 0, "urf_pm_fetch: no batch in flight (urf_match_device_async first)");
   URF_CHECK(P == h->pending_P, "urf_pm_fetch: %d pairs asked, the batch in flight has %d", P, h->pending_P);
-  URF_CHECK(h->begun_P == 0, "urf_pm_fetch_begin: the previous batch has not been handed out yet (urf_pm_fetch_end first)");
+  URF_CHECK(h->bq_n < urf_pm::kBegun, "urf_pm_fetch_begin: two batches of this handle have not been handed out yet (urf_pm_fetch_end first)");
   URF_HIP(hipSetDevice(h->device));
   URF_HIP(hipEventSynchronize(h->ev_done));  // only this handle's last batch, not the whole stream
   pm_collect_times(h);
@@ -1041,29 +1080,42 @@ extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
     URF_HIP(hipMemcpyAsync(h->h_matches, h->fmatches, (size_t)P * NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, h->st));
     URF_HIP(hipStreamSynchronize(h->st));
   }
-  const int r2 = pm_redo_start(h);
+  const int r2 = pm_begin_batch(h);
   if (r2 < 0) return -3;
-  h->begun_P = P; h->begun_set = h->cur_set;
   h->pending_P = 0;
   return r2;
 }
 
+// 1: urf_pm_fetch_end would not block (the oldest begun batch needed no redo, or its redo has delivered); 0: it would; < 0: error
+extern "C" int urf_pm_fetch_ready(urf_pm *h) {
+  URF_CHECK(h && h->built, "PointMatching handle is not built");
+  URF_CHECK(h->bq_n > 0, "urf_pm_fetch_ready: no fetch has begun (urf_pm_fetch_begin first)");
+  const urf_pm::Begun &e = h->bq[h->bq_head];
+  if (e.n == 0) return 1;
+  URF_HIP(hipSetDevice(h->device));
+  const hipError_t q = hipEventQuery(e.ev_done);
+  if (q == hipSuccess) return 1;
+  if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  URF_HIP(q);
+  return 0;
+}
+
 extern "C" int urf_pm_fetch_end(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
-  URF_CHECK(h->begun_P > 0, "urf_pm_fetch_end: no fetch has begun (urf_pm_fetch_begin first)");
-  URF_CHECK(P == h->begun_P, "urf_pm_fetch_end: %d pairs asked, the batch being handed out has %d", P, h->begun_P);
+  URF_CHECK(h->bq_n > 0, "urf_pm_fetch_end: no fetch has begun (urf_pm_fetch_begin first)");
+  URF_CHECK(P == h->bq[h->bq_head].P, "urf_pm_fetch_end: %d pairs asked, the batch being handed out has %d", P, h->bq[h->bq_head].P);
   URF_CHECK(out && nout, "urf_pm_fetch: bad argument");
   URF_HIP(hipSetDevice(h->device));
-  if (pm_redo_finish(h) < 0) return -3;
-  const urf_dmatch *hm = h->hm_set[h->begun_set];
-  const int *hn = h->hn_set[h->begun_set];
+  int set = 0;
+  if (pm_end_batch(h, &set, nullptr) < 0) return -3;
+  const urf_dmatch *hm = h->hm_set[set];
+  const int *hn = h->hn_set[set];
+  h->fetched_set = set;
   for (int p = 0; p < P; ++p) URF_CHECK(hn[p] >= 0 && hn[p] <= cap, "match buffer too small: %d > cap %d", hn[p], cap);
   for (int p = 0; p < P; ++p) {
     nout[p] = hn[p];
     memcpy(out + (size_t)p * cap, hm + (size_t)p * NP, (size_t)hn[p] * sizeof(urf_dmatch));
   }
-  h->fetched_set = h->begun_set;
-  h->begun_P = 0;
   return 0;
 }
 

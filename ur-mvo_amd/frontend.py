@@ -307,8 +307,12 @@ class PointMatching(_PM):
         0 when the lists are final."""
         return check(_lib.lib().urf_pm_fetch_begin(self._h, P), "urf_pm_fetch_begin")
 
+    def fetch_ready(self):
+        """True when fetch_end() would not block (the oldest begun batch needed no redo, or its redo has delivered)"""
+        return check(_lib.lib().urf_pm_fetch_ready(self._h), "urf_pm_fetch_ready") == 1
+
     def fetch_end(self, P, as_arrays=False):
-        """second half of fetch(): waits for the redo, if any, and returns the lists"""
+        """second half of fetch(): waits for the redo of the oldest begun batch, if one runs, and returns its lists"""
         out = np.zeros((P, CAP), dtype=MATCH_DTYPE)
         n = (C.c_int * P)()
         check(_lib.lib().urf_pm_fetch_end(self._h, P, _p(out), CAP, n), "urf_pm_fetch_end")

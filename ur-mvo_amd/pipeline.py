@@ -26,9 +26,12 @@ from . import frontend as F
 from . import _lib
 
 
+MAX_BEGUN = 2      # begun batches a PointMatching handle holds (include/urf.h: urf_pm_fetch_begin)
+
+
 class SlotRingPipeline:
     def __init__(self, sp, pms, d_frames, batch, H, W, *, device, rank=0, world=1, comm=None, gloo=False, overlap=2,
-                 outlier_rejection=True, keep_gathered=False, sp_ahead=2):
+                 outlier_rejection=True, keep_gathered=False, sp_ahead=2, defer=2):
         """sp / pms: built SuperPoint / PointMatching handles on `device` (max_batch = max_pairs = batch).
         d_frames: u8 tensor [NB * batch, H, W] on the device, this rank's frames of NB consecutive global batches
         (cycled); NB >= len(pms) + 1 + sp_ahead.  comm: this rank's D.Comm (RCCL, world-of-one RCCL, or loopback) -- with it
@@ -36,7 +39,10 @@ class SlotRingPipeline:
         sp_ahead: how many batches SuperPoint is enqueued ahead of the matcher (step b enqueues match(b) and SP(b + sp_ahead)).
         2 (default): the host waits for the lists of batch b - len(pms) + 1 with TWO batches of SuperPoint work queued, so a
         matcher that takes long over one batch (the strict mode's exact redo of a flagged pair: ~5 ms of dependent launches)
-        does not drain SuperPoint's stream -- the critical path -- while the host waits; 1 = the round-3 loop."""
+        does not drain SuperPoint's stream -- the critical path -- while the host waits; 1 = the round-3 loop.
+        defer: how many steps the hand-out of a batch whose flagged pairs are being redone may lag (0: the host waits for
+        the redo in the step that finds it).  With the exchange the lists of batch g are shipped in step g + len(pms), which
+        bounds the lag at 1."""
         self.sp, self.pms = sp, list(pms)
         self.B, self.H, self.W = int(batch), int(H), int(W)
         self.dev, self.rank, self.world = device, int(rank), int(world)
@@ -44,6 +50,7 @@ class SlotRingPipeline:
         self.NB = d_frames.shape[0] // self.B
         self.overlap = overlap if len(self.pms) == 1 else 2
         self.ahead = int(sp_ahead) if self.overlap == 2 else 1
+        self.defer = max(0, min(int(defer), MAX_BEGUN))
         # ring slot k is refilled by SuperPoint(b + NB), enqueued in step b + NB - ahead; the last slot of batch b is read by
         # match(b + 1), which the host has fetched by step b + M: NB >= M + 1 + ahead
         assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 1 + self.ahead, "ring too short for the matchers"
@@ -148,7 +155,7 @@ class SlotRingPipeline:
         if self.comm is not None:
             M = len(self.pms)
             if b - M > self.gathered_upto:
-                if self.pending and self.pending[0][0] == b - M and self.pending[0][2]:
+                while self.pending and self.pending[0][0] <= b - M and self.pending[0][2]:
                     self._late.append(self._hand_out(self._record))        # its redo has had a step's time: finish it, then ship
                 assert all(e[0] != b - M for e in self.pending), "gather of a batch that was not fetched yet"
                 self._gather(b - M)
@@ -178,15 +185,19 @@ class SlotRingPipeline:
         self.pending.append([b, mt, False])
         self._record = record
         out, self._late = self._late, []
-        # keep len(pms) - 1 batches in flight behind the host -- one more while the oldest one's flagged pairs are being redone
-        # (strict parity): its fetch has begun, the redo runs on the engine's stream beside this handle's next batch, and the
-        # lists are handed out a step later, in order
-        while len(self.pending) >= len(self.pms):
-            head = self.pending[0]
-            if not head[2] and head[1].fetch_begin(self.B) == 1 and len(self.pending) == len(self.pms):
-                head[2] = True
-                break
-            head[2] = True
+        # The host stays len(pms) - 1 batches behind the enqueue: every older batch has its fetch BEGUN (the host waits for
+        # that batch's fast pass only; strict parity: the exact redo of its flagged pairs starts on the handle's redo engine,
+        # beside the handle's next batches).  Batches are handed out in order, as soon as the head is final -- a head whose
+        # redo still runs is waited for only once `defer` younger batches have queued up behind the len(pms) - 1 (a handle
+        # holds at most two begun batches: MAX_BEGUN).
+        M = len(self.pms)
+        for e in self.pending[:len(self.pending) - (M - 1)]:
+            if not e[2]:
+                while sum(1 for q in self.pending if q[2] and q[1] is e[1]) >= MAX_BEGUN:
+                    out.append(self._hand_out(record))
+                e[1].fetch_begin(self.B)
+                e[2] = True
+        while self.pending and self.pending[0][2] and (len(self.pending) >= M + self.defer or self.pending[0][1].fetch_ready()):
             out.append(self._hand_out(record))
         return out
 
