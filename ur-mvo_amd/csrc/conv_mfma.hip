@@ -461,6 +461,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvArgs &a, float *smem, c
     const int S = nchunks * TAPS;
     issue_w(0, 0, wpf);
     if (S > 1) issue_w(1 / TAPS, 1 % TAPS, wpf2);
+    if (TAPS == 1) issue_in(0);
     auto stage = [&](int s2, f32x4 *wr) {
       const int ch = s2 / TAPS, tap = s2 % TAPS;
       const int c0 = ch * 64;
@@ -469,6 +470,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvArgs &a, float *smem, c
       commit_w(wr);
       __syncthreads();
       if (s2 + 2 < S) issue_w((s2 + 2) / TAPS, (s2 + 2) % TAPS, wr);
+      if (TAPS == 1 && ch + 1 < nchunks) issue_in(ch + 1);   // (linear layers: the next chunk's rows fly beside this chunk's MFMAs)
       compute_tap(tap, kc);
       __syncthreads();
     };
@@ -570,7 +572,13 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   // the redo pass of the guarded fast mode (target-gated launches: a handful of live tiles): 16 output channels per workgroup
   static const bool split_env = [] { const char *e = urf::exp_env("URF_GUARD_SPLIT"); return !e || atoi(e) != 0; }();
   const bool split = split_env && taps == 9 && !fuse1a && a.gate && a.t_scale > 0;   // (conv1: its fused first layer would be redone per quarter)
-  grid.y = split ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
+  // a.narrow (the linear layers of ONE pair on a handle of its own: the per-pair host API): 64 - 192 full tiles for 256 CUs, each as
+  // long as one wave's chain of 8 accumulators x Cin / 4 MFMAs -- a quarter of the channels per workgroup instead: four times the
+  // workgroups, a quarter of the chain; one pair alone 4.41 -> 3.87 ms.  Same fma chain per output.  NOT for the redo engine of a
+  // strict-parity handle, whose launches run beside three saturated streams: there the four-fold staging of the rows is chip time
+  // the other streams lose (1044 against 1066 frames/s), and not for two pairs (3.37 against 3.25 ms alone).
+  const bool narrow = taps == 1 && a.narrow && !a.gate && (a.Cout % 16) == 0 && a.Cout >= 64;
+  grid.y = (split || narrow) ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
   grid.z = batch;
   // full-frame 3x3 launches with whole 64-channel tiles: the weights by LDS-DMA (URF_CONV_WDMA=0 in an experiments build: through registers)
   static const bool wdma_on = [] { const char *e = urf::exp_env("URF_CONV_WDMA"); return !e || atoi(e) != 0; }();
@@ -586,6 +594,7 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<1, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     const int mxd = 80 * 1024;
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
@@ -610,6 +619,8 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     hipLaunchKernelGGL((conv_mfma_kernel<9, true, false>), grid, block, lds, st, a);
   } else if (taps == 9) {
     hipLaunchKernelGGL((conv_mfma_kernel<9, false, false>), grid, block, lds, st, a);
+  } else if (narrow) {
+    hipLaunchKernelGGL((conv_mfma_kernel<1, false, false, 1>), grid, block, lds, st, a);
   } else {
     hipLaunchKernelGGL((conv_mfma_kernel<1, false, false>), grid, block, lds, st, a);
   }

@@ -120,6 +120,8 @@ struct urf_pm {
   hipEvent_t ev_attn[18][2];
   float stage_ms[PT_COUNT + 2];      // [PT_COUNT + 1]: the exact redo of the batch's flagged pairs (host time: enqueue + wait)
   bool ev_valid = false;
+  bool is_engine = false;    // this handle is the redo engine of a strict-parity handle (its launches run beside saturated streams)
+  bool tail_exact = false;   // the exact mode's Sinkhorn behind the fast layers (strict parity: a smaller matcher margin)
   int pending_P = 0;     // pairs of the batch enqueued by urf_match_device_async and not fetched yet (0 = none)
   // guarded modes (precision 2, 3): per-pair guard words (device + pinned mirror), counters
   bool fast = false, guarded = false, strict = false;
@@ -377,6 +379,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     h->rs_xbc_bytes = sinkhorn_resident_xbc_granules((int)P) * sizeof(unsigned long long);
     if (dalloc(&h->rs_xin, sinkhorn_resident_xin_granules((int)P)) || dalloc(&h->rs_xbc, sinkhorn_resident_xbc_granules((int)P))) return -1;
   }
+  if (const char *e = urf::exp_env("URF_TAIL_EXACT")) h->tail_exact = atoi(e) != 0;   // experiments build
   if (h->guarded) {
     if (dalloc(&h->g_flags, P)) return -1;
     URF_HIP(hipHostMalloc((void **)&h->h_gflags, P * sizeof(int), hipHostMallocDefault));
@@ -460,6 +463,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     urf_sg_config rc = h->cfg;
     rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
     if (urf_pm_create(&rc, &h->redo)) return -1;
+    h->redo->is_engine = true;
     if (urf_pm_build(h->redo, blob, n_floats)) return -1;
     for (int k = 0; k < urf_pm::kBegun; ++k)
       if (dalloc(&h->bq[k].counts, NI) || dalloc(&h->bq[k].kxy, NI * NP * 2) || dalloc(&h->bq[k].x, NI * NP * 256)) return -1;
@@ -523,6 +527,7 @@ static int sg_linear(urf_pm *h, int nimg, const float *in, int in_ld, int cin, c
   a.res = res; a.res_ld = out_ld; a.res_bstride = (long)NP * out_ld;
   a.relu = relu ? 1 : 0;
   a.counts = h->counts;
+  a.narrow = (nimg <= 2 && !h->is_engine) ? 1 : 0;
   // (one or two pairs -- the per-pair host API, the redo engine of a strict-parity handle: the 128 x 128 tiles of gemm128 would
   // be 64 - 96 workgroups for 256 CUs; the 128 x 64 tiles below are twice as many and half as long.  Same fma chains.)
   static const int small_nimg = [] { const char *e = urf::exp_env("URF_GEMM128_MIN_IMAGES"); return e ? atoi(e) : 5; }();
@@ -677,13 +682,13 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
   mark(PT_SINKHORN);
   (void)hipEventRecord(h->ev_sink, st);
-  if (fast && h->rs_on) {
+  if (fast && h->rs_on && !h->tail_exact) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
     if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
                                  h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, st))
       return -1;
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, fast, st)) return -1;
+  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, fast && !h->tail_exact, st)) return -1;
   mark(PT_DECODE);
   const bool guard = fast && h->guarded;
   if (guard) URF_HIP(hipMemsetAsync(h->g_flags, 0, P * sizeof(int), st));

@@ -73,6 +73,7 @@ struct ConvArgs {
   int res_ld, res_coff;
   int relu;
   const int *counts;     // optional per-batch-item valid row count (TAPS==1)
+  int narrow;            // TAPS==1: 16 output channels per workgroup (a lone pair's linear layers: latency, not throughput)
   // fused conv1a (FUSE1A): in = u8 image H x W
   const float *w1a;      // [9][64]
   const float *b1a;      // [64]
