@@ -305,6 +305,48 @@ def test_guarded_mode_redoes_flagged_frames_and_pairs_in_the_exact_mode(U, F, sp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", [3, 2])
+def test_the_pipeline_is_reproducible_run_to_run_soak(U, F, sp_blob, sg_blob, prec):
+    """Oracle-free soak of the benched loop on the 1241x376 stream (period 5 batches): batch b and batch b + 5 must give the SAME
+    lists, distances included, for 1500 steps.  Round 4 found the register-resident Sinkhorn NOT reproducible in the strict mode
+    (about one pair in 500 with distances off by 1e-5 ... 3e-2, index lists intact: a transient fault inside the 100 iterations,
+    only beside the exact convolutions and only when its workgroups share their CUs) -- strict handles
+    therefore run the Sinkhorn form that keeps its CUs to itself.  tools/gpu_determinism.py is the long form of this test."""
+    import torch
+    H, W, B = 376, 1241, 8
+    steps = 1500
+    frames = U.synth.shift_stream(100, 40, H, W)
+    dev = torch.device("cuda", 0)
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=B, precision=prec)
+    assert sp.build(sp_blob)
+    pms = []
+    for _ in range(2):
+        pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=B, precision=prec)
+        assert pm.build(sg_blob)
+        pms.append(pm)
+    pipe = U.pipeline.SlotRingPipeline(sp, pms, d_frames, B, H, W, device=dev)
+    pipe.prologue()
+    lists, bad = {}, []
+
+    def rec(b, mt, res):
+        lists[b] = [r.copy() for r in res]
+        if b >= 6:
+            for j in range(B):
+                if not np.array_equal(lists[b][j], lists[b - 5][j]):
+                    bad.append((b, j))
+        lists.pop(b - 10, None)
+
+    for b in range(steps):
+        pipe.one_step(b, rec)
+    pipe.drain(rec)
+    assert not bad, bad[:10]
+    assert sum(m.sinkhorn_fallbacks() for m in pms) == 0
+    if prec == 3:
+        assert sum(m.near_tie_reruns()["redone"] for m in pms) >= steps // 5 - 2       # (one flagged pair per period on this stream)
+
+
+@pytest.mark.gpu
 def test_a_handle_holds_two_begun_batches_and_hands_them_out_in_order(U, F, sp_blob, sg_blob):
     """urf_pm_fetch_begin / _ready / _end (include/urf.h): with every pair flagged (absurd margin) three batches of ONE handle
     are in flight -- two begun, their exact redos queued on the engine, the third computing -- and come out in order, each with

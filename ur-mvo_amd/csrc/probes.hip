@@ -335,3 +335,40 @@ extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int 
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
 }
+
+#ifdef URF_EXPERIMENTS
+// diagnostic (experiments build, tools/gpu_lds_watch.py): does anything else on the CU write into a workgroup's LDS / registers?
+// Every workgroup fills its LDS (static head + dynamic tail) and a few registers with an address pattern and re-checks them for
+// `ticks` of s_memrealtime while other streams' kernels (LDS-DMA users among them) come and go on the same CUs.
+__global__ void __launch_bounds__(256) lds_watch_kernel(unsigned lds_words, unsigned long long ticks, unsigned long long *bad, unsigned *first) {
+  extern __shared__ unsigned wsm[];
+  const unsigned salt = 0x9E3779B9u * (blockIdx.x + 1);
+  for (unsigned i = threadIdx.x; i < lds_words; i += blockDim.x) wsm[i] = i ^ salt;
+  float r0 = (float)threadIdx.x, r1 = r0 * 3.0f + 1.0f, r2 = r0 * 5.0f + 2.0f;   // register canaries through DPP-free arithmetic
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long nbad = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    for (unsigned i = threadIdx.x; i < lds_words; i += blockDim.x) {
+      const unsigned v = wsm[i];
+      if (v != (i ^ salt)) {
+        if (nbad == 0 && atomicAdd(bad + 1, 1ull) == 0) { first[0] = blockIdx.x; first[1] = i; first[2] = v; first[3] = i ^ salt; }
+        nbad += 1;
+        wsm[i] = i ^ salt;
+      }
+    }
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2));
+    if (r1 != r0 * 3.0f + 1.0f || r2 != r0 * 5.0f + 2.0f) nbad += 1u << 20;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+extern "C" int urf_probe_lds_watch(int device, int wgs, int lds_bytes, double ms, void *stream, unsigned long long *d_bad, unsigned *d_first) {
+  URF_HIP(hipSetDevice(device));
+  URF_HIP(hipFuncSetAttribute((const void *)lds_watch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(lds_watch_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned)(lds_bytes / 4),
+                     (unsigned long long)(ms * 1e5), d_bad, d_first);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+#endif

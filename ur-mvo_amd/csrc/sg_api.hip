@@ -30,9 +30,10 @@ size_t sinkhorn_resident_xin_granules(int maxP);
 size_t sinkhorn_resident_xbc_granules(int maxP);
 int sinkhorn_resident_enabled();
 int sinkhorn_resident_supported(int device);
+void sinkhorn_resident_set_debug(unsigned long long *p);
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
-                             hipStream_t st);
+                             int exclusive, hipStream_t st);
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
@@ -120,6 +121,7 @@ struct urf_pm {
   hipEvent_t ev_attn[18][2];
   float stage_ms[PT_COUNT + 2];      // [PT_COUNT + 1]: the exact redo of the batch's flagged pairs (host time: enqueue + wait)
   bool ev_valid = false;
+  int cks_slot = 0;          // experiments build: row of the checksum table (URF_CHECKSUMS)
   bool is_engine = false;    // this handle is the redo engine of a strict-parity handle (its launches run beside saturated streams)
   bool tail_exact = false;   // the exact mode's Sinkhorn behind the fast layers (strict parity: a smaller matcher margin)
   int pending_P = 0;     // pairs of the batch enqueued by urf_match_device_async and not fetched yet (0 = none)
@@ -608,6 +610,11 @@ static int pm_gnn_fast(urf_pm *h, int NI, bool prof) {
 }
 
 static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast);
+#ifdef URF_EXPERIMENTS
+static int pm_checksum(urf_pm *h, int slot, int k, const void *x, size_t n_words);
+static unsigned long long *g_rsdbg_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+constexpr size_t kRsDbgWords = (size_t)8 * 128 * 32 * 2;
+#endif
 
 // keypoint encoder: 4(3)->32->64->128->256->256, + descriptors; fp32 in every mode
 static int pm_kenc(urf_pm *h, int NI) {
@@ -621,11 +628,15 @@ static int pm_kenc(urf_pm *h, int NI) {
 // the 18 GNN layers and the final projection in the exact mode, in place on h->x (-> h->mdesc)
 static int pm_gnn_exact(urf_pm *h, int NI, bool prof) {
   hipStream_t st = h->st;
+  // (experiments build, what-if timing of the redo engine: bit 0 = no attention, bit 1 = no linear layers; results are NOT exact)
+  static const int skip_env = [] { const char *e = urf::exp_env("URF_REDO_SKIP"); return e ? atoi(e) : 0; }();
+  const int skip = h->is_engine ? skip_env : 0;
   for (int l = 0; l < SG_LAYERS; ++l) {
+    if (skip & 2) { if (!(skip & 1) && launch_attn(h->qkv, h->counts, l & 1, h->o, NI, st)) return -1; continue; }
     if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->L[l].wqkv, h->L[l].bqkv, 768, h->qkv, 768, false, nullptr))
       return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][0], st);
-    if (launch_attn(h->qkv, h->counts, l & 1, h->o, NI, st)) return -1;
+    if (!(skip & 1) && launch_attn(h->qkv, h->counts, l & 1, h->o, NI, st)) return -1;
     if (prof) (void)hipEventRecord(h->ev_attn[l][1], st);
     if (sg_linear(h, NI, h->o, 256, 256, nullptr, 0, 0, h->L[l].wm, h->L[l].bm, 256, h->msg, 256, false, nullptr))
       return -1;
@@ -679,16 +690,46 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
 static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool fast) {
   hipStream_t st = h->st;
   auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->ev[i], st); };
+#ifdef URF_EXPERIMENTS
+  if (!h->is_engine) {
+    static int next_slot = 0;
+    if (h->cks_slot == 0) h->cks_slot = 1 + (next_slot++ % 3);
+    if (pm_checksum(h, h->cks_slot, 0, h->x, (size_t)2 * P * NP * 256)) return -1;          // the encoded keypoints (fp32, before the layers)
+    if (pm_checksum(h, h->cks_slot, 1, h->mdesc, (size_t)2 * P * NP * 256)) return -1;      // the projected descriptors (after the layers)
+  }
+#endif
   if (launch_score(h->mdesc, h->counts, h->bin_score, h->C, h->Ct, h->u, h->v, P, st)) return -1;
+#ifdef URF_EXPERIMENTS
+  if (!h->is_engine && pm_checksum(h, h->cks_slot, 2, h->C, (size_t)P * (NP + 1) * LDC)) return -1;   // the couplings
+#endif
   mark(PT_SINKHORN);
   (void)hipEventRecord(h->ev_sink, st);
+#ifdef URF_EXPERIMENTS
+  if (fast && h->rs_on && !h->is_engine) {
+    static const int dbg_on = [] { const char *e = urf::exp_env("URF_RS_DEBUG"); return e ? atoi(e) : 0; }();
+    if (dbg_on && h->cks_slot > 0) {
+      if (!g_rsdbg_dev[h->cks_slot]) URF_HIP(hipMalloc((void **)&g_rsdbg_dev[h->cks_slot], kRsDbgWords * 8));
+      URF_HIP(hipMemsetAsync(g_rsdbg_dev[h->cks_slot], 0, kRsDbgWords * 8, st));
+      sinkhorn_resident_set_debug(g_rsdbg_dev[h->cks_slot]);
+    }
+  }
+#endif
   if (fast && h->rs_on && !h->tail_exact) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
     if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
-                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, st))
+                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, h->strict ? 1 : 0, st))
       return -1;
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  } else if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, h->iters, P, fast && !h->tail_exact, st)) return -1;
+  } else {
+    static const int skip_env = [] { const char *e = urf::exp_env("URF_REDO_SKIP"); return e ? atoi(e) : 0; }();   // bit 2: one Sinkhorn iteration
+    if (launch_sinkhorn(h->counts, h->C, h->Ct, h->u, h->v, (h->is_engine && (skip_env & 4)) ? 1 : h->iters, P, fast && !h->tail_exact, st)) return -1;
+  }
+#ifdef URF_EXPERIMENTS
+  if (!h->is_engine) {
+    if (pm_checksum(h, h->cks_slot, 3, h->u, (size_t)P * LDC)) return -1;
+    if (pm_checksum(h, h->cks_slot, 4, h->v, (size_t)P * LDC)) return -1;
+  }
+#endif
   mark(PT_DECODE);
   const bool guard = fast && h->guarded;
   if (guard) URF_HIP(hipMemsetAsync(h->g_flags, 0, P * sizeof(int), st));
@@ -1070,6 +1111,46 @@ extern "C" int urf_pm_sync(urf_pm *h) {
 // words and STARTS the exact redo of the flagged pairs (strict parity) on the redo engine's stream; returns 1 when a redo is
 // running, 0 when the lists are final already.  The caller may now enqueue this handle's next batch (urf_match_device_async):
 // it runs beside the redo.  end: waits for the redo (if any) and hands the lists out.
+#ifdef URF_EXPERIMENTS
+// diagnostic (experiments build, URF_CHECKSUMS=1): order-independent 64-bit sums of the bit patterns of a stage's tensors, one set
+// per batch, so that a run-to-run difference of a periodic stream can be pinned to the stage that produced it
+__global__ void urf_checksum_kernel(const unsigned *x, size_t n, unsigned long long *out) {
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += x[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+static unsigned long long *g_cks_dev = nullptr, *g_cks_host = nullptr;   // [handle slot 0..3][8]
+static int pm_checksum(urf_pm *h, int slot, int k, const void *x, size_t n_words) {
+  static const int on = [] { const char *e = urf::exp_env("URF_CHECKSUMS"); return e ? atoi(e) : 0; }();
+  if (!on) return 0;
+  if (!g_cks_dev) {
+    URF_HIP(hipMalloc((void **)&g_cks_dev, 4 * 8 * sizeof(unsigned long long)));
+    URF_HIP(hipHostMalloc((void **)&g_cks_host, 4 * 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  unsigned long long *d = g_cks_dev + 8 * slot + k;
+  URF_HIP(hipMemsetAsync(d, 0, sizeof(*d), h->st));
+  hipLaunchKernelGGL(urf_checksum_kernel, dim3(256), dim3(256), 0, h->st, (const unsigned *)x, n_words, d);
+  URF_HIP(hipMemcpyAsync(g_cks_host + 8 * slot + k, d, sizeof(*d), hipMemcpyDeviceToHost, h->st));
+  return 0;
+}
+extern "C" int urf_probe_pm_rs_debug(urf_pm *h, unsigned long long *out) {    // the per-iteration bit sums of the handle's last resident Sinkhorn launch
+  if (!g_rsdbg_dev[h->cks_slot]) return -1;
+  URF_HIP(hipMemcpyAsync(out, g_rsdbg_dev[h->cks_slot], kRsDbgWords * 8, hipMemcpyDeviceToHost, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));
+  return 0;
+}
+extern "C" int urf_probe_pm_checksums(urf_pm *h, unsigned long long *out) {   // of the handle's LAST enqueued batch (after its fetch_begin)
+  if (!g_cks_host) return -1;
+  for (int k = 0; k < 8; ++k) out[k] = g_cks_host[8 * h->cks_slot + k];
+  return 0;
+}
+
+// what-if (experiments build): URF_DUMMY_LAUNCHES=n dependent launches of an empty / a tiny-store kernel on the redo engine's
+// stream per begun batch -- what do kernel boundaries alone cost the other streams?
+__global__ void urf_dummy_kernel(int *p, int touch) { if (touch && threadIdx.x == 0) p[blockIdx.x] = touch; }
+#endif
+
 extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(h->pending_P > 0, "urf_pm_fetch: no batch in flight (urf_match_device_async first)");
@@ -1087,6 +1168,14 @@ extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
   }
   const int r2 = pm_begin_batch(h);
   if (r2 < 0) return -3;
+#ifdef URF_EXPERIMENTS
+  {
+    static const int dummy = [] { const char *e = urf::exp_env("URF_DUMMY_LAUNCHES"); return e ? atoi(e) : 0; }();
+    static const int dummy_wgs = [] { const char *e = urf::exp_env("URF_DUMMY_WGS"); return e ? atoi(e) : 1; }();
+    if (dummy > 0 && h->redo)
+      for (int i = 0; i < dummy; ++i) hipLaunchKernelGGL(urf_dummy_kernel, dim3(dummy_wgs), dim3(64), 0, h->redo->st, h->redo->counts, 0);
+  }
+#endif
   h->pending_P = 0;
   return r2;
 }

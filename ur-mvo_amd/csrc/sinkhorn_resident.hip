@@ -59,6 +59,8 @@ struct RsArgs {
   u64 *xin, *xbc;
   unsigned salt;
   int *err;
+  unsigned long long *dbg;   // diagnostic (experiments build, URF_RS_DEBUG=1): [pair][iteration][workgroup][2] bit sums of a_i and of the reduced column sums
+  int poll_rmw;        // diagnostic (experiments build, URF_SINKHORN_RMW=1): the polls of the register kernel as atomic ORs of 0
   int allow_near;      // 0: always the agent-scope granule stores (A/B runs, URF_SINKHORN_NEAR=0)
   long long *stamps;   // diagnostic runs only (urf_probe_sinkhorn_stamps): s_memtime at 8 points of every iteration
 };
@@ -104,7 +106,7 @@ __device__ __forceinline__ bool rs_wait(const u64 *p, bool active, unsigned tag,
 // only meaningful for the pass that returns true.
 template <int N, bool SUM>
 __device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned tag, float &sum, float *dst, int lane, int *err,
-                                         unsigned *passes = nullptr) {
+                                         unsigned *passes = nullptr, bool rmw = false) {
   u64 t0 = 0;
   const gu64 *q = (const gu64 *)base + lane;
   for (unsigned spins = 1;; ++spins) {
@@ -116,7 +118,10 @@ __device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned ta
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       x[k] = 0;
-      if (lane + 64 * k < count) x[k] = __hip_atomic_load(q + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane + 64 * k < count) {
+        if (rmw) x[k] = __hip_atomic_fetch_or((u64 *)(q + 64 * k), (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostic: a read-modify-write at the L2
+        else x[k] = __hip_atomic_load(q + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -163,8 +168,16 @@ __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lane
   return v;
 }
 
+#ifdef URF_EXPERIMENTS
+#define RS_RMW(a) ((a).poll_rmw != 0)
+#else
+#define RS_RMW(a) false
+#endif
 #define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#ifdef URF_EXPERIMENTS   // the LDS-resident form of round 2 (superseded by the register-resident kernel): experiments build only
+// The LDS-resident form (round 2): 1024 threads and 144 KB of LDS per workgroup, so a CU that hosts one hosts nothing else.  The
+// register-resident kernel below superseded it where sharing the CU pays (fast and guarded modes); the STRICT mode runs this one:
+// beside the exact convolutions the register form is not reproducible run to run ("a fault that only a
+// soak test finds"), a workgroup that has its CU to itself is.
 __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Pt = lds;                      // [32][1024] plan rows of this workgroup
@@ -404,7 +417,6 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
     }
   }
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Register-resident variant (URF_SINKHORN_REGS=1).  Same recurrence, same exchange, but the plan tile lives in VGPRs:
@@ -416,6 +428,10 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
 
 // wave-wide sum whose total is only valid in lane 63 (wave_sum_dpp without the broadcast)
 __device__ __forceinline__ float wave_sum_dpp_l63(float v) {
+#ifdef URF_RS_NO_DPP
+  for (int o = 1; o < 64; o <<= 1) v = v + __shfl_xor(v, o, 64);
+  return v;
+#endif
   auto dpp = [](float x, auto ctrl, auto rows) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
   };
@@ -436,7 +452,13 @@ __device__ __forceinline__ float wave_sum_dpp_l63(float v) {
 typedef unsigned rs_u32x2 __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ float rs_dpp(float x) {
+#ifdef URF_RS_NO_DPP   // diagnostic build: the same lane permutations through ds_bpermute
+  const int l = (int)(threadIdx.x & 63);
+  const int src = CTRL == 0x140 ? ((l & ~15) | (15 - (l & 15))) : CTRL == 0x141 ? ((l & ~7) | (7 - (l & 7))) : CTRL == 0x4E ? (l ^ 2) : (l ^ 1);
+  return __shfl(x, src, 64);
+#else
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+#endif
 }
 __device__ __forceinline__ int rs_row_of_lane(int l) {
   return 16 * (l >> 5) + 8 * ((l >> 4) & 1) + 4 * ((l >> 3) & 1) + 2 * ((l >> 2) & 1) + ((l >> 1) & 1);
@@ -446,13 +468,24 @@ __device__ __forceinline__ float rs_rows32_sum(VAL val, int lane) {   // val(r) 
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {      // lanes 0-31 keep row r, lanes 32-63 row r + 16
+#ifdef URF_RS_NO_PERMLANE_SWAP        // diagnostic build: the same sums (the additions commute) through ds_bpermute
+    const float x0 = val(r), x1 = val(r + 16);
+    const bool hi = (lane & 32) != 0;
+    v[r] = (hi ? x1 : x0) + __shfl_xor(hi ? x0 : x1, 32, 64);
+#else
     const rs_u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(val(r)), __float_as_uint(val(r + 16)), false, false);
     v[r] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+#endif
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {       // 16-lane rows 0, 2 keep row r (+16), rows 1, 3 row r + 8 (+16)
+#ifdef URF_RS_NO_PERMLANE_SWAP
+    const bool hi = (lane & 16) != 0;
+    v[r] = (hi ? v[r + 8] : v[r]) + __shfl_xor(hi ? v[r] : v[r + 8], 16, 64);
+#else
     const rs_u32x2 x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 8]), false, false);
     v[r] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+#endif
   }
   const bool b8 = (lane & 8) != 0, b4 = (lane & 4) != 0, b2 = (lane & 2) != 0;
 #pragma unroll
@@ -641,6 +674,13 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
     }
     __syncthreads();                      // avec written
     RS_STAMP(2);
+#ifdef URF_EXPERIMENTS
+    if (a.dbg && wv == 0) {
+      unsigned long long sb = lane < RS_ROWS ? (unsigned long long)__float_as_uint(avec[lane]) : 0ull;
+      for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+      if (lane == 0) a.dbg[(((size_t)pl * 128 + (k - 1)) * RS_WG + w) * 2] = sb;
+    }
+#endif
     // ---------------- column pass: partial sums over the own 32 rows, all in registers
     float creg[NC];
 #pragma unroll
@@ -676,12 +716,12 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       bool alive = true;
       {
         float x = 0.0f;
-        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err);
+        alive = rs_sweep<16, true>(xin + (size_t)w * RS_WG * 32, RS_WG * 32, tag, x, nullptr, lane, a.err, nullptr, RS_RMW(a));
         x = x + __shfl_xor(x, 32, 64);
         if (alive && lane < 32) rs_store(xbc + 32 * w + lane, tag, x, near);
         if (alive && w == 31) {
           float y = 0.0f;
-          alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RS_WG, tag, y, nullptr, lane, a.err);
+          alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RS_WG, tag, y, nullptr, lane, a.err, nullptr, RS_RMW(a));
           const float ys = half_sum32(lane < 32 ? y : 0.0f);
           if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, near);
         }
@@ -689,7 +729,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       RS_STAMP(4);
       if (alive) {
         float unused = 0.0f;
-        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err);
+        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err, nullptr, RS_RMW(a));
       }
       if (!alive && lane == 0) misc[1] = 1.0f;
       RS_STAMP(5);
@@ -697,6 +737,15 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
     __syncthreads();
     RS_STAMP(6);
     if (misc[1] != 0.0f) return;
+#ifdef URF_EXPERIMENTS
+    if (a.dbg && wv == 0) {
+      unsigned long long sb = 0;
+      for (int q = 0; q < 17; ++q)
+        if (lane + 64 * q < 1025) sb += (unsigned long long)__float_as_uint(csumv[lane + 64 * q]);
+      for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+      if (lane == 0) a.dbg[(((size_t)pl * 128 + (k - 1)) * RS_WG + w) * 2 + 1] = sb;
+    }
+#endif
     float csum_dust = csumv[1024];
     // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
 #pragma unroll
@@ -772,9 +821,12 @@ int sinkhorn_resident_supported(int device) {
   return cus >= RS_WG ? 1 : 0;
 }
 
+static unsigned long long *g_rs_dbg = nullptr;   // diagnostic: where the NEXT launch writes its per-iteration bit sums (sg_api.hip, URF_RS_DEBUG)
+void sinkhorn_resident_set_debug(unsigned long long *p) { g_rs_dbg = p; }
+
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
-                             hipStream_t st) {
+                             int exclusive, hipStream_t st) {
   URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
   URF_CHECK(iters >= 1 && iters < 4096, "sinkhorn_resident: iterations %d outside [1, 4095]", iters);
   RsDevice &d = g_rs_dev[device];
@@ -784,9 +836,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     hipDeviceProp_t prop;
     URF_HIP(hipGetDeviceProperties(&prop, device));
     d.cus = prop.multiProcessorCount;
-#ifdef URF_EXPERIMENTS
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }
@@ -801,8 +851,10 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // 3 (default since round 3) = the register-resident kernel with FOUR columns per thread: 256 threads, one wave per SIMD at 270
   // VGPRs without a spill, which leaves 240 registers of every SIMD lane to another stream's waves (measured against 1: 0.61 ->
   // 0.53 ms serialised, +1 % in the pipeline at 640x480, even at 1241x376)
-  static int regs = -1;
-  if (regs < 0) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs = e ? atoi(e) : 3; if (regs < 0 || regs > 3) regs = 3; }
+  // `exclusive` (strict-parity handles): the LDS-resident kernel, whose workgroups have their CUs to themselves
+  static int regs_env = -2;
+  if (regs_env == -2) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs_env = e ? atoi(e) : -1; if (regs_env < -1 || regs_env > 3) regs_env = -1; }
+  const int regs = regs_env >= 0 ? regs_env : (exclusive ? 0 : 3);
   int group = d.cus / RS_WG;
   if (regs) {
     const char *e = urf::exp_env("URF_SINKHORN_GROUP");
@@ -834,17 +886,27 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
       static int near_knob = -1;
       if (near_knob < 0) { const char *e = urf::exp_env("URF_SINKHORN_NEAR"); near_knob = e ? (atoi(e) != 0) : 0; }
       a.allow_near = near_knob;
+      static int rmw_knob = -1;
+      if (rmw_knob < 0) { const char *e2 = urf::exp_env("URF_SINKHORN_RMW"); rmw_knob = e2 ? (atoi(e2) != 0) : 0; }
+      a.poll_rmw = rmw_knob;
+      a.dbg = (iters <= 128 && P <= 8) ? g_rs_dbg : nullptr;
+      g_rs_dbg = nullptr;
     }
     a.stamps = g_rs_stamps;
     URF_HIP(hipStreamWaitEvent(st, d.last, 0));
 #ifdef URF_EXPERIMENTS
-    if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);
+    static long lpad = -1;   // what-if: dynamic LDS the kernel never touches (keeps LDS-heavy workgroups of other streams off its CU)
+    if (lpad < 0) {
+      const char *e = urf::exp_env("URF_SINKHORN_LDS_PAD"); lpad = e ? atol(e) : 0;
+      if (lpad > 0) URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_regs_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    }
+    if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), (size_t)lpad, st, a);
     else if (regs == 2) hipLaunchKernelGGL((sinkhorn_regs_kernel<4, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else if (regs) hipLaunchKernelGGL((sinkhorn_regs_kernel<3, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
 #else
-    (void)lds;
-    hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);   // the product carries this form only
+    if (regs == 0) hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
+    else hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);   // the product carries these two forms
 #endif
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));

@@ -50,7 +50,7 @@ class SlotRingPipeline:
         self.NB = d_frames.shape[0] // self.B
         self.overlap = overlap if len(self.pms) == 1 else 2
         self.ahead = int(sp_ahead) if self.overlap == 2 else 1
-        self.defer = max(0, min(int(defer), MAX_BEGUN))
+        self.defer = max(0, min(int(defer), 4))
         # ring slot k is refilled by SuperPoint(b + NB), enqueued in step b + NB - ahead; the last slot of batch b is read by
         # match(b + 1), which the host has fetched by step b + M: NB >= M + 1 + ahead
         assert self.NB * self.B == d_frames.shape[0] and self.NB >= len(self.pms) + 1 + self.ahead, "ring too short for the matchers"
