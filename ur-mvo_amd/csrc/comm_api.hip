@@ -90,12 +90,21 @@ using namespace urf;
 struct LoopHub {
   int world = 0, device = 0;
   std::mutex mu;
-  struct Arg { int kind; const void *src; void *dst; size_t bytes; int root; hipStream_t st; };
+  // a queued call carries its OWN "my send buffer is ready" event, recorded on the stream of that call: a rank may issue two
+  // collectives on different streams before its peers arrive, and each stays ordered behind its own producer stream
+  struct Arg { int kind; const void *src; void *dst; size_t bytes; int root; hipStream_t st; hipEvent_t ready; };
   std::vector<std::deque<Arg>> q;          // pending calls per rank, in call order
-  std::vector<hipEvent_t> ev_in, ev_out;   // per rank: "my send buffer is ready" / "my copies are done"
+  std::vector<hipEvent_t> ev_out;          // per rank: "my copies are done" (recorded and waited for inside one rendezvous)
+  std::vector<hipEvent_t> pool;            // free "ready" events
   long collectives = 0;
+  int take(hipEvent_t *e) {
+    if (!pool.empty()) { *e = pool.back(); pool.pop_back(); return 0; }
+    URF_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return 0;
+  }
   ~LoopHub() {
-    for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
+    for (auto &d : q) for (Arg &a : d) (void)hipEventDestroy(a.ready);
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_out) (void)hipEventDestroy(e);
   }
 };
@@ -172,11 +181,8 @@ extern "C" int urf_comm_init_loopback(int world, int device, urf_comm **out) {
   auto hub = std::make_shared<LoopHub>();
   hub->world = world; hub->device = device;
   hub->q.resize(world);
-  hub->ev_in.resize(world); hub->ev_out.resize(world);
-  for (int r = 0; r < world; ++r) {
-    URF_HIP(hipEventCreateWithFlags(&hub->ev_in[r], hipEventDisableTiming));
-    URF_HIP(hipEventCreateWithFlags(&hub->ev_out[r], hipEventDisableTiming));
-  }
+  hub->ev_out.resize(world);
+  for (int r = 0; r < world; ++r) URF_HIP(hipEventCreateWithFlags(&hub->ev_out[r], hipEventDisableTiming));
   for (int r = 0; r < world; ++r) {
     out[r] = new urf_comm();
     out[r]->world = world; out[r]->rank = r; out[r]->device = device; out[r]->hub = hub;
@@ -188,14 +194,17 @@ extern "C" int urf_comm_init_loopback(int world, int device, urf_comm **out) {
 static int loop_collective(urf_comm *c, int kind, const void *src, void *dst, size_t bytes, int root, hipStream_t st) {
   LoopHub &h = *c->hub;
   std::lock_guard<std::mutex> lock(h.mu);
-  h.q[c->rank].push_back({kind, src, dst, bytes, root, st});
-  // (a later record of the same event only makes an earlier collective wait for more of the same stream)
-  URF_HIP(hipEventRecord(h.ev_in[c->rank], st));
+  hipEvent_t ready = nullptr;
+  if (h.take(&ready)) return -1;
+  URF_HIP(hipEventRecord(ready, st));
+  h.q[c->rank].push_back({kind, src, dst, bytes, root, st, ready});
   for (;;) {
     for (int r = 0; r < h.world; ++r)
       if (h.q[r].empty()) return 0;
     std::vector<LoopHub::Arg> set((size_t)h.world);
     for (int r = 0; r < h.world; ++r) { set[r] = h.q[r].front(); h.q[r].pop_front(); }
+    // (the events go back to the pool whatever happens below: a wait already enqueued keeps the record it was given)
+    struct Back { LoopHub &h; std::vector<LoopHub::Arg> &set; ~Back() { for (auto &a : set) h.pool.push_back(a.ready); } } back{h, set};
     for (int r = 1; r < h.world; ++r)
       URF_CHECK(set[r].kind == set[0].kind && set[r].bytes == set[0].bytes && set[r].root == set[0].root,
                 "loopback ranks 0 and %d disagree on a collective (kind %d/%d, %zu/%zu bytes, root %d/%d)", r, set[0].kind,
@@ -207,7 +216,7 @@ static int loop_collective(urf_comm *c, int kind, const void *src, void *dst, si
     for (int q = 0; q < h.world; ++q) {
       if (gather && q != rt) continue;
       URF_CHECK(set[q].dst, "loopback collective: rank %d has no receive buffer", q);
-      for (int r = 0; r < h.world; ++r) URF_HIP(hipStreamWaitEvent(set[q].st, h.ev_in[r], 0));
+      for (int r = 0; r < h.world; ++r) URF_HIP(hipStreamWaitEvent(set[q].st, set[r].ready, 0));
       for (int r = 0; r < h.world; ++r) {
         char *to = (char *)set[q].dst + (size_t)r * nb;
         if ((const void *)to != set[r].src) URF_HIP(hipMemcpyAsync(to, set[r].src, nb, hipMemcpyDeviceToDevice, set[q].st));
