@@ -97,5 +97,9 @@ for (H, W) in sizes:
                     k = np.nonzero(x != y)[0]
                     print(f"   {W}x{H} precision {prec}: slots of batch {b} frame {j} differ from batch {b - 5} in {k.size} words, first at {k[:4]}"
                           f" (header {x[:4].view(np.int32)} vs {y[:4].view(np.int32)})")
+        if hasattr(U._lib.lib(), "urf_probe_rs_verify"):
+            n_ = ctypes.c_ulonglong(0)
+            U._lib.lib().urf_probe_rs_verify(ctypes.byref(n_))
+            print(f"   load verification inside the register Sinkhorn: {n_.value & 0xFFFFFFFF} couplings read differently by two loads, {n_.value >> 32} column sums read back from LDS differently than written (cumulative)")
         print(f"{W}x{H} precision {prec}: {steps} steps, checksum mismatches {bad_c[0]}, list mismatches {bad_l}, slot-batch mismatches {bad_s}, guard {sp.near_tie_reruns()}, pairs redone {sum(m.near_tie_reruns()['redone'] for m in pms)}")
         del pipe, sp, pms

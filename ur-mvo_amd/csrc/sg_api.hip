@@ -717,7 +717,7 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   if (fast && h->rs_on && !h->tail_exact) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
     if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
-                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, h->strict ? 1 : 0, st))
+                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, h->guarded ? 1 : 0, st))
       return -1;
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
   } else {

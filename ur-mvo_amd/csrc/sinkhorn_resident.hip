@@ -39,7 +39,10 @@ namespace urf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;   // explicitly global: the polling loads must be global_load ... sc1, never flat
+typedef __attribute__((address_space(1))) u64 gu64;
+#ifdef URF_RS_VERIFY_LOADS
+__device__ unsigned long long g_rs_verify_bad = 0;
+#endif   // explicitly global: the polling loads must be global_load ... sc1, never flat
 
 constexpr int RS_NP = kCap;          // 1024 keypoints per image at most
 constexpr int RS_LDC = 1028;         // leading dimension of C in HBM (sg_kernels.hip)
@@ -134,6 +137,16 @@ __device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned ta
     }
     sum = acc;
     if (passes) *passes = spins;
+#ifdef URF_RS_VERIFY_LOADS   // diagnostic build: are the values this wave has just written to LDS the ones it reads back?
+    if (!SUM && __all(ok)) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const int g = lane + 64 * k;
+        if (g < count && __float_as_uint(*(volatile float *)(dst + g)) != (unsigned)x[k]) atomicAdd(&g_rs_verify_bad, 1ull << 32);
+      }
+    }
+#endif
     if (__all(ok)) return true;
     if ((spins & 63u) == 0) {
       const u64 now = __builtin_amdgcn_s_memrealtime();
@@ -175,9 +188,10 @@ __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lane
 #endif
 #define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 // The LDS-resident form (round 2): 1024 threads and 144 KB of LDS per workgroup, so a CU that hosts one hosts nothing else.  The
-// register-resident kernel below superseded it where sharing the CU pays (fast and guarded modes); the STRICT mode runs this one:
-// beside the exact convolutions the register form is not reproducible run to run ("a fault that only a
-// soak test finds"), a workgroup that has its CU to itself is.
+// register-resident kernel below superseded it where sharing the CU pays (the fast mode); the modes that carry a guarantee
+// (guarded and strict) run this one: with other kernels' waves on its CUs the register form is not reproducible run to run
+// ("a fault that only a soak test finds": one pair in 500 beside the exact convolutions, one in 14000
+// beside the fast ones), a workgroup that has its CU to itself is.
 __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Pt = lds;                      // [32][1024] plan rows of this workgroup
@@ -602,6 +616,13 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       float xs[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) xs[c] = Cload(i0 + i, c);
+#ifdef URF_RS_VERIFY_LOADS   // diagnostic build: every coupling read a second time through a plain global load, differences counted
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float y = __builtin_nontemporal_load(Cp + (size_t)(i0 + i) * RS_LDC + tid + T * c);
+        if (__float_as_uint(y) != __float_as_uint(xs[c])) atomicAdd(&g_rs_verify_bad, 1ull);
+      }
+#endif
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const float q = __expf((float)(((double)xs[c] + u0i) + v0c[c]));
@@ -851,7 +872,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // 3 (default since round 3) = the register-resident kernel with FOUR columns per thread: 256 threads, one wave per SIMD at 270
   // VGPRs without a spill, which leaves 240 registers of every SIMD lane to another stream's waves (measured against 1: 0.61 ->
   // 0.53 ms serialised, +1 % in the pipeline at 640x480, even at 1241x376)
-  // `exclusive` (strict-parity handles): the LDS-resident kernel, whose workgroups have their CUs to themselves
+  // `exclusive` (guarded and strict-parity handles): the LDS-resident kernel, whose workgroups have their CUs to themselves
   static int regs_env = -2;
   if (regs_env == -2) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs_env = e ? atoi(e) : -1; if (regs_env < -1 || regs_env > 3) regs_env = -1; }
   const int regs = regs_env >= 0 ? regs_env : (exclusive ? 0 : 3);
@@ -918,6 +939,11 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   return 0;
 }
 
+#ifdef URF_RS_VERIFY_LOADS
+extern "C" int urf_probe_rs_verify(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_verify_bad), sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // namespace urf
 
 // diagnostic: the next resident launches record s_memtime stamps (8 per iteration, workgroup 0) into a device
