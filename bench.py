@@ -430,7 +430,8 @@ def main():
             # chip-resident Sinkhorn (sinkhorn_resident.hip; plan tile in registers, or in LDS with URF_SINKHORN_REGS=0): the
             # couplings are read from HBM/L2 once per (re)absorption (initially and after iterations 1, 2, 4, ... 64: 8
             # times), 2 fma per element and iteration; no roof binds it -- an iteration is one inter-CU exchange (latency)
-            rs_name = ("sinkhorn_resident_kernel, %d iterations in LDS" if os.environ.get("URF_SINKHORN_REGS", "1") == "0"
+            # (guarded and strict handles run the LDS-resident form, whose workgroups have their CUs to themselves: DESIGN.md 12)
+            rs_name = ("sinkhorn_resident_kernel, %d iterations in LDS, four pairs per launch" if (PREC >= 2 or os.environ.get("URF_SINKHORN_REGS", "1") == "0")
                        else "sinkhorn_regs_kernel, %d iterations in registers")
             per_step["Sinkhorn (" + rs_name % SINK_ITERS + ")"] = (
                 np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 2 / 1e9, 8 * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)

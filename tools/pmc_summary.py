@@ -48,7 +48,8 @@ def family(name):
         return "linear_exact"                    # the exact mode's linear layers (SuperGlue + the two 1x1 heads of SuperPoint)
     for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "sinkhorn_regs_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
-                "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel", "guard_compact_kernel", "nms_tie_kernel"):
+                "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel", "guard_compact_kernel", "nms_tie_kernel",
+                "sg_prep_slots_kernel"):
         if key in name:
             return key
     return None
@@ -74,9 +75,9 @@ def main():
                   "FETCH_SIZE_KiB_per_launch_raw": round(v["fetch_kib"] / n, 1),
                   "WRITE_SIZE_KiB_per_launch": round(v["write_kib"] / n, 1),
                   "bytes_per_launch": int((2 * v["fetch_kib"] + v["write_kib"]) / n * 1024)}
-    # matcher calls: one resident-Sinkhorn launch per fast-mode call (the strict mode's redo engine launches decode_kernel too,
-    # so that one would over-count there); the exact mode has no resident launch: one decode_kernel launch per call
-    pm_calls = max(fam.get("sinkhorn_regs_kernel", fam.get("decode_kernel", {"launches": 0}))["launches"], 1)
+    # matcher calls: one sg_prep_slots_kernel launch per urf_match_device_async (the redo engine of a strict handle never
+    # launches it; the resident Sinkhorn would: one launch per call in its register form, two in the LDS form of the guarded modes)
+    pm_calls = max(fam.get("sg_prep_slots_kernel", fam.get("decode_kernel", {"launches": 0}))["launches"], 1)
     # one topk_kernel launch per SuperPoint call -- two in the guarded fast mode (the gated redo pass), which also launches
     # one guard_compact_kernel per call
     sp_calls = max(fam.get("guard_compact_kernel", fam.get("topk_kernel", {"launches": 0}))["launches"], 1)
