@@ -96,6 +96,7 @@ def pmc_traffic(kernel_label, resolution, prec):
     fam = ("conv_mfma_kernel<9,pool,fuse1a>" if "conv_mfma_kernel<9" in kernel_label else "linear_exact" if "gemm128" in kernel_label
            else "attn_kernel" if "(attn_kernel)" in kernel_label
            else "h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
+           else "sinkhorn_wide_kernel" if "sinkhorn_wide_kernel" in kernel_label
            else "sinkhorn_regs_kernel" if "sinkhorn_regs_kernel" in kernel_label
            else "sinkhorn_resident_kernel" if "sinkhorn_resident_kernel" in kernel_label
            else "sinkhorn_half_kernel" if "inkhorn" in kernel_label else "h2conv_kernel<pool,fuse1a>")
@@ -430,9 +431,8 @@ def main():
             # chip-resident Sinkhorn (sinkhorn_resident.hip; plan tile in registers, or in LDS with URF_SINKHORN_REGS=0): the
             # couplings are read from HBM/L2 once per (re)absorption (initially and after iterations 1, 2, 4, ... 64: 8
             # times), 2 fma per element and iteration; no roof binds it -- an iteration is one inter-CU exchange (latency)
-            # (guarded and strict handles run the LDS-resident form, whose workgroups have their CUs to themselves: DESIGN.md 12)
-            rs_name = ("sinkhorn_resident_kernel, %d iterations in LDS, four pairs per launch" if (PREC >= 2 or os.environ.get("URF_SINKHORN_REGS", "1") == "0")
-                       else "sinkhorn_regs_kernel, %d iterations in registers")
+            # (the wide register-resident form: 64 rows per workgroup, one launch per batch, CUs to itself -- DESIGN.md 12)
+            rs_name = "sinkhorn_wide_kernel, %d iterations in registers"
             per_step["Sinkhorn (" + rs_name % SINK_ITERS + ")"] = (
                 np.mean(sink_ms), 2 * SINK_ITERS * BATCH * (n_avg + 1) ** 2 * 2 / 1e9, 8 * BATCH * (n_avg + 1) ** 2 * 4 / 1e9)
         else:

@@ -46,7 +46,7 @@ def family(name):
         return "conv_mfma_kernel<9,pool,fuse1a>"  # the same in the exact mode
     if "conv_mfma_kernel<1," in name or "gemm128_kernel" in name:
         return "linear_exact"                    # the exact mode's linear layers (SuperGlue + the two 1x1 heads of SuperPoint)
-    for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_resident_kernel", "sinkhorn_regs_kernel", "conv_mfma_kernel",
+    for key in ("ransac_", "h2gemm", "h2mlp_kernel", "attn_h2_kernel", "h2conv_kernel", "sinkhorn_half_kernel", "sinkhorn_wide_kernel", "sinkhorn_resident_kernel", "sinkhorn_regs_kernel", "conv_mfma_kernel",
                 "gemm128_kernel", "attn_kernel", "score_kernel", "nms_pass_kernel", "topk_kernel", "sample_kernel",
                 "desc_norm_kernel", "softmax_d2s_kernel", "argmax_kernel", "decode_kernel", "split_kernel", "guard_compact_kernel", "nms_tie_kernel",
                 "sg_prep_slots_kernel"):

@@ -33,7 +33,7 @@ int sinkhorn_resident_supported(int device);
 void sinkhorn_resident_set_debug(unsigned long long *p);
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
-                             int exclusive, hipStream_t st);
+                             hipStream_t st);
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
@@ -717,7 +717,7 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   if (fast && h->rs_on && !h->tail_exact) {
     // fast mode: one persistent launch, the plan stays in LDS (sinkhorn_resident.hip)
     if (launch_sinkhorn_resident(h->counts, h->C, h->u, h->v, h->bin_score, h->iters, P, h->rs_xin, h->rs_xbc, h->rs_xin_bytes,
-                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, h->guarded ? 1 : 0, st))
+                                 h->rs_xbc_bytes, &h->rs_salt, h->rs_err, h->device, st))
       return -1;
     URF_HIP(hipMemcpyAsync(h->h_rs_err, h->rs_err, sizeof(int), hipMemcpyDeviceToHost, st));
   } else {

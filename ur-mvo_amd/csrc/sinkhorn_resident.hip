@@ -22,9 +22,11 @@
 // Every spin is bounded (0.25 s of s_memrealtime): a launch that cannot become co-resident gives up,
 // raises *err and the host redoes the batch with the streaming kernels (sg_api.hip) instead of hanging the GPU.
 //
-// Two kernels share the exchange: sinkhorn_resident_kernel keeps the plan tile in LDS (128 KiB, 1024 threads: the CU is
-// its alone), sinkhorn_regs_kernel -- the default -- keeps it in registers (256 threads with 128 VGPRs of plan per thread, or
-// 512 threads with 64; 6 KB of LDS, every pair of a batch in one launch).
+// The product carries ONE kernel, sinkhorn_wide_kernel (round 4): the plan tile in registers, 64 rows per workgroup, sixteen
+// workgroups per pair, every pair of a batch in one launch, each workgroup alone on its CU.  The experiments build also has the
+// forms it superseded: sinkhorn_resident_kernel (plan in LDS, 128 KiB, 1024 threads) and sinkhorn_regs_kernel (plan in registers,
+// 32 rows per workgroup, 256 or 512 threads, sharing the CU with other streams' kernels -- and, beside them, not reproducible run
+// to run: DESIGN.md section 12).  All share the exchange.
 #include "urf_common.h"
 #include "urf_math.h"
 
@@ -187,11 +189,9 @@ __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lane
 #define RS_RMW(a) false
 #endif
 #define RS_STAMP(i) do { if (stamping) a.stamps[(size_t)(k - 1) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-// The LDS-resident form (round 2): 1024 threads and 144 KB of LDS per workgroup, so a CU that hosts one hosts nothing else.  The
-// register-resident kernel below superseded it where sharing the CU pays (the fast mode); the modes that carry a guarantee
-// (guarded and strict) run this one: with other kernels' waves on its CUs the register form is not reproducible run to run
-// ("a fault that only a soak test finds": one pair in 500 beside the exact convolutions, one in 14000
-// beside the fast ones), a workgroup that has its CU to itself is.
+#ifdef URF_EXPERIMENTS
+// The LDS-resident form (round 2; experiments build only): 1024 threads and 144 KB of LDS per workgroup, so a CU that hosts one
+// hosts nothing else; half the chip per launch of four pairs.  Superseded by the register-resident kernels below.
 __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Pt = lds;                      // [32][1024] plan rows of this workgroup
@@ -431,6 +431,7 @@ __global__ void __launch_bounds__(RS_T) sinkhorn_resident_kernel(RsArgs a) {
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Register-resident variant (URF_SINKHORN_REGS=1).  Same recurrence, same exchange, but the plan tile lives in VGPRs:
@@ -519,6 +520,7 @@ __device__ __forceinline__ float rs_rows32_sum(VAL val, int lane) {   // val(r) 
   return v[0] + rs_dpp<0xB1>(v[0]);   // lane ^ 1
 }
 
+#ifdef URF_EXPERIMENTS   // the forms that SHARE their CUs (rounds 2 and 3): not reproducible run to run; experiments build only
 // MINW: waves per SIMD the register budget is cut for (3 -> 168 VGPRs, 4 -> 128, 1 -> no cut).  NC: columns per thread, 1024 / NC
 // threads: NC = 2 is the kernel described above; NC = 4 (URF_SINKHORN_REGS=3) is ONE wave per SIMD with 128 registers of plan,
 // which leaves the SIMD's other half of the register file to a second kernel's waves (an h2gemm workgroup needs 2 x 104).
@@ -806,6 +808,258 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
   }
 }
 
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Wide register-resident form (round 4): 512 threads, thread t owns columns t and t + 512 of the workgroup's SIXTY-FOUR rows (128
+// VGPRs of plan; two waves per SIMD, so 256 registers per thread are there), SIXTEEN workgroups per pair -- every pair of a batch
+// of eight in ONE launch on 128 CUs.  Same recurrence and the same two-hop exchange as above (16 reducers of 64 columns: a
+// reducer's 1024 hop-1 granules are [source][column], so lane l of the sweeping wave sums column l over the sources in order, no
+// cross-lane step).  The launch asks for dynamic LDS it never touches so that nothing with a tile in LDS fits beside a workgroup:
+// the CU is the workgroup's alone, which is what makes the resident Sinkhorn reproducible run to run -- at
+// half the CU-time of the LDS-resident form's two half-chip launches.
+constexpr int RW_ROWS = 64, RW_WG = 16, RW_T = 512, RW_NWV = 8, RW_NC = 2;
+constexpr size_t kWidePadBytes = 110 * 1024;   // untouched dynamic LDS: with the 8 KB the kernel uses, 42 KB are left on the CU -- less than any tile
+__global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
+  constexpr int NC = RW_NC, T = RW_T;
+  __shared__ __attribute__((aligned(16))) float avec[RW_ROWS];
+  __shared__ __attribute__((aligned(16))) float pcvec[RW_ROWS];
+  __shared__ float rowpart[RW_NWV][RW_ROWS];
+  __shared__ float wsum[RW_NWV];
+  __shared__ float misc[4];
+  __shared__ float csumv[1028];
+  __shared__ double u0vec[RW_ROWS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pl = (int)blockIdx.x % a.npairs, w = (int)blockIdx.x / a.npairs;
+  const int p = a.pair0 + pl;
+  const int n0 = a.counts[2 * p], n1 = a.counts[2 * p + 1];
+  const float *Cp = a.C + (size_t)p * (RS_NP + 1) * RS_LDC;
+  const __amdgpu_buffer_rsrc_t Crs = __builtin_amdgcn_make_buffer_rsrc((void *)Cp, 0, (RS_NP + 1) * RS_LDC * 4, 0x00020000);
+  auto Cload = [&](int row, int c) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Crs, 4 * (int)threadIdx.x + 4 * T * c, row * (RS_LDC * 4), 0));
+  };
+  u64 *xin = a.xin + (size_t)p * RS_XIN, *xbc = a.xbc + (size_t)p * RS_XBC;
+  const float tot = (float)(n0 + n1);
+  const float mu = 1.0f / tot, mu_d = (float)n1 / tot, nu = 1.0f / tot, nu_d = (float)n0 / tot;
+  const float alpha = a.alpha;
+  const int i0 = w * RW_ROWS;
+  int col[NC];
+  bool ok[NC], dust[NC];
+  bool own_dust = (n1 < RS_NP) ? false : (tid == 0);          // the dustbin column's sum travels in the slot of column n1, or (n1 == 1024) in thread 0's extra slot
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    col[c] = tid + T * c;
+    ok[c] = col[c] < n1;
+    dust[c] = n1 < RS_NP && col[c] == n1;
+    own_dust = own_dust || dust[c];
+  }
+  const int dust_wave = (n1 & (T - 1)) >> 6;
+
+  float P[NC][RW_ROWS];
+  float bc[NC], pd[NC];
+  double v0c[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { bc[c] = ok[c] ? 1.0f : 0.0f; pd[c] = 0.0f; v0c[c] = 0.0; }
+  double u0d = -(double)alpha, v0d = 0.0;
+  float Pdd = 1.0f, bdust = 1.0f, ad = 0.0f;
+
+  // ---- u0_i = -max_j C_ij over the valid columns and the dustbin entry alpha (sixteen rows at a time)
+#pragma unroll
+  for (int ib = 0; ib < RW_ROWS; ib += 16) {
+    float mv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float m = alpha;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { const float x = Cload(i0 + ib + i, c); m = ok[c] ? fmaxf(m, x) : m; }
+      mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float m = bfly64_max(mv[i]);
+      if (lane == 0) rowpart[wv][ib + i] = m;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  if (tid < RW_ROWS) {
+    float m = rowpart[0][tid];
+#pragma unroll
+    for (int q = 1; q < RW_NWV; ++q) m = fmaxf(m, rowpart[q][tid]);
+    u0vec[tid] = (i0 + tid < n0) ? -(double)m : -1.0e300;
+  }
+
+  auto absorb = [&]() {
+    __syncthreads();                      // u0vec written, nobody still reads avec / pcvec
+#pragma unroll
+    for (int ib = 0; ib < RW_ROWS; ib += 16) {   // sixteen rows of couplings in flight at a time
+      float xs[16][NC];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xs[i][c] = Cload(i0 + ib + i, c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double u0i = u0vec[ib + i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float q = __expf((float)(((double)xs[i][c] + u0i) + v0c[c]));
+          P[c][ib + i] = ok[c] ? q : 0.0f;   // rows >= n0: u0 = -1e300, the exponential is 0
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid < RW_ROWS) pcvec[tid] = (i0 + tid < n0) ? __expf((float)(((double)alpha + u0vec[tid]) + v0d)) : 0.0f;
+    if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      pd[c] = ok[c] ? __expf((float)(((double)alpha + u0d) + v0c[c])) : 0.0f;
+      bc[c] = ok[c] ? 1.0f : 0.0f;
+    }
+    Pdd = __expf((float)(((double)alpha + u0d) + v0d));
+    bdust = 1.0f;
+    __syncthreads();
+  };
+  absorb();
+
+  // ---- the launch's workgroups check in (a launch that cannot become co-resident gives up here, like in the loop)
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned tag0 = (a.salt << 12) | 0xFFFu;
+    if (tid == 0) rs_store(xbc + 1056 + w, tag0, (float)(xcc & 15u), false);
+    if (wv == 0) {
+      float ids = 0.0f;
+      const bool alive = rs_sweep<1, true>(xbc + 1056, RW_WG, tag0, ids, nullptr, lane, a.err);
+      if (lane == 0 && !alive) misc[1] = 1.0f;
+    }
+    __syncthreads();
+    if (misc[1] != 0.0f) return;
+  }
+
+  int next_absorb = 1;
+  for (int k = 1; k <= a.iters; ++k) {
+    const unsigned tag = (a.salt << 12) | (unsigned)k;
+    // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust); 2 x 32 wave sums, 8 partials per row through LDS
+    __syncthreads();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
+    bdust = misc[0];
+    {
+      const float s0 = rs_rows32_sum([&](int r) { return fma_rn(P[0][r], bc[0], P[1][r] * bc[1]); }, lane);
+      if ((lane & 1) == 0) rowpart[wv][rs_row_of_lane(lane)] = s0;
+      const float s1 = rs_rows32_sum([&](int r) { return fma_rn(P[0][32 + r], bc[0], P[1][32 + r] * bc[1]); }, lane);
+      if ((lane & 1) == 0) rowpart[wv][32 + rs_row_of_lane(lane)] = s1;
+    }
+    {
+      const float part = wave_sum_dpp_l63(fma_rn(pd[0], bc[0], pd[1] * bc[1]));   // dustbin row: sum_j pd_j b_j
+      if (lane == 63) wsum[wv] = part;
+    }
+    __syncthreads();
+    if (tid < RW_ROWS) {
+      float r = rowpart[0][tid];
+#pragma unroll
+      for (int q = 1; q < RW_NWV; ++q) r = r + rowpart[q][tid];
+      r = fma_rn(pcvec[tid], bdust, r);
+      avec[tid] = (i0 + tid < n0) ? mu / r : 0.0f;
+    }
+    {
+      float rd = wsum[0];
+#pragma unroll
+      for (int q = 1; q < RW_NWV; ++q) rd = rd + wsum[q];
+      rd = fma_rn(Pdd, bdust, rd);
+      ad = mu_d / rd;
+    }
+    __syncthreads();                      // avec written
+    // ---------------- column pass: partial sums over the own 64 rows, all in registers
+    float creg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) creg[c] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < RW_ROWS / 4; ++q) {
+      const f32x4 x = *(const f32x4 *)(avec + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) creg[c] = fma_rn(x[e], P[c][4 * q + e], creg[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (!ok[c]) creg[c] = 0.0f;
+    float cdust = 0.0f;
+    if (wv == dust_wave) {                // the wave of the dustbin slot's owner (uniform branch)
+#pragma unroll
+      for (int q = 0; q < RW_ROWS / 4; ++q) {
+        const f32x4 x = *(const f32x4 *)(avec + 4 * q), y = *(const f32x4 *)(pcvec + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cdust = fma_rn(x[e], y[e], cdust);
+      }
+    }
+    // ---------------- all-reduce of the 1025 column sums over the 16 workgroups of the pair: reducer = column / 64,
+    // hop-1 granule [reducer][source][column % 64]; the dustbin column's sums at the end of the region, reduced by workgroup 15
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      rs_store(xin + ((size_t)((col[c] >> 6) * RW_WG + w) * 64 + (col[c] & 63)), tag, dust[c] ? cdust : creg[c], false);
+    if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, false);
+    if (wv == 0) {
+      bool alive = true;
+      {
+        float x = 0.0f;
+        alive = rs_sweep<16, true>(xin + (size_t)w * RW_WG * 64, RW_WG * 64, tag, x, nullptr, lane, a.err);   // x = sum over the sources, in order
+        if (alive) rs_store(xbc + 64 * w + lane, tag, x, false);
+        if (alive && w == RW_WG - 1) {
+          float y = 0.0f;
+          alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RW_WG, tag, y, nullptr, lane, a.err);
+          const float ys = half_sum32(lane < RW_WG ? y : 0.0f);
+          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, false);
+        }
+      }
+      if (alive) {
+        float unused = 0.0f;
+        alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err);
+      }
+      if (!alive && lane == 0) misc[1] = 1.0f;
+    }
+    __syncthreads();
+    if (misc[1] != 0.0f) return;
+    float csum_dust = csumv[1024];
+    // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float cs = csumv[col[c]];
+      bc[c] = ok[c] ? nu / fma_rn(ad, pd[c], cs) : 0.0f;
+      if (dust[c]) csum_dust = cs;
+    }
+    if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, csum_dust);
+    // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
+    if (k == next_absorb && k < a.iters) {
+      next_absorb *= 2;
+      __syncthreads();                    // misc[0] written
+      bdust = misc[0];
+      if (tid < RW_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
+      u0d = u0d + (double)__logf(ad);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (ok[c]) v0c[c] = v0c[c] + (double)__logf(bc[c]);
+      v0d = v0d + (double)__logf(bdust);
+      absorb();
+    }
+  }
+  // ---------------- u = u0 + log a, v = v0 + log b
+  __syncthreads();
+  bdust = misc[0];
+  if (tid < RW_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
+  if (w == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (ok[c]) a.v[(size_t)p * RS_LDC + col[c]] = (float)(v0c[c] + (double)__logf(bc[c]));
+    if (tid == 0) {
+      a.u[(size_t)p * RS_LDC + n0] = (float)(u0d + (double)__logf(ad));
+      a.v[(size_t)p * RS_LDC + n1] = (float)(v0d + (double)__logf(bdust));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host side.  Two resident launches must never be in flight together (each needs every workgroup of
 // its grid on a CU of its own before any of them can finish): launches of one process are chained on a
@@ -847,7 +1101,7 @@ void sinkhorn_resident_set_debug(unsigned long long *p) { g_rs_dbg = p; }
 
 int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float *v, float alpha, int iters, int P,
                              void *xin, void *xbc, size_t xin_bytes, size_t xbc_bytes, unsigned *salt, int *err, int device,
-                             int exclusive, hipStream_t st) {
+                             hipStream_t st) {
   URF_CHECK(device >= 0 && device < 16, "sinkhorn_resident: device %d out of range", device);
   URF_CHECK(iters >= 1 && iters < 4096, "sinkhorn_resident: iterations %d outside [1, 4095]", iters);
   RsDevice &d = g_rs_dev[device];
@@ -857,7 +1111,10 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     hipDeviceProp_t prop;
     URF_HIP(hipGetDeviceProperties(&prop, device));
     d.cus = prop.multiProcessorCount;
+#ifdef URF_EXPERIMENTS
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+    URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePadBytes));
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }
@@ -872,11 +1129,15 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
   // 3 (default since round 3) = the register-resident kernel with FOUR columns per thread: 256 threads, one wave per SIMD at 270
   // VGPRs without a spill, which leaves 240 registers of every SIMD lane to another stream's waves (measured against 1: 0.61 ->
   // 0.53 ms serialised, +1 % in the pipeline at 640x480, even at 1241x376)
-  // `exclusive` (guarded and strict-parity handles): the LDS-resident kernel, whose workgroups have their CUs to themselves
+  // 4 (default since the soak of round 4, every mode; the only form of the product build) = the WIDE register-resident kernel: 64 rows
+  // per workgroup, sixteen workgroups per pair, every pair of a batch of eight in one launch on 128 CUs that the workgroups have
+  // to themselves.  The forms 1 - 3 share their CUs with other streams' kernels and are not reproducible run to run beside them
+  // (DESIGN.md section 12); strict mode, 640x480: 1056 frames/s against 1043 (form 3, shared) and 1025 (form 0, LDS-resident)
   static int regs_env = -2;
-  if (regs_env == -2) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs_env = e ? atoi(e) : -1; if (regs_env < -1 || regs_env > 3) regs_env = -1; }
-  const int regs = regs_env >= 0 ? regs_env : (exclusive ? 0 : 3);
+  if (regs_env == -2) { const char *e = urf::exp_env("URF_SINKHORN_REGS"); regs_env = e ? atoi(e) : -1; if (regs_env < -1 || regs_env > 4) regs_env = -1; }
+  const int regs = regs_env >= 0 ? regs_env : 4;
   int group = d.cus / RS_WG;
+  if (regs == 4) group = d.cus / RW_WG >= 8 ? 8 : d.cus / RW_WG;        // (sixteen workgroups per pair: a batch of eight in one launch)
   if (regs) {
     const char *e = urf::exp_env("URF_SINKHORN_GROUP");
     const int want = e ? atoi(e) : 0;
@@ -921,13 +1182,14 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
       const char *e = urf::exp_env("URF_SINKHORN_LDS_PAD"); lpad = e ? atol(e) : 0;
       if (lpad > 0) URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_regs_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
-    if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), (size_t)lpad, st, a);
+    if (regs == 4) hipLaunchKernelGGL(sinkhorn_wide_kernel, dim3(RW_WG * a.npairs), dim3(RW_T), kWidePadBytes, st, a);
+    else if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), (size_t)lpad, st, a);
     else if (regs == 2) hipLaunchKernelGGL((sinkhorn_regs_kernel<4, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else if (regs) hipLaunchKernelGGL((sinkhorn_regs_kernel<3, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
 #else
-    if (regs == 0) hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(RS_WG * a.npairs), dim3(RS_T), lds, st, a);
-    else hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), 0, st, a);   // the product carries these two forms
+    (void)lds;
+    hipLaunchKernelGGL(sinkhorn_wide_kernel, dim3(RW_WG * a.npairs), dim3(RW_T), kWidePadBytes, st, a);   // the product carries this form only
 #endif
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
