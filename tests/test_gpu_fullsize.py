@@ -310,8 +310,8 @@ def test_the_pipeline_is_reproducible_run_to_run_soak(U, F, sp_blob, sg_blob, pr
     """Oracle-free soak of the benched loop on the 1241x376 stream (period 5 batches): batch b and batch b + 5 must give the SAME
     lists, distances included, for 1500 steps.  Round 4 found the register-resident Sinkhorn NOT reproducible in the strict mode
     (about one pair in 500 with distances off by 1e-5 ... 3e-2, index lists intact: a transient fault inside the 100 iterations,
-    only beside the exact convolutions and only when its workgroups share their CUs) -- strict handles
-    therefore run the Sinkhorn form that keeps its CUs to itself.  tools/gpu_determinism.py is the long form of this test."""
+    only when its workgroups share their CUs with other streams' kernels) -- the product's resident Sinkhorn
+    (sinkhorn_wide_kernel) therefore keeps its CUs to itself, in every mode.  tools/gpu_determinism.py is the long form of this test."""
     import torch
     H, W, B = 376, 1241, 8
     steps = 1500
