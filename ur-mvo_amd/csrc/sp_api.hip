@@ -362,6 +362,23 @@ extern "C" int urf_sp_build(urf_sp *h, const float *blob, size_t n_floats) {
     h->g_delta = h->cfg.guard_delta > 0.0f ? h->cfg.guard_delta : kGuardSpDelta;
     h->g_ulps = h->cfg.guard_ulps > 0.0f ? h->cfg.guard_ulps : kGuardSpUlps;
   }
+  if (h->precision == 0) {
+    // The SuperPoint of a strict-parity pipeline (precision 3 in the configuration): the tail of a call (NMS, selection, descriptor
+    // normalisation and sampling: seven launches of a few workgroups, 0.16 ms of latency for next to no chip time) runs on a second
+    // stream, beside the NEXT call's convolutions -- which therefore work in a second arena (A, A2 alternate).  The convolutions'
+    // stream is the busiest of that pipeline: 1114 against 1072 frames/s at 640x480, 961 against 944 at 1241x376.  NOT in the
+    // exact mode proper (precision 0), whose exact matcher streams lose more to the extra concurrency than SuperPoint gains
+    // (594 against 653).  URF_SP_TAIL_STREAM = 0 / 1 overrides in the experiments build.
+    static const int tail_env = [] { const char *e = urf::exp_env("URF_SP_TAIL_STREAM"); return e ? (atoi(e) != 0) : -1; }();
+    const bool tail_stream = tail_env >= 0 ? tail_env != 0 : h->cfg.precision == 3;
+    if (tail_stream) {
+      if (arena(h->A2, false)) return -1;
+      URF_HIP(hipStreamCreateWithFlags(&h->stx, hipStreamNonBlocking));
+      URF_HIP(hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming));
+      URF_HIP(hipEventCreateWithFlags(&h->ev_tail[0], hipEventDisableTiming));
+      URF_HIP(hipEventCreateWithFlags(&h->ev_tail[1], hipEventDisableTiming));
+    }
+  }
   if (dalloc(&h->d_feat, B * (size_t)kCap * 259)) return -1;
   if (dalloc(&h->d_slots, B * kSlotFloats)) return -1;
   URF_HIP(hipHostMalloc((void **)&h->h_img, B * H * W, hipHostMallocDefault));
@@ -627,8 +644,20 @@ static int sp_pipeline(urf_sp *h, int B, const uint8_t *d_imgs, int H, int W, co
                        float *d_slots) {
   SpGuard g = {};
   h->lastH = H; h->lastW = W; h->lastB = B;
-  if (h->precision != 2)
-    return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 7, h->st);
+  if (h->precision != 2) {
+    if (h->stx == h->st)
+      return sp_pipeline_on(h, h->A, h->precision == 1, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 7, h->st);
+    // exact mode with the tail on its own stream: this call's arena is the one the call before last used
+    std::swap(h->A, h->A2);
+    h->parity ^= 1;
+    URF_HIP(hipStreamWaitEvent(h->st, h->ev_tail[h->parity], 0));     // (never recorded: no wait)
+    if (sp_pipeline_on(h, h->A, false, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 1, h->st)) return -1;
+    URF_HIP(hipEventRecord(h->ev_fast, h->st));
+    URF_HIP(hipStreamWaitEvent(h->stx, h->ev_fast, 0));
+    if (sp_pipeline_on(h, h->A, false, B, d_imgs, H, W, d_mask, d_feat, d_slots, nullptr, g, nullptr, true, 6, h->stx)) return -1;
+    URF_HIP(hipEventRecord(h->ev_tail[h->parity], h->stx));
+    return 0;
+  }
   hipStream_t st = h->st, sx = h->stx;
   const bool two = sx != st;
   if (two) {
