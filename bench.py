@@ -490,6 +490,13 @@ def main():
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
         exact = None
         secondary = None
+        if world == 1:
+            # the headline's handles go NOW (explicitly: closures above still reference them, `del` alone would not destroy them):
+            # their idle streams -- six in the strict mode -- otherwise share the runtime's four hardware queues with the
+            # configurations measured next and slow those down by 10 - 20 %
+            for m_ in pms:
+                m_.__del__()
+            sp.__del__()
         if world == 1 and not args.no_exact_check and NB == 5:
             # The exact fp32 mode (every tensor bit-identical to the oracle) through the same loop on the same stream, >= 20 steps
             # x 3 regions, and the headline's lists against its lists: in the strict-parity mode every pair's INDEX LIST must be
