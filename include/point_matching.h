@@ -17,6 +17,11 @@ class PointMatching {
       std::cout << "Erron in superglue building" << std::endl;
   }
   bool build(const float *blob, size_t n_floats) { return superglue.build(blob, n_floats); }
+  // Not in the reference (before build(blob, n); a configuration that names its files says it with "#outlier=opencv42" behind
+  // engine_file, include/urf_shim.h): which outlier stage MatchingPoints(..., true) runs -- 0 = the in-tree 8-point search with
+  // the reference call's 3 px / 0.99 (default), 1 = cv::findFundamentalMat(FM_RANSAC, 3, 0.99) of OpenCV 4.2 restated
+  void set_outlier_stage(int stage) { superglue.set_outlier_stage(stage); }
+  int outlier_stage() const { return superglue.outlier_stage(); }
   // Not in the reference: the guard word of the pair the last MatchingPoints call handled (urf_pm_near_tie_flags): 0 = its
   // match list is the exact pipeline's; non-zero in the guarded fast mode (precision 2) = a decisive entry sat within the
   // fast pipeline's error of its alternative and the list may differ there (in the strict mode, the default, such a pair

@@ -22,11 +22,21 @@
 class SuperGlue {
  public:
   explicit SuperGlue(const SuperGlueConfig &superglue_config) : superglue_config_(superglue_config) {
-    precision_ = urf_shim::split_engine_file(superglue_config.engine_file, &engine_path_);
+    const urf_shim::engine_options o = urf_shim::parse_engine_file(superglue_config.engine_file, &engine_path_);
+    precision_ = o.precision;
+    outlier_stage_ = o.outlier_stage;
+    calibrate_pairs_ = o.calibrate_pairs;
   }
   // Not in the reference: the precision mode of the handle build() creates (urf_shim.h; default = strict parity)
   void set_precision(int precision) { precision_ = precision; }
   int precision() const { return precision_; }
+  // Not in the reference: the outlier stage of PointMatching::MatchingPoints (before build(); or "#outlier=opencv42" behind
+  // engine_file): 0 = the in-tree 8-point search with the reference call's 3 px / 0.99 (default), 1 = that call itself,
+  // cv::findFundamentalMat(FM_RANSAC) of OpenCV 4.2 restated (urf_sg_config.outlier_stage)
+  void set_outlier_stage(int stage) { outlier_stage_ = stage; }
+  int outlier_stage() const { return outlier_stage_; }
+  // Not in the reference: pairs the handle measures its own error on after build() (urf_sg_config.calibrate_pairs; 0 = never)
+  void set_calibrate_pairs(int n) { calibrate_pairs_ = n; }
   ~SuperGlue() { urf_pm_destroy(h_); }
   SuperGlue(const SuperGlue &) = delete;
   SuperGlue &operator=(const SuperGlue &) = delete;
@@ -81,6 +91,8 @@ class SuperGlue {
     c.image_height = superglue_config_.image_height;
     c.matching_threshold = superglue_config_.matching_threshold;
     c.precision = precision_;
+    c.outlier_stage = outlier_stage_;
+    c.calibrate_pairs = calibrate_pairs_ > 0 ? calibrate_pairs_ : -1;
     if (urf_pm_create(&c, &h_) != 0) { report("create"); return false; }
     return true;
   }
@@ -88,6 +100,8 @@ class SuperGlue {
   SuperGlueConfig superglue_config_;
   std::string engine_path_;      // engine_file without the "#precision=N" suffix
   int precision_ = URF_SHIM_PRECISION;
+  int outlier_stage_ = 0;
+  int calibrate_pairs_ = 8;
   urf_pm *h_ = nullptr;
 };
 

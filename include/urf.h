@@ -181,6 +181,21 @@ typedef struct {
    * ransac_iterations / ransac_sigma / ransac_seed are unused.  The matches are walked in list order, as the reference's
    * points0 / points1 are. */
   int outlier_stage;
+  /* integrity bound of the fast Sinkhorn (precision 1, 2, 3; appended, 0 = default 1e-4, < 0 = off): the decode sums every
+   * column of the plan it reads.  An iteration ends with the column update, so the column marginals are 1 to rounding in every
+   * correct result, converged or not; a pair whose columns miss by more than this (or hold a NaN) has its batch's tail redone with
+   * the streaming kernels before the lists are handed out.  It catches a damaged last iteration / final potentials / couplings,
+   * not an earlier transient the later iterations absorbed.  urf_pm_sinkhorn_integrity() counts,
+   * urf_pm_sinkhorn_residuals() reports the measured values. */
+  float sinkhorn_residual_bound;
+  /* automatic calibration of the matcher's guard (precision 2, 3; appended): the first calibrate_pairs pairs the handle is given
+   * (by any entry: urf_match, urf_sg_infer, urf_match_device_async) are measured BEFORE they are matched -- the fast against the
+   * exact matcher, as urf_pm_calibrate_guard does -- and the margin becomes at least 1.6 x the largest difference seen (the
+   * maximum over a few pairs underestimates a stream's), so that the strict guarantee follows the deployment's own weights
+   * instead of the synthetic ones the built-in 2.2e-4 was measured on.  0 = the mode's default (3: 8 pairs; 2: none), < 0 =
+   * never.  Costs one exact pass per measured batch, once; reported on stderr.  Above 2.5e-3 a strict handle redoes EVERY pair
+   * in the exact mode (still the oracle's lists, at the exact mode's speed) and says so. */
+  int calibrate_pairs;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -223,7 +238,7 @@ int urf_match_device(urf_pm *h, int P, const void *const *d_slots0, const void *
 /* same, asynchronous: results stay in the handle until urf_pm_fetch(h, P, ...) with the same P; a fetch without a
  * batch in flight, or for another pair count, is an error. */
 int urf_match_device_async(urf_pm *h, int P, const void *const *d_slots0,
-                           const void *const *d_slots1, int outlier_rejection);
+                           const void *const *d_slots1, int outlier_rejection);   /* error while the batch enqueued last is unfetched */
 int urf_pm_fetch(urf_pm *h, int P, urf_dmatch *out, int cap, int *nout);
 /* urf_pm_fetch in two halves, for callers that keep the GPU busy across a redo (strict parity, precision 3; in the other
  * modes begin never returns 1).  begin: waits for the batch's fast pass, reads the guard words and STARTS the exact redo of
@@ -345,6 +360,11 @@ int urf_pm_device_results(urf_pm *h, const urf_dmatch **d_matches, const int **d
  * results were handed out (the handle then stays on the streaming kernels).  Normally 0.  Results are the same either way;
  * a caller that shipped the device lists elsewhere before fetching (the gather above) ships them again when this number moved. */
 int urf_pm_sinkhorn_fallbacks(const urf_pm *h);
+/* integrity check of the fast Sinkhorn (urf_sg_config.sinkhorn_residual_bound): out[0] = pairs whose result failed the bound and
+ * was redone, out[1] = batches in which that happened, out[2] = the bound in use, out[3] = pairs processed (n <= 4 values). */
+int urf_pm_sinkhorn_integrity(urf_pm *h, double *out, int n);
+/* the largest |column marginal - 1| of the plan the decode read, for the P pairs of the batch handed out last (zeros in the exact mode) */
+int urf_pm_sinkhorn_residuals(urf_pm *h, float *out, int P);
 /* guarded fast mode (precision 2), counters since build(): out[0] = pairs redone in the exact mode, out[1] = pairs
  * processed, out[2] / out[3] = redone pairs by cause (threshold margin / runner-up margin), out[4] = pairs flagged
  * (n <= 8 values written) */
@@ -428,8 +448,12 @@ int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols);
  * ref: NULL or n global frame indices (counted from the first submitted frame): frame j is matched
  * against frame ref[j] (-1 = its predecessor) -- the reference matches against the last keyframe
  * (src/tracking.cc:196-203).  A referenced frame must be in this batch or in one of the
- * 2 + history_batches batches before it.  At most `matchers` + 1 batches may be in flight (the
- * newest one's SuperPoint runs while the older ones are matched). */
+ * 2 + history_batches batches before it.  At most `matchers` + 3 batches may be in flight: a submit enqueues its
+ * own SuperPoint, the match call of the batch two submits back and begins the fetch of the batch `matchers` + 1 submits
+ * back (the only wait, for that batch's fast pass; a strict handle's exact redo of flagged pairs then runs beside the
+ * next batches) -- the loop bench.py times, driven by the caller:
+ *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 2 || urf_fe_ready() == 1) urf_fe_collect(...);
+ * A caller that collects right after every submit gets the synchronous behaviour (collect enqueues what is missing). */
 int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step, size_t frame_stride,
                   const long *ref);
 /* Oldest batch in flight: K[j] keypoints, nmatch[j] matches at matches[j*cap ...] (queryIdx -> the
@@ -437,6 +461,8 @@ int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, s
  * feat: NULL or nframes matrices of 259 x URF_MAX_KEYPOINTS f64 (column-major). */
 int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat);
 int urf_fe_in_flight(urf_fe *h);
+/* 1 when urf_fe_collect would hand out the oldest batch without waiting for the GPU, 0 when it would wait, <0 on error */
+int urf_fe_ready(urf_fe *h);
 /* 1 if the NEXT urf_fe_submit may name global frame `frame` in `ref` (its slot is still in the ring: one of the last
  * 2 + history_batches SUBMITS, whatever their sizes), 0 if not, <0 on error.  A caller that tracks keyframes asks here
  * instead of counting frames (batches are ragged), and matches the host features of a frame that has left the ring. */
@@ -512,22 +538,31 @@ int urf_search_by_projection_slot(const urf_sbp_config *cfg, const void *d_slot,
                                   const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M,
                                   int *best_idx);
 
-/* micro-probes used by the GPU parity tests (MFMA fma-chain, canonical math) */
+/* arithmetic taps of the GPU parity tests: pure functions of their arguments (the fp32 matrix core as an ordered fma chain, the
+ * canonical exp / log, IEEE division and square root, the split-f16 GEMM, one f16 matrix-core instruction).  They touch no handle. */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);
 int urf_probe_math(const float *x, int n, float *exp_out, float *log_out, int device);
-/* split-f16 GEMM probe (fast precision mode): Y = X W + bias, avg ms over reps */
-/* probe only: force the split-f16 GEMM kernel (0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 = default) */
-int urf_probe_h2gemm_variant(int v);
+int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
+/* split-f16 GEMM (fast precision mode): Y = X W + bias, avg ms over reps */
 int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                      int reps, float *ms_out, int device);
-/* research probe: ncases independent v_mfma_f32_16x16x32_f16 (A 16x32 f16, B 32x16 f16, C/D 16x16 f32, row-major) */
+/* ncases independent v_mfma_f32_16x16x32_f16 (A 16x32 f16, B 32x16 f16, C/D 16x16 f32, row-major) */
 int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const float *C, float *D, int ncases, int device);
-/* diagnostic: s_memtime stamps of the LDS-resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
+
+#ifdef URF_EXPERIMENTS
+/* Test hooks and diagnostics: exported ONLY by the experiments build (`make -C ur-mvo_amd/csrc experiments`,
+ * liburf_front_exp.so) -- fault injection and kernel A/B switches have no place in the product library. */
+/* force the split-f16 GEMM kernel (0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 = default) */
+int urf_probe_h2gemm_variant(int v);
+/* s_memtime stamps of the resident Sinkhorn (8 per iteration, workgroup 0); tools/gpu_sinkhorn_stamps.py */
 int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out);
-/* test hook: the next `launches` resident Sinkhorn launches of this process report a give-up (exercises the recovery above) */
+/* the next `launches` resident Sinkhorn launches of this process report a give-up (exercises the recovery of sg_api.hip) */
 int urf_probe_sinkhorn_fault(int launches);
-/* test hook: matcher handles built after this call stay on the streaming Sinkhorn for `batches` batches after a give-up (0 = the default, 64) */
+/* matcher handles built after this call stay on the streaming Sinkhorn for `batches` batches after a give-up (0 = the default, 64) */
 int urf_probe_sinkhorn_backoff(int batches);
+/* the next `launches` resident Sinkhorn launches get `delta` added to one column potential of their first pair AFTER the
+ * iterations (a damaged last iteration); exercises the integrity check */
+int urf_probe_sinkhorn_corrupt(int launches, float delta);
 /* roof probe: the split-f16 MFMA inner loop, `waves_per_cu` in {4, 8, 16}: PFLOP/s of MFMA issue and the in-kernel clock the
  * chip holds under that load.  mode 0 = register-resident operands, no memory; 1 = plus the linear-layer kernel's fragment reads
  * from LDS; 2 = plus its barrier per step; 3 = plus its LDS-DMA from L2-resident sources; 4 = activations streamed from HBM;
@@ -536,7 +571,7 @@ int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float
 /* diagnostics of the linear-layer kernel for tools/gpu_h2fixed.py: 1 = non-temporal stores, 2 = no stores, 4 = one K chunk only
  * (2 and 4 give wrong results: timing only); 0 restores the product behaviour */
 int urf_probe_h2gemm_xflags(int flags);
-int urf_probe_divsqrt(const float *a, const float *b, int n, float *q, float *s, double *qd, double *sd, int device);
+#endif
 
 #ifdef __cplusplus
 }

@@ -28,15 +28,43 @@
 #endif
 
 namespace urf_shim {
+// What a deployment can say in `engine_file` behind the file name, any number of "#key=value" suffixes in any order:
+//   #precision=N        N in 0..3 (above)
+//   #outlier=opencv42   PointMatching / SuperGlue only: the outlier stage of MatchingPoints is the reference's own call,
+//                       cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask) as OpenCV 4.2 publishes it
+//                       (urf_sg_config.outlier_stage = 1; a restatement that no OpenCV binary has checked);
+//                       #outlier=8point (the default): the in-tree 8-point search with the same 3 px / 0.99
+//   #calibrate=N        PointMatching / SuperGlue only, strict or guarded mode: measure the matcher's own error on the first N
+//                       pairs the handle sees (0 = never; default 8) and widen the guard's margin where these weights need it
+// A suffix that is not understood is left in the path (the open then fails loudly with the whole string in the message).
+struct engine_options {
+  int precision = URF_SHIM_PRECISION;
+  int outlier_stage = 0;
+  int calibrate_pairs = 8;
+};
+inline engine_options parse_engine_file(const std::string &engine_file, std::string *path) {
+  engine_options o;
+  std::string rest = engine_file;
+  for (;;) {
+    const size_t at = rest.rfind('#');
+    if (at == std::string::npos) break;
+    const std::string kv = rest.substr(at + 1);
+    bool ok = true;
+    if (kv.size() == 11 && kv.compare(0, 10, "precision=") == 0 && kv[10] >= '0' && kv[10] <= '3') o.precision = kv[10] - '0';
+    else if (kv == "outlier=opencv42") o.outlier_stage = 1;
+    else if (kv == "outlier=8point") o.outlier_stage = 0;
+    else if (kv.compare(0, 10, "calibrate=") == 0 && kv.size() > 10 && kv.size() <= 13 &&
+             kv.find_first_not_of("0123456789", 10) == std::string::npos) o.calibrate_pairs = std::atoi(kv.c_str() + 10);
+    else ok = false;
+    if (!ok) break;
+    rest.erase(at);
+  }
+  *path = rest;
+  return o;
+}
 // "weights.urfw#precision=2" -> path "weights.urfw", returns 2; no (or a malformed) suffix -> the whole string, URF_SHIM_PRECISION
 inline int split_engine_file(const std::string &engine_file, std::string *path) {
-  static const char key[] = "#precision=";
-  const size_t at = engine_file.rfind(key);
-  if (at == std::string::npos) { *path = engine_file; return URF_SHIM_PRECISION; }
-  const std::string v = engine_file.substr(at + sizeof(key) - 1);
-  if (v.size() != 1 || v[0] < '0' || v[0] > '3') { *path = engine_file; return URF_SHIM_PRECISION; }
-  *path = engine_file.substr(0, at);
-  return v[0] - '0';
+  return parse_engine_file(engine_file, path).precision;
 }
 }  // namespace urf_shim
 

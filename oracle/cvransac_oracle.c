@@ -46,18 +46,20 @@ static int rng_uniform(cv_rng *r, int a, int b) { return a == b ? a : (int)(rng_
 static int collinear_last(const float *p, const int *idx, int count) {
   const int i = count - 1;
   for (int j = 0; j < i; ++j) {
-    const double dx1 = (double)p[2 * idx[j]] - (double)p[2 * idx[i]], dy1 = (double)p[2 * idx[j] + 1] - (double)p[2 * idx[i] + 1];
+    /* Point2f differences: float arithmetic, widened afterwards */
+    const double dx1 = (double)(float)(p[2 * idx[j]] - p[2 * idx[i]]), dy1 = (double)(float)(p[2 * idx[j] + 1] - p[2 * idx[i] + 1]);
     for (int k = 0; k < j; ++k) {
-      const double dx2 = (double)p[2 * idx[k]] - (double)p[2 * idx[i]], dy2 = (double)p[2 * idx[k] + 1] - (double)p[2 * idx[i] + 1];
+      const double dx2 = (double)(float)(p[2 * idx[k]] - p[2 * idx[i]]), dy2 = (double)(float)(p[2 * idx[k] + 1] - p[2 * idx[i] + 1]);
       if (fabs(dx2 * dy1 - dy2 * dx1) <= (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 1;
     }
   }
   return 0;
 }
 
-/* getSubset: 7 distinct indices, redrawn as a whole (at most 10000 times) while the subset fails checkSubset */
-static int get_subset(const float *m1, const float *m2, int count, cv_rng *rng, int *idx) {
-  for (int iters = 0; iters < 10000; ++iters) {
+/* getSubset: 7 distinct indices, redrawn as a whole while the subset fails checkSubset -- at most 10000 times from the RANSAC
+ * registrator, getSubset's default 1000 from the LMedS one */
+static int get_subset(const float *m1, const float *m2, int count, cv_rng *rng, int *idx, int max_attempts) {
+  for (int iters = 0; iters < max_attempts; ++iters) {
     for (int i = 0; i < 7; ++i) {
       for (;;) {
         const int c = rng_uniform(rng, 0, count);
@@ -254,7 +256,7 @@ int ocv_find_fundamental_mask(const float *m1, const float *m2, int n, double th
     const float t = (float)(thresh * thresh);
     int niters = 1000, max_good = 0;
     for (int iter = 0; iter < niters; ++iter) {
-      if (!get_subset(m1, m2, n, &rng, idx)) { if (iter == 0) { free(cur); free(err); return n; } break; }
+      if (!get_subset(m1, m2, n, &rng, idx, 10000)) { if (iter == 0) { free(cur); free(err); return n; } break; }
       const int nm = run_7point(m1, m2, idx, F);
       for (int k = 0; k < nm; ++k) {
         int good = 0;
@@ -274,7 +276,7 @@ int ocv_find_fundamental_mask(const float *m1, const float *m2, int n, double th
     if (niters < 3) niters = 3;
     double min_median = DBL_MAX;
     for (int iter = 0; iter < niters; ++iter) {
-      if (!get_subset(m1, m2, n, &rng, idx)) { if (iter == 0) { free(cur); free(err); return n; } break; }
+      if (!get_subset(m1, m2, n, &rng, idx, 1000)) { if (iter == 0) { free(cur); free(err); return n; } break; }
       const int nm = run_7point(m1, m2, idx, F);
       for (int k = 0; k < nm; ++k) {
         for (int i = 0; i < n; ++i) err[i] = epi_error(F + 9 * k, m1, m2, i);
@@ -294,8 +296,7 @@ int ocv_find_fundamental_mask(const float *m1, const float *m2, int n, double th
       const float t = (float)(sigma * sigma);
       int good = 0;
       for (int i = 0; i < n; ++i) { mask[i] = epi_error(best, m1, m2, i) <= t; good += mask[i]; }
-      result = good;
-      if (good < 7) for (int i = 0; i < n; ++i) mask[i] = 1;        /* run() reports failure: empty result, nothing is rejected */
+      result = good;                                                /* (good < 7: run() reports failure, the mask it copied out stands) */
     }
   }
   free(cur); free(err);

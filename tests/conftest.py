@@ -33,6 +33,41 @@ def U():
     return load_pkg()
 
 
+def load_pkg_exp():
+    """the same package a second time, bound to the experiments build (liburf_front_exp.so: fault injection, kernel A/B
+    switches) -- its own module tree, its own library handle; None when that library was not built"""
+    if "ur_mvo_amd_exp" in sys.modules:
+        return sys.modules["ur_mvo_amd_exp"]
+    d = os.path.join(ROOT, "ur-mvo_amd")
+    so = os.path.join(d, "liburf_front_exp.so")
+    if not os.path.exists(so):
+        return None
+    spec = importlib.util.spec_from_file_location("ur_mvo_amd_exp", os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["ur_mvo_amd_exp"] = m
+    old = os.environ.get("URF_LIB")
+    os.environ["URF_LIB"] = so
+    try:
+        spec.loader.exec_module(m)
+        m._lib.lib()
+    finally:
+        if old is None:
+            del os.environ["URF_LIB"]
+        else:
+            os.environ["URF_LIB"] = old
+    return m
+
+
+@pytest.fixture(scope="session")
+def Uexp():
+    """the experiments build (test hooks); tests that need it skip when it is absent"""
+    m = load_pkg_exp()
+    if m is None:
+        pytest.skip("liburf_front_exp.so is not built (`make -C ur-mvo_amd/csrc experiments`; __graft_entry__.build() does)")
+    return m
+
+
 @pytest.fixture(scope="session")
 def O():
     from oracle import oracle

@@ -30,9 +30,10 @@ class RNG:
 def collinear_last(p, count):
     i = count - 1
     for j in range(i):
-        dx1, dy1 = float(p[j][0]) - float(p[i][0]), float(p[j][1]) - float(p[i][1])
+        # Point2f differences: float32 arithmetic, widened afterwards
+        dx1, dy1 = float(np.float32(p[j][0]) - np.float32(p[i][0])), float(np.float32(p[j][1]) - np.float32(p[i][1]))
         for k in range(j):
-            dx2, dy2 = float(p[k][0]) - float(p[i][0]), float(p[k][1]) - float(p[i][1])
+            dx2, dy2 = float(np.float32(p[k][0]) - np.float32(p[i][0])), float(np.float32(p[k][1]) - np.float32(p[i][1]))
             if abs(dx2 * dy1 - dy2 * dx1) <= np.finfo(np.float32).eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
                 return True
     return False

@@ -12,15 +12,37 @@ import pytest
 from conftest import ROOT
 
 
+def _declared(hdr):
+    d = set(re.findall(r"\b(urf_[a-z0-9_]+)\s*\(", hdr, flags=re.I))
+    return {x for x in d if not x.startswith("urf_sp_config") and x != "urf_dmatch"}
+
+
 def test_library_exports_every_declared_symbol(U):
     hdr = open(os.path.join(ROOT, "include", "urf.h")).read()
-    declared = set(re.findall(r"\b(urf_[a-z0-9_]+)\s*\(", hdr, flags=re.I))
-    declared = {d for d in declared if not d.startswith("urf_sp_config") and d != "urf_dmatch"}
-    assert len(declared) >= 30
+    # the block under #ifdef URF_EXPERIMENTS (test hooks, kernel A/B switches) belongs to the experiments build alone
+    m = re.search(r"#ifdef URF_EXPERIMENTS\n(.*?)#endif\n", hdr, flags=re.S)
+    assert m, "include/urf.h lost its experiments block"
+    hooks = _declared(m.group(1))
+    declared = _declared(hdr.replace(m.group(0), ""))
+    assert len(declared) >= 30 and len(hooks) >= 5 and not (declared & hooks)
     L = U._lib.lib()
     missing = [d for d in sorted(declared) if not hasattr(L, d)]
     assert not missing, missing
     assert set(U._lib.SYMBOLS) == declared
+    assert set(U._lib.EXPERIMENT_SYMBOLS) == hooks
+    # the product library carries no fault injection and no kernel switches
+    leaked = [d for d in sorted(hooks) if hasattr(L, d)]
+    assert not leaked, leaked
+
+
+def test_experiments_build_exports_the_test_hooks():
+    from conftest import load_pkg_exp
+    X = load_pkg_exp()
+    if X is None:
+        pytest.skip("liburf_front_exp.so is not built")
+    L = X._lib.lib()
+    assert b"EXPERIMENTS" in L.urf_build_info()
+    assert all(hasattr(L, d) for d in X._lib.SYMBOLS + X._lib.EXPERIMENT_SYMBOLS)
 
 
 def test_no_gpu_fails_loudly_not_silently(U):
@@ -355,3 +377,36 @@ def test_shim_headers_opencv_branch_is_well_formed():
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "cpp", "cv_stubs"),
                         "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_no_barrier_is_reached_with_an_lds_write_in_flight():
+    """hipcc of ROCm 7.2 leaves out the `s_waitcnt lgkmcnt(0)` of __syncthreads() at a barrier that heads a loop when the
+    pending LDS write sits on the back edge; the other waves then read the previous iteration's value whenever that write is
+    still queued behind other workgroups' LDS traffic -- the run-to-run differences of the register-resident Sinkhorn that
+    round 4 could only avoid.  The audit (tools/isa_barrier_audit.py) walks the basic-block graph of
+    every kernel of the product build: no s_barrier may be reachable with one of the wave's own LDS writes un-waited.  It
+    must also still see the fault where it is known to be: the shared forms of the experiments build without their fix."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_barrier_audit", os.path.join(ROOT, "tools", "isa_barrier_audit.py"))
+    A = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(A)
+    # the checker on hand-written streams: a write on the back edge of a loop whose header is the barrier (the fault), the same
+    # with the wait written out, a counted wait that does / does not cover the write, a scalar load in between (out of order)
+    def fn(body):
+        return "kern:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n"
+    loop = "\tds_read_b32 v1, v0\n.LBB0_1:\n\ts_barrier\n\tds_read_b32 v2, v0\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 v0, v2\n%s\ts_cbranch_scc1 .LBB0_1"
+    assert [ln for _, ln in A.audit_text(fn(loop % ""))] == [4]
+    assert A.audit_text(fn(loop % "\ts_waitcnt lgkmcnt(0)\n")) == []
+    assert A.audit_text(fn("\tds_write_b32 v0, v1\n\tds_read_b32 v2, v0\n\ts_waitcnt lgkmcnt(1)\n\ts_barrier")) == []
+    assert len(A.audit_text(fn("\tds_write_b32 v0, v1\n\tds_read_b32 v2, v0\n\ts_waitcnt lgkmcnt(2)\n\ts_barrier"))) == 1
+    assert len(A.audit_text(fn("\tds_write_b32 v0, v1\n\ts_load_dword s0, s[2:3], 0x0\n\ts_waitcnt lgkmcnt(1)\n\ts_barrier"))) == 1
+    assert A.audit_text(fn("\tds_write_b32 v0, v1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier")) == []
+    csrc = os.path.join(ROOT, "ur-mvo_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read() if f.endswith(".hip") else ""
+        if "__syncthreads" in src or "s_barrier" in src:
+            assert A.audit_text(A.compile_to_asm(os.path.join(csrc, f))) == [], f
+    hits = A.audit_text(A.compile_to_asm(os.path.join(csrc, "sinkhorn_resident.hip"), ["-DURF_EXPERIMENTS"]))
+    assert any("sinkhorn_regs_kernel" in name for name, _ in hits), "the audit no longer sees the known fault of the shared forms"
+    fixed = A.audit_text(A.compile_to_asm(os.path.join(csrc, "sinkhorn_resident.hip"), ["-DURF_EXPERIMENTS", "-DURF_RS_LGKM_BARRIER"]))
+    assert not any("sinkhorn_regs_kernel" in name for name, _ in fixed)

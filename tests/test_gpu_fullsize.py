@@ -620,10 +620,12 @@ def test_resident_sinkhorn_equals_the_streaming_kernels(U, tmp_path):
             o += zs + 2 * n0
 
 
-def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(U, F, sg_blob):
+def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(Uexp, sg_blob):
     """a resident launch that reports a give-up (urf_probe_sinkhorn_fault; in the field: its workgroups never became
     co-resident) costs nothing but time: the batch is redone with the streaming kernels before the results leave the
-    library, the handle stays on them, and the caller sees the same matches"""
+    library, the handle stays on them, and the caller sees the same matches.  (The fault-injection hook exists in the
+    experiments build only.)"""
+    U, F = Uexp, Uexp.frontend
     L = U._lib.lib()
     rng = np.random.default_rng(77)
     f0 = make_features(rng, 1000)
@@ -653,10 +655,64 @@ def test_resident_sinkhorn_give_up_is_redone_with_the_streaming_kernels(U, F, sg
     assert pm.sinkhorn_fallbacks() == 1
 
 
-def test_resident_sinkhorn_give_up_is_not_sticky(U, F, sg_blob, monkeypatch):
+def test_sinkhorn_integrity_check_catches_a_shifted_potential(Uexp, sg_blob):
+    """the strict guarantee does not rest on the resident Sinkhorn being infallible: the decode sums every column of the plan it
+    reads, and a launch whose column marginals miss 1 by more than the bound (1e-4; clean launches stay below 2e-5) has its
+    tail redone with the streaming kernels before the lists leave the library.  urf_probe_sinkhorn_corrupt (experiments
+    build) shifts one column potential of the next launch after its iterations -- a damaged last iteration: the caller sees the same lists, the counter moves, the handle stays on the resident kernel."""
+    import ctypes as C
+    U, F = Uexp, Uexp.frontend
+    L = U._lib.lib()
+    L.urf_probe_sinkhorn_corrupt.argtypes = [C.c_int, C.c_float]
+    rng = np.random.default_rng(79)
+    f0 = make_features(rng, 900)
+    f1 = make_features(rng, 1000, planted_from=f0, m=550)
+    for prec in (3, 1):
+        pm = F.PointMatching(F.SuperGlueConfig(), precision=prec, calibrate_pairs=-1)   # (the calibration's own fast pass would eat the armed fault)
+        assert pm.build(sg_blob)
+        want = pm.MatchingPoints(f0, f1, True)
+        clean = pm.sinkhorn_residuals(1)[0]
+        assert len(want) > 300 and 0.0 < clean < 2e-5, clean
+        assert pm.sinkhorn_integrity()["pairs"] == 0
+        try:
+            assert L.urf_probe_sinkhorn_corrupt(1, 3e-3) == 0
+            got = pm.MatchingPoints(f0, f1, True)
+        finally:
+            L.urf_probe_sinkhorn_corrupt(0, 0.0)
+        integ = pm.sinkhorn_integrity()
+        assert integ["pairs"] == 1 and integ["events"] == 1 and abs(integ["bound"] - 1e-4) < 1e-9
+        assert pm.sinkhorn_fallbacks() == 0                      # not a give-up: no back-off
+        assert [(q, t) for q, t, _ in got] == [(q, t) for q, t, _ in want]
+        assert np.abs(np.array([m[2] for m in got]) - np.array([m[2] for m in want])).max() < 1e-3
+        assert pm.sinkhorn_residuals(1)[0] < 2e-5                # of the redone tail
+        # the next launch is a resident one again and passes
+        assert [(q, t) for q, t, _ in pm.MatchingPoints(f0, f1, True)] == [(q, t) for q, t, _ in want]
+        assert pm.sinkhorn_integrity()["pairs"] == 1
+    # a shift below the bound is not reported (and moves no decision: it is far inside the guard's margin of the strict mode)
+    pm = F.PointMatching(F.SuperGlueConfig(), precision=3, calibrate_pairs=-1)
+    assert pm.build(sg_blob)
+    try:
+        assert L.urf_probe_sinkhorn_corrupt(1, 2e-5) == 0
+        got = pm.MatchingPoints(f0, f1, True)
+    finally:
+        L.urf_probe_sinkhorn_corrupt(0, 0.0)
+    assert pm.sinkhorn_integrity()["pairs"] == 0
+    # the bound is configuration: off (< 0) lets the corrupted launch through
+    pm = F.PointMatching(F.SuperGlueConfig(), precision=1, sinkhorn_residual_bound=-1.0)
+    assert pm.build(sg_blob)
+    try:
+        assert L.urf_probe_sinkhorn_corrupt(1, 3e-3) == 0
+        pm.MatchingPoints(f0, f1, True)
+    finally:
+        L.urf_probe_sinkhorn_corrupt(0, 0.0)
+    assert pm.sinkhorn_integrity()["pairs"] == 0 and pm.sinkhorn_residuals(1)[0] > 1e-3
+
+
+def test_resident_sinkhorn_give_up_is_not_sticky(Uexp, sg_blob, monkeypatch):
     """after a give-up the handle stays on the streaming kernels for a bounded number of batches (64, doubling per give-up;
     2 here through the test knob) and then goes back to the resident kernel: a later fault is seen again -- it would not
     be if the handle had stayed on the streaming kernels for good"""
+    U, F = Uexp, Uexp.frontend
     L = U._lib.lib()
     rng = np.random.default_rng(78)
     f0 = make_features(rng, 700)

@@ -628,14 +628,16 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2, 3])
-def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec):
+@pytest.mark.parametrize("prec,depth", [(0, 3), (1, 3), (2, 3), (3, 3), (3, 5), (3, 1)])
+def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec, depth):
     """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
     SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)
     (src/tracking.cc:321-377) as the CPU ORACLE runs it: O.sp_infer / O.match_points on the same 21 frames.
     Exact mode: features and match lists bit for bit; fast modes: the same keypoint sets, and correspondences that may differ
     in a pair whose decisive matching scores are a near-tie (measured on this stream: one pair of twenty differs in two of its
-    ~700 correspondences)."""
+    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 5 = matchers + 3 is the pipelined loop
+    bench.py times (SuperPoint two batches ahead of the matchers, fetches begun one step before they are ended), 1 = a collect
+    right after every submit (integration/tracking.patch)."""
     from conftest import oracle_frames_and_pairs
     frames = np.stack(U.synth.shift_stream(17, 21, 480, 640))
     ofeats, olists = oracle_frames_and_pairs(list(frames), [(t - 1, t) for t in range(1, 21)])
@@ -645,7 +647,7 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
     got_K, got_m, got_f = [], [], []
     for b0 in (0, 8, 16):
         fs.submit(frames[b0:b0 + 8])
-        if fs.in_flight() == 3:
+        while fs.in_flight() >= depth:
             K, m, f = fs.collect(want_features=True)
             got_K += list(K); got_m += m; got_f += f
     while fs.in_flight():
@@ -701,8 +703,7 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     fs.submit(frames[0:4])                      # predecessor chain
     fs.submit(frames[4:8], ref=[0, 0, 5, -1])   # keyframe 0 (previous batch), an earlier frame of this batch, predecessor
     fs.submit(frames[8:12], ref=[0, 3, 7, 10])  # keyframe two batches back; its match call is deferred
-    with pytest.raises(RuntimeError, match="in flight"):
-        fs.submit(frames[8:12])                 # matchers + 1 batches already in flight
+    assert fs.in_flight() == 3 and not fs.ready()   # (the oldest batch's fetch has not begun: a collect would wait)
     while fs.in_flight():
         out += fs.collect()[1]
     for t in range(1, 12):
@@ -712,6 +713,16 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
     assert _as_tuples(fs.collect()[1][3]) == olists[11]
+    # matchers + 3 batches may be in flight (SuperPoint two ahead of the matchers, one batch begun, one being handed out)
+    for _ in range(5):
+        fs.submit(frames[4:8])
+    with pytest.raises(RuntimeError, match="in flight"):
+        fs.submit(frames[4:8])
+    assert fs.in_flight() == 5
+    n = 0
+    while fs.in_flight():
+        n += len(fs.collect()[1])
+    assert n == 20
 
 
 def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg_blob):

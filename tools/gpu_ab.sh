@@ -3,7 +3,7 @@
 #   tools/gpu_ab.sh OUTDIR "name1 ENV=.. ENV=.." "name2 ..." ...      (extra bench flags: BENCH_FLAGS="--precision 2")
 out=$1; shift
 mkdir -p "$out"
-export URF_LIB=$PWD/ur-mvo_amd/liburf_front_exp.so
+export URF_LIB=${AB_LIB:-$PWD/ur-mvo_amd/liburf_front_exp.so}
 for spec in "$@"; do
   set -- $spec
   name=$1; shift

@@ -28,7 +28,8 @@ for (H, W) in sizes:
         assert sp.build(spb)
         pms = []
         for _ in range(2):
-            pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=8, precision=prec)
+            pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=8, precision=prec,
+                                 sinkhorn_residual_bound=float(os.environ.get("URF_SOAK_RESID_BOUND", "0")))
             assert pm.build(sgb)
             pms.append(pm)
         pipe = P.SlotRingPipeline(sp, pms, d_frames, 8, H, W, device=dev, defer=int(os.environ.get('URF_BENCH_DEFER', '2')), sp_ahead=int(os.environ.get('URF_BENCH_SP_AHEAD', '2')))
@@ -43,8 +44,15 @@ for (H, W) in sizes:
         CKS = os.environ.get("URF_CHECKSUMS") == "1"     # experiments build + URF_BENCH_DEFER=0: per-stage checksums of every batch
         CKN = ("encoded keypoints", "projected descriptors", "couplings", "u", "v")
 
+        resid = {}
+        rmax = [0.0]
+        integ0 = [m.sinkhorn_integrity()["pairs"] for m in pms]
+
         def rec(b, mt, res):
             lists[b] = [r.copy() for r in res]
+            resid[b] = mt.sinkhorn_residuals(8)
+            rmax[0] = max(rmax[0], max(resid[b]))
+            resid.pop(b - 10, None)
             if CKS:
                 arr = (ctypes.c_ulonglong * 8)()
                 U._lib.lib().urf_probe_pm_checksums(mt._h, arr)
@@ -77,7 +85,8 @@ for (H, W) in sizes:
                             same_idx = len(x) == len(y) and np.array_equal(x["queryIdx"], y["queryIdx"]) and np.array_equal(x["trainIdx"], y["trainIdx"])
                             dd = float(np.abs(x["distance"] - y["distance"]).max()) if same_idx and len(x) else -1.0
                             print(f"   {W}x{H} precision {prec}: batch {b} pair {j}: {len(x)} vs {len(y)} matches (batch {b - 5}); same index lists {same_idx}, max |distance difference| {dd:.3g}; "
-                                  f"flags {mt.near_tie_flags(8)}, Sinkhorn fallbacks {[m.sinkhorn_fallbacks() for m in pms]}")
+                                  f"flags {mt.near_tie_flags(8)}, Sinkhorn fallbacks {[m.sinkhorn_fallbacks() for m in pms]}; "
+                                  f"column-marginal residual {resid[b][j]:.3g} (batch {b}) / {resid[b - 5][j]:.3g} (batch {b - 5})")
             lists.pop(b - 10, None)
 
         for b in range(steps):
@@ -101,5 +110,7 @@ for (H, W) in sizes:
             n_ = ctypes.c_ulonglong(0)
             U._lib.lib().urf_probe_rs_verify(ctypes.byref(n_))
             print(f"   load verification inside the register Sinkhorn: {n_.value & 0xFFFFFFFF} couplings read differently by two loads, {n_.value >> 32} column sums read back from LDS differently than written (cumulative)")
+        print(f"   largest column-marginal residual of any handed-out pair {rmax[0]:.3g}; pairs redone by the integrity check "
+              f"{sum(m.sinkhorn_integrity()['pairs'] for m in pms) - sum(integ0)} (bound {pms[0].sinkhorn_integrity()['bound']:.3g})")
         print(f"{W}x{H} precision {prec}: {steps} steps, checksum mismatches {bad_c[0]}, list mismatches {bad_l}, slot-batch mismatches {bad_s}, guard {sp.near_tie_reruns()}, pairs redone {sum(m.near_tie_reruns()['redone'] for m in pms)}")
         del pipe, sp, pms

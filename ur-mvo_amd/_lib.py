@@ -19,16 +19,21 @@ SYMBOLS = [
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
     "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_fetch_begin", "urf_pm_fetch_ready", "urf_pm_fetch_end", "urf_pm_sync",
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
-    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_sp_result_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_probe_h2gemm_variant", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
+    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_sp_result_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync", "urf_cam_size",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
-    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
+    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_ready", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
     "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_group_start", "urf_comm_group_end", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
-    "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_probe_sinkhorn_fault", "urf_probe_sinkhorn_backoff",
-    "urf_probe_sinkhorn_stamps", "urf_sg_debug_couplings", "urf_probe_mfma_roof", "urf_probe_h2gemm_xflags", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
+    "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_pm_sinkhorn_integrity", "urf_pm_sinkhorn_residuals",
+    "urf_sg_debug_couplings", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
+]
+# exported by the experiments build only (#ifdef URF_EXPERIMENTS in include/urf.h): fault injection, kernel A/B switches, diagnostics
+EXPERIMENT_SYMBOLS = [
+    "urf_probe_h2gemm_variant", "urf_probe_h2gemm_xflags", "urf_probe_sinkhorn_stamps", "urf_probe_sinkhorn_fault",
+    "urf_probe_sinkhorn_backoff", "urf_probe_sinkhorn_corrupt", "urf_probe_mfma_roof",
 ]
 
 
@@ -43,7 +48,8 @@ class SGConfig(C.Structure):
                 ("sinkhorn_iterations", C.c_int), ("max_pairs", C.c_int), ("device", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
                 ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
-                ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int)]
+                ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int),
+                ("sinkhorn_residual_bound", C.c_float), ("calibrate_pairs", C.c_int)]
 
 
 class EpiConfig(C.Structure):
@@ -110,6 +116,11 @@ def lib():
         missing = [s for s in SYMBOLS if not hasattr(L, s)]
         if missing:
             raise RuntimeError(f"liburf_front.so lacks C-ABI symbols: {missing}")
+        L.urf_build_info.restype = C.c_char_p
+        if b"EXPERIMENTS" in L.urf_build_info():
+            missing = [s for s in EXPERIMENT_SYMBOLS if not hasattr(L, s)]
+            if missing:
+                raise RuntimeError(f"the experiments build lacks its test hooks: {missing}")
         L.urf_last_error.restype = C.c_char_p
         L.urf_build_info.restype = C.c_char_p
         L.urf_slot_bytes.restype = C.c_size_t

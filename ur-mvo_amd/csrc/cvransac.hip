@@ -34,20 +34,22 @@ struct CvRng {
   __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + (unsigned)a); }
 };
 
+// (the differences are taken in float -- Point2f minus Point2f -- and widened afterwards, as haveCollinearPoints does)
 __device__ bool cv_collinear_last(const float *p, const int *idx) {
-  const double xi = p[2 * idx[6]], yi = p[2 * idx[6] + 1];
+  const float xi = p[2 * idx[6]], yi = p[2 * idx[6] + 1];
   for (int j = 0; j < 6; ++j) {
-    const double dx1 = (double)p[2 * idx[j]] - xi, dy1 = (double)p[2 * idx[j] + 1] - yi;
+    const double dx1 = (double)(p[2 * idx[j]] - xi), dy1 = (double)(p[2 * idx[j] + 1] - yi);
     for (int k = 0; k < j; ++k) {
-      const double dx2 = (double)p[2 * idx[k]] - xi, dy2 = (double)p[2 * idx[k] + 1] - yi;
+      const double dx2 = (double)(p[2 * idx[k]] - xi), dy2 = (double)(p[2 * idx[k] + 1] - yi);
       if (fabs(dx2 * dy1 - dy2 * dx1) <= (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
     }
   }
   return false;
 }
 
-__device__ bool cv_get_subset(const float *m1, const float *m2, int count, CvRng &rng, int *idx) {
-  for (int attempt = 0; attempt < 10000; ++attempt) {
+// max_attempts: 10000 from RANSACPointSetRegistrator::run, getSubset's default 1000 from LMeDSPointSetRegistrator::run
+__device__ bool cv_get_subset(const float *m1, const float *m2, int count, CvRng &rng, int *idx, int max_attempts) {
+  for (int attempt = 0; attempt < max_attempts; ++attempt) {
     for (int i = 0; i < 7; ++i) {
       for (;;) {
         const int c = rng.uniform(0, count);
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
         if (lane == 0) {
           int idx[7];
           int nm = -1;
-          if (cv_get_subset(m1, m2, n, rng, idx)) {
+          if (cv_get_subset(m1, m2, n, rng, idx, 10000)) {
             for (int i = 0; i < 7; ++i) sIdx[i] = idx[i];
             nm = cv_run_7point(m1, m2, idx, sA, sF);
           }
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
         if (lane == 0) {
           int idx[7];
           int nm = -1;
-          if (cv_get_subset(m1, m2, n, rng, idx)) nm = cv_run_7point(m1, m2, idx, sA, sF);
+          if (cv_get_subset(m1, m2, n, rng, idx, 1000)) nm = cv_run_7point(m1, m2, idx, sA, sF);
           sCtl[0] = nm;
         }
         __syncthreads();
@@ -318,11 +320,9 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
         double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (n - 7)) * sqrt(min_median);
         if (sigma < 0.001) sigma = 0.001;
         const float t = (float)(sigma * sigma);
-        int good = 0;
-        if (lane < n) { const uint8_t in = cv_epi_error(sBest, m1, m2, lane) <= t; mask[lane] = in; good = in; }
-        good = wave_sum_int(good);
-        if (good < 7)
-          for (int i = lane; i < n; i += 64) mask[i] = 1;
+        // (fewer than 7 inliers: run() reports failure and findFundamentalMat returns an empty matrix, but the mask has been
+        // copied out by then -- the reference filters with it as it stands)
+        if (lane < n) mask[lane] = cv_epi_error(sBest, m1, m2, lane) <= t;
       }
     }
   }

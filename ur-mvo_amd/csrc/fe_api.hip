@@ -11,8 +11,16 @@
 // consecutive batches (SuperPoint | matcher A | matcher B).  Only raw u8 frames
 // go up and match lists (optionally features) come down.
 //
+// The loop shape is the one bench.py times (ur-mvo_amd/pipeline.py), driven by the caller's submits:
+//   urf_fe_submit(b):  copy + SuperPoint(b)  ->  match(b - 2)  ->  fetch_begin(b - M - 1)   (the only wait: that batch's fast pass)
+// so SuperPoint -- the busiest stream of the strict mode -- always has two batches queued when the host waits, a matcher handle
+// gets its next batch as soon as the previous one's fetch has BEGUN (the exact redo of its flagged pairs then runs on the handle's
+// redo engine, beside the next batches), and urf_fe_collect hands out the oldest batch, waiting for a redo only when the caller
+// insists on a batch whose redo is still running.  A caller that collects right after a submit (integration/tracking.patch) gets
+// the synchronous behaviour: collect enqueues whatever of that batch is still missing.
+//
 // This file is orchestration only: it calls the same C ABI a user would
-// (urf_sp_infer_device, urf_match_device_async, urf_pm_fetch, urf_cam_*).
+// (urf_sp_infer_device, urf_match_device_async, urf_pm_fetch_begin / _end, urf_cam_*).
 #include <cstring>
 #include <deque>
 #include <vector>
@@ -47,7 +55,8 @@ struct urf_fe {
   long frames_seen = 0;               // global index of the first frame of the next batch
   struct Pending {
     long batch; int n; int first_pair; long first_frame;
-    bool matched;                       // its match call has been enqueued (else deferred until its matcher is free)
+    bool matched;                       // its match call has been enqueued
+    bool begun;                         // its urf_pm_fetch_begin has been made (the matcher handle is free for its next batch)
     std::vector<const void *> s0, s1;
   };
   std::deque<Pending> pending;
@@ -67,8 +76,16 @@ extern "C" int urf_fe_create(const urf_fe_config *cfg, urf_fe **out) {
   h->cfg = *cfg;
   h->B = cfg->batch;
   h->M = cfg->matchers <= 0 ? 2 : (cfg->matchers > kMaxMatchers ? kMaxMatchers : cfg->matchers);
-  // ring: M batches being matched + 1 whose SuperPoint already runs + the 2 + history_batches a reference may reach
-  h->NB = h->M + 3 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
+  // ring: entry k is refilled by SuperPoint(b) while every batch up to b - M - 2 has had its fetch begun (its fast pass is over);
+  // a match reads slots up to 2 + history_batches submits old: NB = M + 4 + history_batches
+  h->NB = h->M + 4 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
+  // a strict matcher promises the oracle's lists only on slots an exact SuperPoint made (include/urf.h): a configuration that
+  // asks for precision 3 on one side alone would get a 2.2e-4 margin on noisy descriptors -- neither strict nor guarded
+  if (cfg->sg.precision == 3 && (cfg->sp.precision == 1 || cfg->sp.precision == 2)) {
+    delete h;
+    URF_CHECK(false, "urf_fe_create: a strict-parity matcher (sg.precision 3) needs an exact SuperPoint (sp.precision 0 or 3), not %d: "
+              "give both entries the same #precision suffix", cfg->sp.precision);
+  }
   urf_sp_config sc = cfg->sp;
   sc.max_batch = h->B;
   if (urf_sp_create(&sc, &h->sp)) { delete h; return -1; }
@@ -162,16 +179,45 @@ static int fe_enqueue_match(urf_fe *h, urf_fe::Pending &p) {
   p.matched = true;
   return 0;
 }
+static int fe_begin(urf_fe *h, urf_fe::Pending &p) {
+  if (!p.s0.empty() && urf_pm_fetch_begin(h->pm[p.batch % h->M], (int)p.s0.size()) < 0) return -1;
+  p.begun = true;
+  return 0;
+}
+// everything of the batches up to `upto` (index into pending, oldest first) that is still missing, in order: a batch's match
+// call needs its matcher's previous batch begun (M submits older: further up the queue), its begin needs its match call
+static int fe_force(urf_fe *h, size_t upto) {
+  for (size_t i = 0; i <= upto && i < h->pending.size(); ++i) {
+    urf_fe::Pending &q = h->pending[i];
+    if (!q.matched) {
+      for (size_t j = 0; j < i; ++j)
+        if (h->pending[j].batch % h->M == q.batch % h->M && !h->pending[j].begun && fe_begin(h, h->pending[j])) return -1;
+      if (fe_enqueue_match(h, q)) return -1;
+    }
+  }
+  return 0;
+}
+// the throughput step of a submit (newest batch b): match(b - 2), then fetch_begin(b - M - 1)
+static int fe_pump(urf_fe *h) {
+  const long b = h->pending.back().batch;
+  for (size_t i = 0; i < h->pending.size(); ++i)
+    if (h->pending[i].batch <= b - 2 && !h->pending[i].matched && fe_force(h, i)) return -1;
+  for (size_t i = 0; i < h->pending.size(); ++i) {
+    urf_fe::Pending &q = h->pending[i];
+    if (q.batch <= b - h->M - 1 && q.matched && !q.begun && fe_begin(h, q)) return -1;
+  }
+  return 0;
+}
 
 // Would the NEXT urf_fe_submit accept global frame `frame` as a reference?  The same test submit applies to a reference
 // outside its own batch: the frame sits in a ring entry that is not the one about to be refilled and is at most
-// NB - M - 1 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
+// NB - M - 2 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
 // drain --, so the window cannot be derived from a frame count; integration/tracking.patch asks here).
 static const uint8_t *fe_resident_slot(urf_fe *h, long want) {
   const long b = h->next_batch;
   const int k = (int)(b % h->NB);
   for (int e = 0; e < h->NB; ++e)
-    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 1) && want >= h->batch_first[e] &&
+    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 2) && want >= h->batch_first[e] &&
         want < h->batch_first[e] + h->batch_n[e])
       return slot_ptr(h, e, (int)(want - h->batch_first[e]));
   return nullptr;
@@ -190,7 +236,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
                              size_t frame_stride, const long *ref) {
   URF_CHECK(h && h->built, "urf_fe_submit: handle is not built");
   URF_CHECK(frames && n >= 1 && n <= h->B && rows > 0 && cols > 0 && step >= (size_t)cols, "urf_fe_submit: bad argument");
-  URF_CHECK((int)h->pending.size() <= h->M, "urf_fe_submit: %d batches in flight, collect one first", h->M + 1);
+  URF_CHECK((int)h->pending.size() <= h->M + 2, "urf_fe_submit: %d batches in flight, collect one first", h->M + 3);
   URF_HIP(hipSetDevice(h->cfg.sp.device));
   if (!h->d_raw) {
     h->rows = rows; h->cols = cols;
@@ -216,8 +262,8 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
     if (want >= h->frames_seen) {
       src = slot_ptr(h, k, (int)(want - h->frames_seen));   // an earlier frame of this batch
     } else {
-      // window = the last NB - M - 1 batches: an older ring entry may be refilled by SuperPoint while
-      // this batch's matcher (up to M submits behind) still reads it; entry k is being refilled now
+      // window = the last NB - M - 2 batches: an older ring entry may be refilled by SuperPoint while
+      // this batch's matcher (up to M + 1 submits behind) still reads it; entry k is being refilled now
       src = fe_resident_slot(h, want);
     }
     URF_CHECK(src, "urf_fe_submit: reference frame %ld has left the ring (history_batches too small)", want);
@@ -227,7 +273,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
   const size_t fr = (size_t)rows * cols;
   hipStream_t st = (hipStream_t)urf_sp_stream(h->sp);
   // raw frames -> pinned staging -> device, on SuperPoint's stream.  The staging entry k was last
-  // read by the copy of batch b - NB, which finished before match(b - NB) was collected.
+  // read by the copy of batch b - NB, which finished before match(b - NB) had its fetch begun.
   uint8_t *stage = h->h_stage + (size_t)k * h->B * fr;
   for (int j = 0; j < n; ++j)
     for (int r = 0; r < rows; ++r) memcpy(stage + (size_t)j * fr + (size_t)r * cols, frames + (size_t)j * frame_stride + (size_t)r * step, cols);
@@ -249,15 +295,13 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
   h->batch_first[k] = h->frames_seen;
   h->batch_n[k] = n;
   h->batch_id[k] = b;
-  urf_fe::Pending p{b, n, first_pair, h->frames_seen, false, std::move(s0), std::move(s1)};
-  // SuperPoint(b) is enqueued in any case; the match call needs its matcher handle free, i.e. the batch
-  // M submits back collected -- otherwise it is deferred to that collect
-  if ((int)h->pending.size() < h->M) {
-    if (fe_enqueue_match(h, p)) return -1;
-  }
+  urf_fe::Pending p{b, n, first_pair, h->frames_seen, false, false, std::move(s0), std::move(s1)};
   h->pending.push_back(std::move(p));
   h->next_batch = b + 1;
   h->frames_seen += n;
+  // SuperPoint(b) is enqueued; now the step of the older batches (see the head of this file).  This batch has been accepted:
+  // a failure on behalf of an older one is reported by the collect that reaches it
+  if (fe_pump(h)) h->deferred_error = true;
   return 0;
 }
 
@@ -271,15 +315,16 @@ extern "C" int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *match
   if (h->deferred_error) { h->deferred_error = false; return -1; }   // urf_last_error() still holds the enqueue failure
   URF_CHECK(!h->pending.empty(), "urf_fe_collect: nothing submitted");
   URF_HIP(hipSetDevice(h->cfg.sp.device));
-  const urf_fe::Pending &p0 = h->pending.front();
-  URF_CHECK(p0.matched, "urf_fe_collect: internal: oldest batch has no match call");
+  if (fe_force(h, 0)) return -1;                       // (a caller that collects right after its submit: the synchronous shape)
+  urf_fe::Pending &p0 = h->pending.front();
+  if (!p0.begun && fe_begin(h, p0)) return -1;
   const urf_fe::Pending p = p0;
   const int k = (int)(p.batch % h->NB);
   urf_pm *pm = h->pm[p.batch % h->M];
   const int P = p.n - p.first_pair;
   for (int j = 0; j < p.n; ++j) nmatch[j] = 0;
   if (P > 0) {
-    if (urf_pm_fetch(pm, P, matches + (size_t)p.first_pair * cap, cap, nmatch + p.first_pair)) return -1;
+    if (urf_pm_fetch_end(pm, P, matches + (size_t)p.first_pair * cap, cap, nmatch + p.first_pair)) return -1;
   } else {
     if (urf_sp_sync(h->sp)) return -1;
   }
@@ -292,13 +337,17 @@ extern "C" int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *match
     }
   *nframes = p.n;
   h->pending.pop_front();
-  for (auto &q : h->pending)     // the matcher handle is free again: enqueue the batch that was waiting for it
-    if (!q.matched && q.batch % h->M == p.batch % h->M) {
-      // this batch has been delivered: a failure of the deferred enqueue belongs to the NEXT call
-      if (fe_enqueue_match(h, q)) h->deferred_error = true;
-      break;
-    }
   return 0;
+}
+
+// 1 when urf_fe_collect would return without waiting for the GPU (the oldest batch's lists are final), 0 when not, < 0 on error
+extern "C" int urf_fe_ready(urf_fe *h) {
+  URF_CHECK(h && h->built, "urf_fe_ready: handle is not built");
+  if (h->pending.empty() || h->deferred_error) return 0;
+  const urf_fe::Pending &p = h->pending.front();
+  if (!p.matched || !p.begun) return 0;
+  if (p.s0.empty()) return 1;
+  return urf_pm_fetch_ready(h->pm[p.batch % h->M]);
 }
 
 extern "C" int urf_fe_in_flight(urf_fe *h) { return h ? (int)h->pending.size() : 0; }

@@ -480,8 +480,10 @@ int launch_split(const float *x, size_t n, _Float16 *h, _Float16 *l, hipStream_t
 using namespace urf;
 
 // probe: Y[M][N] = X[M][K] W[K][N] + bias via the split-f16 path; returns ms per call (avg of reps)
+#ifdef URF_EXPERIMENTS   // kernel A/B switches: experiments build only (include/urf.h)
 extern "C" int urf_probe_h2gemm_variant(int v) { urf::g_h2gemm_variant = v; return 0; }
 extern "C" int urf_probe_h2gemm_xflags(int f) { urf::g_h2gemm_xflags = f; return 0; }
+#endif
 extern "C" int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                                 int reps, float *ms_out, int device) {
   URF_CHECK(X && W && Y && (N % 128) == 0 && (K % 64) == 0, "probe_h2gemm: need N%%128==0, K%%64==0");

@@ -136,6 +136,7 @@ extern "C" int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const fl
   return 0;
 }
 
+#ifdef URF_EXPERIMENTS   // roof probe, LDS watcher: diagnostics of the experiments build only (include/urf.h)
 // ---------------------------------------------------------------------------------------------------
 // Roof probe: the split-f16 inner loop of h2gemm / h2conv / h2mlp (24 x v_mfma_f32_16x16x32_f16 on 12 operand
 // fragments) with the fragments held in registers -- no LDS, no memory, no barrier.  What the chip sustains on random
@@ -336,7 +337,6 @@ extern "C" int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int 
   return 0;
 }
 
-#ifdef URF_EXPERIMENTS
 // diagnostic (experiments build, tools/gpu_lds_watch.py): does anything else on the CU write into a workgroup's LDS / registers?
 // Every workgroup fills its LDS (static head + dynamic tail) and a few registers with an address pattern and re-checks them for
 // `ticks` of s_memrealtime while other streams' kernels (LDS-DMA users among them) come and go on the same CUs.
@@ -362,6 +362,71 @@ __global__ void __launch_bounds__(256) lds_watch_kernel(unsigned lds_words, unsi
     __builtin_amdgcn_s_sleep(8);
   }
   if (nbad) atomicAdd(bad, nbad);
+}
+// diagnostic (experiments build, tools/gpu_lds_handoff.py): is a value one wave writes to LDS and publishes with a barrier always
+// the value the other waves read?  The workgroup repeats the hand-offs of the register-resident Sinkhorn's iteration (DESIGN.md
+// section 12) -- per-wave partials -> 32 threads -> a broadcast vector read as b128 -> one wave that polls global memory and then
+// writes 1025 words for everybody -- with values that encode (iteration, index), for `ticks` of s_memrealtime, while other
+// streams' kernels (the exact convolutions with their LDS-DMA) share the CUs.  bad[0] = wrong words seen, bad[1] = of those the
+// PREVIOUS iteration's value (a stale read), first[0..5] = workgroup, hand-off, index, iteration, got, want of the first one.
+namespace urf {
+__device__ __forceinline__ unsigned ho_enc(unsigned k, unsigned what, unsigned idx) { return (k * 2654435761u) ^ (what * 0x85EBCA6Bu) ^ (idx * 40503u + 0x1234567u); }
+__global__ void __launch_bounds__(256) lds_handoff_kernel(unsigned long long ticks, unsigned long long *bad, unsigned *first, const unsigned long long *poll) {
+  __shared__ __attribute__((aligned(16))) unsigned avec[32];
+  __shared__ unsigned rowpart[4][32];
+  __shared__ unsigned csumv[1028];
+  const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned long long nbad = 0, nstale = 0;
+  auto check = [&](unsigned got, unsigned what, unsigned idx, unsigned k) {
+    const unsigned want = ho_enc(k, what, idx);
+    if (got != want) {
+      if (nbad == 0 && atomicAdd(bad + 2, 1ull) == 0) { first[0] = blockIdx.x; first[1] = what; first[2] = idx; first[3] = k; first[4] = got; first[5] = want; }
+      nbad += 1;
+      if (got == ho_enc(k - 1, what, idx)) nstale += 1;
+    }
+  };
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned k = 0;
+  bool more = true;
+  while (more) {
+    ++k;
+    __syncthreads();
+    if ((lane & 1) == 0) rowpart[wv][lane >> 1] = ho_enc(k, 1 + wv, lane >> 1);       // per-wave partials (half the lanes write, like the row pass)
+    __syncthreads();
+    if (tid < 32) {
+      for (unsigned q = 0; q < 4; ++q) check(rowpart[q][tid], 1 + q, tid, k);
+      avec[tid] = ho_enc(k, 7, tid);
+    }
+    __syncthreads();
+    for (unsigned q = 0; q < 8; ++q) {                                                  // the broadcast vector, 16 bytes at a time
+      const uint4 x = *(const uint4 *)(avec + 4 * q);
+      check(x.x, 7, 4 * q, k); check(x.y, 7, 4 * q + 1, k); check(x.z, 7, 4 * q + 2, k); check(x.w, 7, 4 * q + 3, k);
+    }
+    if (wv == 0) {
+      unsigned long long acc = 0;                                                        // the polling wave: 17 agent-scope loads, then 17 LDS writes
+#pragma unroll
+      for (unsigned q = 0; q < 17; ++q) acc += __hip_atomic_load(poll + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned z = (unsigned)(acc >> 63);                                          // 0 (the buffer holds small numbers); keeps the loads alive
+#pragma unroll
+      for (unsigned q = 0; q < 17; ++q)
+        if (lane + 64 * q < 1025) csumv[lane + 64 * q] = ho_enc(k, 9, lane + 64 * q) + z;
+      more = __builtin_amdgcn_s_memrealtime() - t0 < ticks;
+      if (lane == 0) csumv[1026] = more ? 1u : 0u;
+    }
+    __syncthreads();
+    for (unsigned c = 0; c < 4; ++c) check(csumv[tid + 256 * c], 9, tid + 256 * c, k);
+    check(csumv[1024], 9, 1024, k);
+    more = csumv[1026] != 0u;
+  }
+  if (nbad) { atomicAdd(bad, nbad); atomicAdd(bad + 1, nstale); }
+  if (tid == 0) atomicAdd(bad + 3, (unsigned long long)k);
+}
+}  // namespace urf
+extern "C" int urf_probe_lds_handoff(int device, int wgs, double ms, void *stream, unsigned long long *d_bad, unsigned *d_first, const unsigned long long *d_poll) {
+  URF_HIP(hipSetDevice(device));
+  hipLaunchKernelGGL(urf::lds_handoff_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (unsigned long long)(ms * 1e5), d_bad, d_first, d_poll);
+  URF_HIP(hipGetLastError());
+  return 0;
 }
 extern "C" int urf_probe_lds_watch(int device, int wgs, int lds_bytes, double ms, void *stream, unsigned long long *d_bad, unsigned *d_first) {
   URF_HIP(hipSetDevice(device));

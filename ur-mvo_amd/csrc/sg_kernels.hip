@@ -459,10 +459,16 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
 // GUARD (guarded fast mode): also the runner-up of every row / column; a pair is flagged (gflags[p] != 0) when a best
 // entry that can become a match -- at or above the matching threshold minus the margin gz (log domain) -- is closer than
 // gz to the threshold (bit 0) or closer than 2 gz to its runner-up (bit 1): decisions the exact mode could take differently.
-template <bool ROWS, bool GUARD>
+// RESID (every mode with a fast Sinkhorn; the COLUMN pass): the column marginal of the plan the decode is about to read --
+// sum_i exp(Z_ij) over the column's n0 rows and its dustbin entry.  An iteration ends with the column update v = log nu - LSE_i(C + u),
+// so this sum is 1 to rounding in every correct result, converged or not (the ROW marginals are not an invariant: after 100
+// iterations they still miss by up to 0.4 on the bench streams).  resid[p] = the largest |sum - 1| over the pair's columns: the
+// integrity word of the pair's Sinkhorn result (sg_api.hip, pm_check_resident) -- it catches a result whose last iteration, final
+// potentials or couplings were damaged, not a transient error of an earlier iteration that the later ones have absorbed.
+template <bool ROWS, bool GUARD, bool RESID>
 __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const float *M, const float *u, const float *v,
                                                      int *midx, float *mval, float *Zout, int *gflags, float gz,
-                                                     float log_thr) {
+                                                     float log_thr, float *resid) {
   const int p = blockIdx.y;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int R = ROWS ? n0 : n1, Cn = ROWS ? n1 : n0;
@@ -480,10 +486,18 @@ __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const fl
   // reference semantics (max_matrix): value starts at -FLT_MAX, index 0, strict '<'
   float best = -FLT_MAX, second = -FLT_MAX;
   int bi = 0;
+  float rsum = 0.0f;
   for (int c = lane; c < Cn; c += 64) {
     const float z = ROWS ? (((mr[c] + up[row]) + vp[c]) - norm) : (((mr[c] + up[c]) + vp[row]) - norm);
     if (best < z) { if (GUARD) second = best; best = z; bi = c; }
     else if (GUARD && second < z) second = z;
+    if (RESID) rsum = rsum + __expf(z);
+  }
+  if (RESID) {
+    if (lane == 0) rsum = rsum + __expf((ROWS ? ((mr[Cn] + up[row]) + vp[Cn]) : ((mr[Cn] + up[Cn]) + vp[row])) - norm);   // the dustbin entry
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) rsum = rsum + __shfl_xor(rsum, s, 64);
+    if (lane == 0 && resid) atomicMax((int *)(resid + p), __float_as_int(fabsf(rsum - 1.0f)));   // (non-negative floats order as ints)
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -536,7 +550,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
                                                       const int *mi1, double thresh, const float *kxy,
                                                       int *idx0, int *idx1, double *ms0,
                                                       double *ms1, DMatch *matches, float *pts0, float *pts1,
-                                                      int *nmatch) {
+                                                      int *nmatch, const float *resid, float resid_bound, int *err) {
   __shared__ int s_valid0[NP];
   __shared__ double s_ms0[NP];
   __shared__ int wsum[16];
@@ -582,6 +596,12 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
     pts1[((size_t)p * NP + pos) * 2 + 1] = k1[2 * my0 + 1];
   }
   if (i == 0) nmatch[p] = total;
+  // integrity of the pair's Sinkhorn result (argmax_kernel, RESID): above the bound (or not a number) the launch is reported
+  // like a give-up -- err[0] = 2 unless a give-up (1) is already there, err[2..3] = the pairs -- and the host redoes the tail
+  if (i == 0 && resid && !(resid[p] <= resid_bound)) {
+    atomicCAS(err, 0, 2);
+    atomicOr(err + 2 + (p >> 5), 1 << (p & 31));
+  }
 }
 
 // ----------------------------------------------------------------- guard calibration
@@ -656,18 +676,21 @@ int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1,
                   int *idx0, int *idx1, double *ms0, double *ms1, void *matches, float *pts0, float *pts1,
-                  int *nmatch, float *Zout, int *gflags, float gz, int P, hipStream_t st) {
+                  int *nmatch, float *Zout, int *gflags, float gz, float *resid, float resid_bound, int *err, int P, hipStream_t st) {
   const dim3 grid((NP + 1 + 3) / 4, P), block(256);
   const float log_thr = thresh > 0.0 ? (float)log(thresh) : -FLT_MAX;
   if (gflags) {
-    hipLaunchKernelGGL((argmax_kernel<true, true>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr);
-    hipLaunchKernelGGL((argmax_kernel<false, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr);
+    hipLaunchKernelGGL((argmax_kernel<true, true, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
+    hipLaunchKernelGGL((argmax_kernel<false, true, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid);
+  } else if (resid) {
+    hipLaunchKernelGGL((argmax_kernel<true, false, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
+    hipLaunchKernelGGL((argmax_kernel<false, false, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid);
   } else {
-    hipLaunchKernelGGL((argmax_kernel<true, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr);
-    hipLaunchKernelGGL((argmax_kernel<false, false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr);
+    hipLaunchKernelGGL((argmax_kernel<true, false, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
+    hipLaunchKernelGGL((argmax_kernel<false, false, false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, (float *)nullptr);
   }
   hipLaunchKernelGGL(decode_kernel, dim3(P), dim3(1024), 0, st, counts, mi0, mv0, mi1, thresh, kxy, idx0,
-                     idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch);
+                     idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch, (const float *)resid, resid_bound, err);
   URF_HIP(hipGetLastError());
   return 0;
 }

@@ -76,10 +76,33 @@ struct RsArgs {
 // where the readers' L1-bypassing agent-scope loads find it ~0.1 us later.  That is below the scope the memory model requires
 // between workgroups and relies on this chip's cache hierarchy: measured 0.48 vs 0.60 ms per 8-pair launch, 0.8 % of the
 // pipeline's throughput -- not worth leaving the model for, hence off by default.
+// diagnostic build (-DURF_RS_GID_TAG): a granule's tag also carries a hash of its own address, so a value that arrives from
+// ANOTHER granule of the same iteration (all of an iteration's granules share the plain tag) is taken for "not there yet" and
+// polled again instead of being consumed
+__device__ __forceinline__ unsigned rs_gh(const void *p) {
+#ifdef URF_RS_GID_TAG
+  return (unsigned)((unsigned long long)p >> 3) * 0x9E3779B1u;
+#else
+  (void)p;
+  return 0u;
+#endif
+}
 __device__ __forceinline__ void rs_store(u64 *p, unsigned tag, float v, bool near) {
+  tag ^= rs_gh(p);
   const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
   if (near) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The workgroup barrier of these kernels: every LDS operation of the wave has completed before it arrives.  __syncthreads() asks
+// for the same (a workgroup release fence), but the `s_waitcnt lgkmcnt(0)` of that fence is the compiler's to place -- and hipcc
+// (ROCm 7.2, gfx950) leaves it out at a barrier that heads a loop when the pending LDS write sits on the back edge: the other
+// waves then read the previous iteration's value whenever the write is still queued behind other workgroups' LDS traffic (the
+// un-root-caused "nondeterminism beside other kernels" of round 4).  Inline assembly is invisible to the
+// pass that drops the wait.  tools/isa_barrier_audit.py (a CPU test) checks every s_barrier of the library for this.
+__device__ __forceinline__ void rs_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 // Every lane of the wave with `active` set re-reads its own granule until all their tags equal `tag`.
@@ -91,7 +114,7 @@ __device__ __forceinline__ bool rs_wait(const u64 *p, bool active, unsigned tag,
     if (active) {
       const u64 x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       val = __uint_as_float((unsigned)x);
-      ok = (unsigned)(x >> 32) == tag;
+      ok = (unsigned)(x >> 32) == (tag ^ rs_gh(p));
     }
     if (__all(ok)) return true;
     if ((spins & 255u) == 0) {
@@ -134,7 +157,7 @@ __device__ __forceinline__ bool rs_sweep(const u64 *base, int count, unsigned ta
       if (g < count) {
         const float v = __uint_as_float((unsigned)x[k]);
         if (SUM) acc = acc + v; else dst[g] = v;
-        ok = ok && ((unsigned)(x[k] >> 32) == tag);
+        ok = ok && ((unsigned)(x[k] >> 32) == (tag ^ rs_gh((const u64 *)base + g)));
       }
     }
     sum = acc;
@@ -521,6 +544,20 @@ __device__ __forceinline__ float rs_rows32_sum(VAL val, int lane) {   // val(r) 
 }
 
 #ifdef URF_EXPERIMENTS   // the forms that SHARE their CUs (rounds 2 and 3): not reproducible run to run; experiments build only
+// diagnostic builds of the shared form: -DURF_RS_STRONG_BARRIER = every barrier with a full s_waitcnt (vmcnt too) in front and
+// wait states behind; -DURF_RS_READBACK = the polling wave reads one of the column sums it has just written back before the barrier
+// -DURF_RS_LGKM_BARRIER = the fix: the workgroup barrier with its LDS wait written out (rs_sync below) -- hipcc of ROCm 7.2 drops
+// the `s_waitcnt lgkmcnt(0)` of __syncthreads() at the loop-header barrier of these kernels (the pending write, misc[0] = b_dust,
+// sits on the back edge), so the other waves could read the previous iteration's value: the run-to-run differences of DESIGN.md
+// section 12.  Without the flag these forms keep the plain __syncthreads(): they are the reproducer of that fault.
+#if defined(URF_RS_STRONG_BARRIER)
+#define RS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); asm volatile("s_nop 7\n\ts_nop 7"); \
+                       __builtin_amdgcn_s_barrier(); asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#elif defined(URF_RS_LGKM_BARRIER)
+#define RS_SYNC() rs_sync()
+#else
+#define RS_SYNC() __syncthreads()
+#endif
 // MINW: waves per SIMD the register budget is cut for (3 -> 168 VGPRs, 4 -> 128, 1 -> no cut).  NC: columns per thread, 1024 / NC
 // threads: NC = 2 is the kernel described above; NC = 4 (URF_SINKHORN_REGS=3) is ONE wave per SIMD with 128 registers of plan,
 // which leaves the SIMD's other half of the register file to a second kernel's waves (an h2gemm workgroup needs 2 x 104).
@@ -602,7 +639,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       if (lane == 0) rowpart[wv][i] = m;
     }
   }
-  __syncthreads();
+  RS_SYNC();
   if (tid < RS_ROWS) {
     float m = rowpart[0][tid];
 #pragma unroll
@@ -611,7 +648,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
   }
 
   auto absorb = [&]() {
-    __syncthreads();                      // u0vec written, nobody still reads avec / pcvec
+    RS_SYNC();                      // u0vec written, nobody still reads avec / pcvec
 #pragma unroll
     for (int i = 0; i < RS_ROWS; ++i) {
       const double u0i = u0vec[i];
@@ -640,7 +677,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
     }
     Pdd = __expf((float)(((double)alpha + u0d) + v0d));
     bdust = 1.0f;
-    __syncthreads();
+    RS_SYNC();
   };
   absorb();
 
@@ -658,7 +695,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       const bool same = __all(lane >= RS_WG || ids == first);
       if (lane == 0) { misc[2] = same ? 1.0f : 0.0f; if (!alive) misc[1] = 1.0f; }
     }
-    __syncthreads();
+    RS_SYNC();
     if (misc[1] != 0.0f) return;
     near = misc[2] != 0.0f && a.allow_near != 0;
   }
@@ -668,7 +705,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
   for (int k = 1; k <= a.iters; ++k) {
     const unsigned tag = (a.salt << 12) | (unsigned)k;
     // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust); 32 wave sums, 8 partials per row through LDS
-    __syncthreads();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
+    RS_SYNC();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
     bdust = misc[0];
     RS_STAMP(0);
     {
@@ -680,7 +717,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       if (lane == 63) wsum[wv] = part;
     }
     RS_STAMP(1);
-    __syncthreads();
+    RS_SYNC();
     if (tid < RS_ROWS) {
       float r = rowpart[0][tid];
 #pragma unroll
@@ -695,7 +732,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
       rd = fma_rn(Pdd, bdust, rd);
       ad = mu_d / rd;
     }
-    __syncthreads();                      // avec written
+    RS_SYNC();                      // avec written
     RS_STAMP(2);
 #ifdef URF_EXPERIMENTS
     if (a.dbg && wv == 0) {
@@ -755,9 +792,12 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
         alive = rs_sweep<17, false>(xbc, 1025, tag, unused, csumv, lane, a.err, nullptr, RS_RMW(a));
       }
       if (!alive && lane == 0) misc[1] = 1.0f;
+#ifdef URF_RS_READBACK
+      if (alive) { const float rb = *(volatile float *)(csumv + lane); asm volatile("" :: "v"(rb)); }
+#endif
       RS_STAMP(5);
     }
-    __syncthreads();
+    RS_SYNC();
     RS_STAMP(6);
     if (misc[1] != 0.0f) return;
 #ifdef URF_EXPERIMENTS
@@ -782,7 +822,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
     // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
     if (k == next_absorb && k < a.iters) {
       next_absorb *= 2;
-      __syncthreads();                    // misc[0] written
+      RS_SYNC();                    // misc[0] written
       bdust = misc[0];
       if (tid < RS_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
       u0d = u0d + (double)__logf(ad);
@@ -794,7 +834,7 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
     }
   }
   // ---------------- u = u0 + log a, v = v0 + log b
-  __syncthreads();
+  RS_SYNC();
   bdust = misc[0];
   if (tid < RS_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
   if (w == 0) {
@@ -882,7 +922,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
+  rs_sync();
   if (tid < RW_ROWS) {
     float m = rowpart[0][tid];
 #pragma unroll
@@ -891,7 +931,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
   }
 
   auto absorb = [&]() {
-    __syncthreads();                      // u0vec written, nobody still reads avec / pcvec
+    rs_sync();                      // u0vec written, nobody still reads avec / pcvec
 #pragma unroll
     for (int ib = 0; ib < RW_ROWS; ib += 16) {   // sixteen rows of couplings in flight at a time
       float xs[16][NC];
@@ -919,7 +959,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     }
     Pdd = __expf((float)(((double)alpha + u0d) + v0d));
     bdust = 1.0f;
-    __syncthreads();
+    rs_sync();
   };
   absorb();
 
@@ -934,7 +974,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       const bool alive = rs_sweep<1, true>(xbc + 1056, RW_WG, tag0, ids, nullptr, lane, a.err);
       if (lane == 0 && !alive) misc[1] = 1.0f;
     }
-    __syncthreads();
+    rs_sync();
     if (misc[1] != 0.0f) return;
   }
 
@@ -942,7 +982,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
   for (int k = 1; k <= a.iters; ++k) {
     const unsigned tag = (a.salt << 12) | (unsigned)k;
     // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust); 2 x 32 wave sums, 8 partials per row through LDS
-    __syncthreads();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
+    rs_sync();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
     bdust = misc[0];
     {
       const float s0 = rs_rows32_sum([&](int r) { return fma_rn(P[0][r], bc[0], P[1][r] * bc[1]); }, lane);
@@ -954,7 +994,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       const float part = wave_sum_dpp_l63(fma_rn(pd[0], bc[0], pd[1] * bc[1]));   // dustbin row: sum_j pd_j b_j
       if (lane == 63) wsum[wv] = part;
     }
-    __syncthreads();
+    rs_sync();
     if (tid < RW_ROWS) {
       float r = rowpart[0][tid];
 #pragma unroll
@@ -969,7 +1009,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       rd = fma_rn(Pdd, bdust, rd);
       ad = mu_d / rd;
     }
-    __syncthreads();                      // avec written
+    rs_sync();                      // avec written
     // ---------------- column pass: partial sums over the own 64 rows, all in registers
     float creg[NC];
 #pragma unroll
@@ -1020,7 +1060,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       }
       if (!alive && lane == 0) misc[1] = 1.0f;
     }
-    __syncthreads();
+    rs_sync();
     if (misc[1] != 0.0f) return;
     float csum_dust = csumv[1024];
     // ---------------- b_j = nu / (sum_i a_i P_ij + a_dust pd_j)
@@ -1034,7 +1074,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
     if (k == next_absorb && k < a.iters) {
       next_absorb *= 2;
-      __syncthreads();                    // misc[0] written
+      rs_sync();                    // misc[0] written
       bdust = misc[0];
       if (tid < RW_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
       u0d = u0d + (double)__logf(ad);
@@ -1046,7 +1086,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     }
   }
   // ---------------- u = u0 + log a, v = v0 + log b
-  __syncthreads();
+  rs_sync();
   bdust = misc[0];
   if (tid < RW_ROWS && i0 + tid < n0) a.u[(size_t)p * RS_LDC + i0 + tid] = (float)(u0vec[tid] + (double)__logf(avec[tid]));
   if (w == 0) {
@@ -1087,7 +1127,12 @@ int sinkhorn_resident_enabled() {
 
 long long *g_rs_stamps = nullptr;   // set by urf_probe_sinkhorn_stamps
 
+#ifdef URF_EXPERIMENTS
 static std::atomic<int> g_rs_fault{0};   // urf_probe_sinkhorn_fault: that many launches report a give-up (tests of the recovery)
+extern std::atomic<int> g_rs_corrupt;    // urf_probe_sinkhorn_corrupt: that many launches get one column potential shifted afterwards
+extern float g_rs_corrupt_delta;
+__global__ void rs_corrupt_kernel(float *v, float delta) { if (threadIdx.x == 0) v[3] = v[3] + delta; }
+#endif
 
 // can this device hold a pair's 32 workgroups at all?  (no: the handle uses the streaming kernels, sg_api.hip)
 int sinkhorn_resident_supported(int device) {
@@ -1182,7 +1227,9 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
       const char *e = urf::exp_env("URF_SINKHORN_LDS_PAD"); lpad = e ? atol(e) : 0;
       if (lpad > 0) URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_regs_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
-    if (regs == 4) hipLaunchKernelGGL(sinkhorn_wide_kernel, dim3(RW_WG * a.npairs), dim3(RW_T), kWidePadBytes, st, a);
+    static long wpad = -1;   // what-if: the wide form WITHOUT its CU to itself (URF_SINKHORN_WIDE_PAD=0)
+    if (wpad < 0) { const char *e = urf::exp_env("URF_SINKHORN_WIDE_PAD"); wpad = e ? atol(e) : (long)kWidePadBytes; }
+    if (regs == 4) hipLaunchKernelGGL(sinkhorn_wide_kernel, dim3(RW_WG * a.npairs), dim3(RW_T), (size_t)wpad, st, a);
     else if (regs == 3) hipLaunchKernelGGL((sinkhorn_regs_kernel<1, 4>), dim3(RS_WG * a.npairs), dim3(256), (size_t)lpad, st, a);
     else if (regs == 2) hipLaunchKernelGGL((sinkhorn_regs_kernel<4, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
     else if (regs) hipLaunchKernelGGL((sinkhorn_regs_kernel<3, 2>), dim3(RS_WG * a.npairs), dim3(RG_T), 0, st, a);
@@ -1194,10 +1241,17 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     URF_HIP(hipGetLastError());
     URF_HIP(hipEventRecord(d.last, st));
   }
+#ifdef URF_EXPERIMENTS
   if (g_rs_fault.load() > 0) {
     g_rs_fault.fetch_sub(1);
     URF_HIP(hipMemsetAsync(err, 1, sizeof(int), st));
   }
+  if (g_rs_corrupt.load() > 0) {
+    g_rs_corrupt.fetch_sub(1);
+    hipLaunchKernelGGL(rs_corrupt_kernel, dim3(1), dim3(64), 0, st, v, g_rs_corrupt_delta);
+    URF_HIP(hipGetLastError());
+  }
+#endif
   return 0;
 }
 
@@ -1208,6 +1262,7 @@ extern "C" int urf_probe_rs_verify(unsigned long long *out) {
 #endif
 }  // namespace urf
 
+#ifdef URF_EXPERIMENTS   // test hooks and diagnostics: experiments build only (include/urf.h)
 // diagnostic: the next resident launches record s_memtime stamps (8 per iteration, workgroup 0) into a device
 // buffer; enable = 0 copies the stamps of `iters` iterations to `out` and switches recording off again
 extern "C" int urf_probe_sinkhorn_stamps(int enable, int iters, long long *out) {
@@ -1234,3 +1289,13 @@ extern "C" int urf_probe_sinkhorn_fault(int launches) {
   urf::g_rs_fault.store(launches < 0 ? 0 : launches);
   return 0;
 }
+
+// test hook: the next `launches` resident launches get `delta` added to one column potential of their first pair after the
+// iterations -- a damaged last iteration; the integrity check of the decode (column marginals) must catch it
+namespace urf { std::atomic<int> g_rs_corrupt{0}; float g_rs_corrupt_delta = 0.0f; }
+extern "C" int urf_probe_sinkhorn_corrupt(int launches, float delta) {
+  urf::g_rs_corrupt_delta = delta;
+  urf::g_rs_corrupt.store(launches < 0 ? 0 : launches);
+  return 0;
+}
+#endif

@@ -181,7 +181,7 @@ PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
                  ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0,
-                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0):
+                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0, sinkhorn_residual_bound=0.0, calibrate_pairs=0):
         """outlier stage: all-zero = the reference call's parameters (3 px, confidence 0.99, src/point_matching.cc:50);
         ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count.
         precision: 0 exact, 1 fast, 2 guarded fast (flagged pairs reported), 3 strict parity (flagged pairs redone in the
@@ -190,7 +190,8 @@ class _PM:
         self.cfg = cfg
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
                            max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision,
-                           ransac_threshold_px, ransac_confidence, redo_flagged_pairs, guard_margin, outlier_stage)
+                           ransac_threshold_px, ransac_confidence, redo_flagged_pairs, guard_margin, outlier_stage,
+                           sinkhorn_residual_bound, calibrate_pairs)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 
@@ -206,6 +207,18 @@ class _PM:
     def sinkhorn_fallbacks(self):
         """how often the resident Sinkhorn launch of this handle gave up and the batch was redone with the streaming kernels"""
         return int(_lib.lib().urf_pm_sinkhorn_fallbacks(self._h))
+
+    def sinkhorn_integrity(self):
+        """integrity check of the fast Sinkhorn: dict(pairs redone, batches, bound, pairs processed) since build()"""
+        v = (C.c_double * 4)()
+        check(_lib.lib().urf_pm_sinkhorn_integrity(self._h, v, 4), "urf_pm_sinkhorn_integrity")
+        return dict(pairs=int(v[0]), events=int(v[1]), bound=float(v[2]), seen=int(v[3]))
+
+    def sinkhorn_residuals(self, P=1):
+        """largest |column marginal - 1| of the plan the decode read, per pair of the batch handed out last"""
+        f = (C.c_float * P)()
+        check(_lib.lib().urf_pm_sinkhorn_residuals(self._h, f, P), "urf_pm_sinkhorn_residuals")
+        return [float(f[p]) for p in range(P)]
 
     def near_tie_reruns(self):
         """guarded fast mode: dict(redone, pairs, threshold, runner_up) since build()"""
@@ -525,6 +538,10 @@ class FrameStream:
         if want_features:
             return K[:n.value].copy(), out, [feat[j, :K[j]].copy() for j in range(n.value)]
         return K[:n.value].copy(), out
+
+    def ready(self):
+        """True when collect() would return without waiting for the GPU"""
+        return check(_lib.lib().urf_fe_ready(self._h), "urf_fe_ready") == 1
 
     def in_flight(self):
         return _lib.lib().urf_fe_in_flight(self._h)
