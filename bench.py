@@ -152,6 +152,67 @@ def stream_run(U, spb, sgb, dev, device_index, prec, Hh, Ww, batch, steps, repea
     return (out, kept) if keep else out
 
 
+def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, steps, repeats, warmup=5, kept_ref=None):
+    """The C++ caller a maintainer binds (urf_fe_submit / urf_fe_collect, integration/tracking.patch; src/tracking.cc:338-377):
+    HOST u8 frames in (the copy to pinned memory and the PCIe transfer are inside the timed region), match lists out, the
+    pipelined loop of ur-mvo_amd/csrc/fe_api.hip -- no Python in the data path but the two ctypes calls per batch.
+    kept_ref: {batch: lists} of the headline run over the same stream: every list this run collects must equal it."""
+    F, synth = U.frontend, U.synth
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=MAX_KP), F.SuperGlueConfig(image_width=640, image_height=512), batch=batch,
+                       max_height=Hh, max_width=Ww, device=device_index, precision=prec, matchers=2)
+    assert fs.build(spb, sgb), U._lib.lib().urf_last_error()
+    NB_ = 5
+    fr = np.stack(synth.shift_stream(100, NB_ * batch, Hh, Ww))
+    depth = 2 + 2                        # matchers + 2 batches stay in flight behind a submit (include/urf.h)
+    got = {}
+    nsub = [0]
+
+    def pump(n, keep):
+        for _ in range(n):
+            k = nsub[0] % NB_
+            fs.submit(fr[k * batch:(k + 1) * batch])
+            nsub[0] += 1
+            while fs.in_flight() > depth:
+                K_, m_ = fs.collect()
+                if keep is not None:
+                    keep.append(m_)
+
+    def drain(keep):
+        while fs.in_flight():
+            K_, m_ = fs.collect()
+            if keep is not None:
+                keep.append(m_)
+
+    pump(warmup, None)
+    drain(None)
+    regions, lists = [], []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        pump(steps, lists)
+        drain(lists)
+        regions.append(time.perf_counter() - t0)
+    dt = float(np.median(regions))
+    out = {"frames_per_s": round(steps * batch / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": batch, "steps": steps,
+           "regions_frames_per_s": [round(steps * batch / r, 2) for r in regions],
+           "what": "urf_fe_submit (host u8 frames: pinned staging + PCIe inside the timed region) / urf_fe_collect (host DMatch lists), "
+                   "two matcher handles, matchers + 2 batches in flight"}
+    if kept_ref is not None:
+        # batch index of lists[i] in the stream: warm-up batches came first; the stream is periodic in NB_ batches (the first
+        # frame of a batch is matched against the last frame of the previous one, so from batch 1 on the lists repeat)
+        same = tot = 0
+        for i, m_ in enumerate(lists):
+            b = warmup + i
+            refs = [kept_ref[r] for r in kept_ref if r % NB_ == b % NB_ and r >= 1]
+            if not refs or b < 1:
+                continue
+            for a_, x_ in zip(m_, refs[0]):
+                tot += 1
+                same += int(len(a_) == len(x_) and np.array_equal(a_["queryIdx"], x_["queryIdx"]) and np.array_equal(a_["trainIdx"], x_["trainIdx"]))
+        out["pairs_with_the_headline_runs_index_list"] = f"{same}/{tot}"
+    del fs
+    return out
+
+
 def latency_runs(U, spb, sgb, device_index, prec, Hh, Ww, repeats=3):
     """BASELINE configs[1] (SuperPoint only, batch 1, <= 1024 keypoints) and the per-call path of the UNPATCHED reference caller
     (Tracking::ExtractFeatureAndMatch, src/tracking.cc:338-377: SuperPoint::infer on one frame, then MatchingPoints on host
@@ -525,6 +586,8 @@ def main():
                     secondary[name_] = stream_run(U, spb, sgb, dev, local_rank, prec_, 480, 640, 8, 30, 3)
             if PREC != 3:
                 secondary["strict_parity_640x480_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 480, 640, 8, 30, 3)
+            secondary["native_frame_stream_strict_640x480"] = native_frame_stream_run(U, spb, sgb, local_rank, 3, 480, 640, 8, 30, 3,
+                                                                                         kept_ref=kept if PREC == 3 else None)
             secondary["strict_parity_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 8, 20, 3)
             secondary["strict_parity_1241x376_batch4"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 4, 20, 3)
             secondary["guarded_fast_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 2, 376, 1241, 8, 20, 3)

@@ -379,6 +379,10 @@ int urf_pm_near_tie_flags(urf_pm *h, int *flags, int P);
  * if it is smaller (never narrows).  out[0] = the measured difference, out[1] = the margin in use after the call (out may be
  * null).  Synchronous; allocates and frees a scratch copy of the P matrices. */
 int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1, double *out);
+/* the guard of a precision-2 / -3 handle: out[0] = the margin in use (log domain), out[1] = the largest fast-vs-exact difference
+ * the calibrations (automatic or explicit) have measured, out[2] = pairs the automatic calibration still wants to measure,
+ * out[3] = 1 when the measured error exceeded the cap and a strict handle redoes every pair in the exact mode (n <= 4 values) */
+int urf_pm_guard_state(urf_pm *h, double *out, int n);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
 /* HIP-event timing of the pipeline stages on the handle's own stream. */

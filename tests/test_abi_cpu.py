@@ -320,10 +320,9 @@ def test_register_and_lds_budgets_keep_the_pipeline_coresident(tmp_path):
     assert attn[0][1] == 0
     conv_lds = 2 * (2 * 2 * 64 * 64 + 2 * 10 * 18 * 64) + 12 * 20 * 4   # launch_h2conv's dynamic LDS, fused variant
     assert attn[0][2] + conv_lds <= 160 * 1024
-    # the resident Sinkhorn of the product (sinkhorn_wide_kernel: 512 threads, 64 rows per workgroup) must have its CU to itself --
-    # with other kernels' waves on the CU the register-resident forms were not reproducible run to run.  It
-    # gets there by asking for dynamic LDS it never touches: what is left on the CU has to be less than the smallest tile of the
-    # path (the one-tap exact convolution: 54 KB); and the kernel has to fit two waves per SIMD with (next to) no scratch.
+    # the resident Sinkhorn of the product (sinkhorn_wide_kernel: 512 threads, 64 rows per workgroup): two waves per SIMD with
+    # (next to) no scratch, a few KB of LDS (round 4's 110 KB of padding that kept the CU to itself is gone with the fault it was
+    # there to avoid: DESIGN.md section 12), and no shared form in the product build
     out = tmp_path / "sinkhorn_resident.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
                     os.path.join(ROOT, "ur-mvo_amd", "csrc", "sinkhorn_resident.hip"), "-o", str(out)], check=True, capture_output=True)
@@ -332,10 +331,7 @@ def test_register_and_lds_budgets_keep_the_pipeline_coresident(tmp_path):
         usage[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
     wide = [v for k, v in usage.items() if "sinkhorn_wide_kernel" in k]
     assert len(wide) == 1, usage
-    src = open(os.path.join(ROOT, "ur-mvo_amd", "csrc", "sinkhorn_resident.hip")).read()
-    pad = int(re.search(r"kWidePadBytes = (\d+) \* 1024", src).group(1)) * 1024
-    assert wide[0][0] <= 256 and wide[0][1] <= 512, wide
-    assert 160 * 1024 - (wide[0][2] + pad) < 54 * 1024, (wide, pad)
+    assert wide[0][0] <= 256 and wide[0][1] <= 512 and wide[0][2] <= 16 * 1024, wide
     assert not any("sinkhorn_regs_kernel" in k or "sinkhorn_resident_kernel" in k for k in usage), "the forms that share their CUs are experiments-build only"
 
 

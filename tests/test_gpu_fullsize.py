@@ -708,6 +708,40 @@ def test_sinkhorn_integrity_check_catches_a_shifted_potential(Uexp, sg_blob):
     assert pm.sinkhorn_integrity()["pairs"] == 0 and pm.sinkhorn_residuals(1)[0] > 1e-3
 
 
+def test_strict_handle_calibrates_itself_on_other_weights(U, F):
+    """the strict margin's built-in constant (2.2e-4) was measured on this repo's default synthetic weights; a deployment's
+    trained weights have other activation ranges.  A strict handle measures itself on the first pairs it sees
+    (urf_sg_config.calibrate_pairs, default 8): with a second weight set whose residual-stream gain is three times the
+    default's the split-f16 error grows, the margin follows it, and every list still equals the exact mode's index for
+    index.  With the calibration switched off the same handle keeps the built-in margin (what round 4 shipped)."""
+    sgw = U.synth.pack_sg(U.synth.sg_weights(1, gnn_gain=1.5))
+    rng = np.random.default_rng(80)
+    pairs = []
+    for n0, n1, m in ((1000, 1000, 600), (700, 900, 400), (1024, 1024, 800), (320, 500, 200), (1000, 640, 500), (64, 1000, 40),
+                      (1000, 1000, 300), (900, 901, 700), (1000, 999, 650), (512, 512, 256), (1024, 700, 600), (800, 1000, 450)):
+        f0 = make_features(rng, n0)
+        pairs.append((f0, make_features(rng, n1, planted_from=f0, m=m)))
+    ex = F.PointMatching(F.SuperGlueConfig(), precision=0)
+    st = F.PointMatching(F.SuperGlueConfig(), precision=3)
+    off = F.PointMatching(F.SuperGlueConfig(), precision=3, calibrate_pairs=-1)
+    assert ex.build(sgw) and st.build(sgw) and off.build(sgw)
+    assert st.guard_state()["pairs_left"] == 8 and off.guard_state()["pairs_left"] == 0
+    redone = 0
+    for i, (f0, f1) in enumerate(pairs):
+        want = ex.MatchingPoints(f0, f1, True)
+        got = st.MatchingPoints(f0, f1, True)
+        assert [(q, t) for q, t, _ in got] == [(q, t) for q, t, _ in want], i
+        assert not want or max(abs(a[2] - b[2]) for a, b in zip(got, want)) < 1e-3
+        g = st.guard_state()
+        assert g["pairs_left"] == max(0, 8 - (i + 1))
+    g = st.guard_state()
+    assert g["measured"] > 0.0 and g["margin"] >= max(2.2e-4, 1.6 * g["measured"]) - 1e-9 and not g["redo_all"]
+    assert abs(off.guard_state()["margin"] - 2.2e-4) < 1e-9 and off.guard_state()["measured"] == 0.0
+    redone = st.near_tie_reruns()["redone"]
+    assert st.near_tie_reruns()["pairs"] == len(pairs)              # the calibration passes are not counted as pairs
+    print(f"calibrated margin {g['margin']:.3g} (measured {g['measured']:.3g} on 8 pairs), {redone} of {len(pairs)} pairs redone")
+
+
 def test_resident_sinkhorn_give_up_is_not_sticky(Uexp, sg_blob, monkeypatch):
     """after a give-up the handle stays on the streaming kernels for a bounded number of batches (64, doubling per give-up;
     2 here through the test knob) and then goes back to the resident kernel: a later fault is seen again -- it would not

@@ -224,6 +224,114 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
   GM_STAMP(4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the same tile with the activations THREE chunks deep and the weights two (asymmetric ring, 80 KB: still two workgroups
+// per CU).  The two-stage loop above gives a chunk's DMA exactly one chunk of MFMAs to land (vmcnt(0) at the top of every chunk);
+// the weights come out of L2 in that time, the activations -- written by the previous launch on other XCDs, i.e. Infinity-Cache
+// or HBM latency -- do not (profiles/r04_mfma_roof.txt: this loop shape 0.80 PF of MFMA issue with activations from HBM, 1.4 with
+// every source L2-resident).  Here chunk ch + 2 of the activations and chunk ch + 1 of the weights are in flight while chunk ch
+// computes.  Per chunk a wave issues A(ch + 1) then B(ch + 2), two instructions each; at the top of chunk ch the operations still
+// counted are, oldest first, B(ch) | A(ch) B(ch + 1) -- so `s_waitcnt vmcnt(2)` retires exactly what chunk ch reads (LDS-DMA, loads
+// and stores retire in issue order), and the raw s_barrier behind it makes every wave's share visible; nothing else orders a ds_read
+// behind an LDS-DMA.  (No __syncthreads() in the loop: its fence drains vmcnt to 0 while an LDS-DMA is pending.)  WAR: stage
+// A[(ch + 1) & 1] and stage B[(ch + 2) % 3] were last read in chunk ch - 1, whose fragment reads every wave has consumed (its MFMAs
+// are issued) before it arrives at chunk ch's barrier.
+// LDS: [A stage 0 | A stage 1][Ah | Al][128][32]  then  [B stage 0 | 1 | 2][Bh | Bl][128][32]
+constexpr int G3_LDS_HALFS = 2 * 2 * GP + 3 * 2 * GP;
+template <bool TOUT, int R>
+__device__ __forceinline__ void h2gemm_ring_tile(const H2Args &a, _Float16 *hsm, int b, int cout_base, int row0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int wc = wave >> 2, wr = wave & 3;
+  f32x4 acc[4][2];
+  h2_init_acc<TOUT>(a, acc, cout_base, wc, px, g);
+  _Float16 *const sA = hsm, *const sB = hsm + 2 * 2 * GP;
+  const int drow = wave * 16 + (lane >> 2);
+  const int dkg = (lane & 3) ^ ((-(drow >> 2)) & 3);
+  // every wave issues its two activation DMAs in every chunk (the counted wait below depends on it): rows past the end of the
+  // image or of a 64-row tile read the image's last valid row instead -- their accumulators are never stored
+  const bool has_b = R == 2 || wave < 4;           // 64-row tile: waves 4-7 have no activation rows (wave-uniform)
+  int srow = row0 + drow;
+  if (srow > a.rows - 1) srow = a.rows - 1;
+  const _Float16 *srcA_h = a.wh + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
+  const _Float16 *srcA_l = a.wl + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
+  const size_t xoff = (size_t)b * a.x_bstride + (size_t)srow * a.ldx + 8 * dkg;
+  const size_t x2off = a.x2h ? (size_t)b * a.x2_bstride + (size_t)srow * a.ldx2 + 8 * dkg : 0;
+  auto issueA = [&](int ch) {
+    _Float16 *base = sA + (ch & 1) * 2 * GP + wave * 16 * BK;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(srcA_h + ch * BK), (lds_void *)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void *)(srcA_l + ch * BK), (lds_void *)(base + GP), 16, 0, 0);
+  };
+  auto issueB = [&](int ch) {
+    if (!has_b) return;
+    const int c0 = ch * BK;
+    _Float16 *base = sB + (ch % 3) * 2 * GP + wave * 16 * BK;
+    const bool second = a.x2h && c0 >= a.Cin1;
+    const _Float16 *xh = second ? a.x2h + x2off + (c0 - a.Cin1) : a.xh + xoff + c0;
+    const _Float16 *xl = second ? a.x2l + x2off + (c0 - a.Cin1) : a.xl + xoff + c0;
+    __builtin_amdgcn_global_load_lds((gbl_void *)xh, (lds_void *)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void *)xl, (lds_void *)(base + GP), 16, 0, 0);
+  };
+  const int swz = 8 * (g ^ ((-(px >> 2)) & 3));
+  const int aoff = (wc * 64 + px) * BK + swz;
+  const int boff = (wr * 16 * R + px) * BK + swz;
+  const int nchunks = a.Cin / BK;                  // >= 2 (Cin % 64 == 0)
+  // prologue, in the loop's order: B(0) | A(0) B(1)
+  issueB(0);
+  issueA(0);
+  issueB(1);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // what chunk ch reads has landed: everything but the youngest activation chunk (two instructions; none for a wave without rows)
+    if (ch + 1 < nchunks && has_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < nchunks) issueA(ch + 1);
+    if (ch + 2 < nchunks) issueB(ch + 2);
+    const _Float16 *stA = sA + (ch & 1) * 2 * GP, *stB = sB + (ch % 3) * 2 * GP;
+    f16x8 ah[4], al[4], bh[R], bl[R];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ah[m] = *(const f16x8 *)(stA + aoff + m * 16 * BK);
+      al[m] = *(const f16x8 *)(stA + GP + aoff + m * 16 * BK);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bh[r] = *(const f16x8 *)(stB + boff + r * 16 * BK);
+      bl[r] = *(const f16x8 *)(stB + GP + boff + r * 16 * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (TOUT) {  // D[row = token][col = cout]
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[r], al[m], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[r], ah[m], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[r], ah[m], acc[m][r], 0, 0, 0);
+        } else {     // D[row = cout][col = token]
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[r], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[r], acc[m][r], 0, 0, 0);
+          acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
+        }
+      }
+  }
+  h2_epilogue<TOUT, R>(a, acc, b, cout_base, row0, wc, wr, px, g);
+}
+
+// MODE 0: token-major outputs, 1: transposed outputs, 2: both in one launch, 4: 64-row tiles (token-major)
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) h2gemm_ring_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];
+  const int b = blockIdx.z;
+  const int cout_base = blockIdx.y * 128, row0 = blockIdx.x * (MODE == 4 ? 64 : 128);
+  if (a.counts && row0 >= a.counts[b]) return;
+  if (MODE == 4) h2gemm_ring_tile<false, 1>(a, hsm, b, cout_base, row0);
+  else if (MODE == 0) h2gemm_ring_tile<false, 2>(a, hsm, b, cout_base, row0);
+  else if (MODE == 1) h2gemm_ring_tile<true, 2>(a, hsm, b, cout_base, row0);
+  else if ((int)blockIdx.y * 128 >= a.t_from) h2gemm_ring_tile<true, 2>(a, hsm, b, cout_base, row0);
+  else h2gemm_ring_tile<false, 2>(a, hsm, b, cout_base, row0);
+}
+
 template <bool TOUT>
 __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
   const int b = blockIdx.z;
@@ -401,14 +509,35 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
 #ifdef URF_EXPERIMENTS
   if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
     const char *e = urf::exp_env("URF_H2GEMM_VARIANT");
-    g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+    g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
   }
   const int variant = g_h2gemm_variant;
 #else
-  const int variant = 2;         // the product carries the LDS-DMA kernel only
+  const int variant = 3;         // the product carries the LDS-DMA kernels only: 3 = the asymmetric ring (round 5), 2 = two stages (round 2)
 #endif
-  URF_CHECK(a.t_from == 0 || (variant == 2 && (a.t_from % 128) == 0 && a.ohT),
+  URF_CHECK(a.t_from == 0 || (variant >= 2 && (a.t_from % 128) == 0 && a.ohT),
             "h2gemm: the dual epilogue needs the LDS-DMA kernel and a 128-aligned split");
+  if (variant == 3) {
+    const size_t lds = sizeof(_Float16) * G3_LDS_HALFS;   // 80 KB: two workgroups per CU
+    static DeviceOnce attr3;
+    if (attr3.need()) {
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      URF_HIP(hipFuncSetAttribute((const void *)h2gemm_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr3.mark();
+    }
+    H2Args b3 = a;
+    b3.xflags = g_h2gemm_xflags;
+    const dim3 grid((a.rows + 127) / 128, a.Cout / 128, batch);
+    if (!a.ohT && a.Cout <= 256)
+      hipLaunchKernelGGL(h2gemm_ring_kernel<4>, dim3((a.rows + 63) / 64, a.Cout / 128, batch), dim3(512), lds, st, b3);
+    else if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_ring_kernel<2>), grid, dim3(512), lds, st, b3);
+    else if (a.ohT) hipLaunchKernelGGL((h2gemm_ring_kernel<1>), grid, dim3(512), lds, st, b3);
+    else hipLaunchKernelGGL((h2gemm_ring_kernel<0>), grid, dim3(512), lds, st, b3);
+    URF_HIP(hipGetLastError());
+    return 0;
+  }
   if (variant == 2) {
     // 64 KiB: two stages of four planes (+ URF_H2GEMM_LDS_PAD bytes: occupancy experiments -- a padded workgroup keeps
     // its CU to itself and leaves registers / LDS for another stream's kernel)

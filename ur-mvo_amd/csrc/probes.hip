@@ -428,6 +428,14 @@ extern "C" int urf_probe_lds_handoff(int device, int wgs, double ms, void *strea
   URF_HIP(hipGetLastError());
   return 0;
 }
+// the dropped-wait reproducer at run time (tools/repro/dropped_lds_wait.hip, tools/gpu_back_edge_repro.py)
+#include "../../tools/repro/dropped_lds_wait.hip"
+extern "C" int urf_probe_back_edge(int fixed, int wgs, int iters, const float *d_in, float *d_out, void *stream) {
+  if (fixed) hipLaunchKernelGGL(back_edge_kernel<true>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, d_out, d_in, iters);
+  else hipLaunchKernelGGL(back_edge_kernel<false>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, d_out, d_in, iters);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
 extern "C" int urf_probe_lds_watch(int device, int wgs, int lds_bytes, double ms, void *stream, unsigned long long *d_bad, unsigned *d_first) {
   URF_HIP(hipSetDevice(device));
   URF_HIP(hipFuncSetAttribute((const void *)lds_watch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

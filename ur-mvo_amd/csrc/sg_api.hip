@@ -915,7 +915,7 @@ static int pm_check_resident(urf_pm *h) {
   URF_HIP(hipMemsetAsync(h->rs_err, 0, 4 * sizeof(int), h->st));
   URF_CHECK(h->last_P >= 1, "the fast Sinkhorn reported a fault and there is no batch to redo");
   const bool was_on = h->rs_on;
-  if (what == 1) {
+  if (what != 2) {   // 1 (or anything else the word may hold): a launch gave up
     h->rs_fallbacks += 1;
     h->rs_backoff = h->rs_backoff_next;
     h->rs_backoff_next = h->rs_backoff_next < 4096 ? h->rs_backoff_next * 2 : 4096;
@@ -938,7 +938,7 @@ static int pm_check_resident(urf_pm *h) {
   }
   h->rs_on = false;
   const int rc = pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast);
-  if (what != 1) h->rs_on = was_on;
+  if (what == 2) h->rs_on = was_on;
   if (rc) return -1;
   URF_HIP(hipStreamSynchronize(h->st));   // (the redone tail has new guard words: pm_guard_redo reads them next)
   if (h->h_rs_err[0] == 2) {
@@ -1219,6 +1219,13 @@ extern "C" int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n)
   v[1] = h->pairs_seen;
   v[4] = h->pairs_flagged;
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 0;
+}
+
+extern "C" int urf_pm_guard_state(urf_pm *h, double *out, int n) {
+  URF_CHECK(h && h->built && out && n >= 1, "urf_pm_guard_state: bad argument");
+  const double v[4] = {(double)h->g_z, (double)h->calib_worst, (double)h->calib_left, h->redo_all ? 1.0 : 0.0};
+  for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
   return 0;
 }
 

@@ -855,11 +855,12 @@ __global__ void __launch_bounds__(1024 / NC, MINW) sinkhorn_regs_kernel(RsArgs a
 // VGPRs of plan; two waves per SIMD, so 256 registers per thread are there), SIXTEEN workgroups per pair -- every pair of a batch
 // of eight in ONE launch on 128 CUs.  Same recurrence and the same two-hop exchange as above (16 reducers of 64 columns: a
 // reducer's 1024 hop-1 granules are [source][column], so lane l of the sweeping wave sums column l over the sources in order, no
-// cross-lane step).  The launch asks for dynamic LDS it never touches so that nothing with a tile in LDS fits beside a workgroup:
-// the CU is the workgroup's alone, which is what makes the resident Sinkhorn reproducible run to run -- at
-// half the CU-time of the LDS-resident form's two half-chip launches.
+// cross-lane step).  Round 4 launched it with 110 KB of untouched dynamic LDS so that no other kernel's workgroup would share its CU:
+// the shared forms were not reproducible run to run and nobody knew why.  Round 5 found why -- a barrier the compiler emitted
+// without its LDS wait (rs_sync above) -- and this kernel never had that barrier (tools/isa_barrier_audit.py); the padding is gone
+// (same throughput with and without, 1104 frames/s strict, and 3000-step soaks clean either way: DESIGN.md section 12).
 constexpr int RW_ROWS = 64, RW_WG = 16, RW_T = 512, RW_NWV = 8, RW_NC = 2;
-constexpr size_t kWidePadBytes = 110 * 1024;   // untouched dynamic LDS: with the 8 KB the kernel uses, 42 KB are left on the CU -- less than any tile
+constexpr size_t kWidePadBytes = 0;            // (experiments build: URF_SINKHORN_WIDE_PAD=bytes brings round 4's padding back for A/B runs)
 __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
   constexpr int NC = RW_NC, T = RW_T;
   __shared__ __attribute__((aligned(16))) float avec[RW_ROWS];
@@ -1159,7 +1160,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
 #ifdef URF_EXPERIMENTS
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-    URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePadBytes));
+    URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }
@@ -1244,7 +1245,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
 #ifdef URF_EXPERIMENTS
   if (g_rs_fault.load() > 0) {
     g_rs_fault.fetch_sub(1);
-    URF_HIP(hipMemsetAsync(err, 1, sizeof(int), st));
+    URF_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, st));    // err[0] = 1: "a launch gave up"
   }
   if (g_rs_corrupt.load() > 0) {
     g_rs_corrupt.fetch_sub(1);

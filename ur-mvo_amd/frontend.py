@@ -236,6 +236,12 @@ class _PM:
         check(_lib.lib().urf_pm_calibrate_guard(self._h, P, a0, a1, out), "urf_pm_calibrate_guard")
         return dict(z_difference=out[0], margin=out[1])
 
+    def guard_state(self):
+        """dict(margin in use, largest calibrated fast-vs-exact difference, pairs the automatic calibration still wants, redo_all)"""
+        v = (C.c_double * 4)()
+        check(_lib.lib().urf_pm_guard_state(self._h, v, 4), "urf_pm_guard_state")
+        return dict(margin=float(v[0]), measured=float(v[1]), pairs_left=int(v[2]), redo_all=bool(v[3]))
+
     def near_tie_flags(self, P=1):
         """guard words of the pairs of the batch handed out last (0 = the pair's match set is the exact pipeline's)"""
         f = (C.c_int * P)()
