@@ -163,7 +163,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
     assert fs.build(spb, sgb), U._lib.lib().urf_last_error()
     NB_ = 5
     fr = np.stack(synth.shift_stream(100, NB_ * batch, Hh, Ww))
-    depth = 2 + 2                        # matchers + 2 batches stay in flight behind a submit (include/urf.h)
+    depth = 2 + 3                        # matchers + 3 batches stay in flight behind a submit (include/urf.h)
     got = {}
     nsub = [0]
 
@@ -172,7 +172,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
             k = nsub[0] % NB_
             fs.submit(fr[k * batch:(k + 1) * batch])
             nsub[0] += 1
-            while fs.in_flight() > depth:
+            while fs.in_flight() > depth or (fs.in_flight() and fs.ready()):
                 K_, m_ = fs.collect()
                 if keep is not None:
                     keep.append(m_)
@@ -195,7 +195,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
     out = {"frames_per_s": round(steps * batch / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": batch, "steps": steps,
            "regions_frames_per_s": [round(steps * batch / r, 2) for r in regions],
            "what": "urf_fe_submit (host u8 frames: pinned staging + PCIe inside the timed region) / urf_fe_collect (host DMatch lists), "
-                   "two matcher handles, matchers + 2 batches in flight"}
+                   "two matcher handles, matchers + 3 batches in flight, batches handed out as soon as they are final"}
     if kept_ref is not None:
         # batch index of lists[i] in the stream: warm-up batches came first; the stream is periodic in NB_ batches (the first
         # frame of a batch is matched against the last frame of the previous one, so from batch 1 on the lists repeat)
@@ -586,8 +586,9 @@ def main():
                     secondary[name_] = stream_run(U, spb, sgb, dev, local_rank, prec_, 480, 640, 8, 30, 3)
             if PREC != 3:
                 secondary["strict_parity_640x480_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 480, 640, 8, 30, 3)
-            secondary["native_frame_stream_strict_640x480"] = native_frame_stream_run(U, spb, sgb, local_rank, 3, 480, 640, 8, 30, 3,
+            secondary["native_frame_stream_strict_640x480"] = native_frame_stream_run(U, spb, sgb, local_rank, 3, 480, 640, 8, args.steps, 3,
                                                                                          kept_ref=kept if PREC == 3 else None)
+            # (timed regions as long as the headline's: a region ends with a drain of the pipeline, 2 - 3 steps of latency)
             secondary["strict_parity_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 8, 20, 3)
             secondary["strict_parity_1241x376_batch4"] = stream_run(U, spb, sgb, dev, local_rank, 3, 376, 1241, 4, 20, 3)
             secondary["guarded_fast_1241x376_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 2, 376, 1241, 8, 20, 3)

@@ -262,6 +262,9 @@ int urf_pm_share_stream(urf_pm *h, urf_sp *sp);
  * beside the Sinkhorn iterations (cache-bandwidth-bound). */
 int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp);
 int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h);
+/* the matcher's stream waits for an event the caller has recorded (hipEvent_t) -- e.g. right behind ONE SuperPoint call on
+ * urf_sp_result_stream(), when later calls have been enqueued behind it already and urf_pm_wait_for_sp would wait for those too */
+int urf_pm_wait_event(urf_pm *h, void *event);
 void *urf_sp_stream(urf_sp *h);
 /* urf_sp_stream: the stream a call READS its frames on (order producers -- an undistortion, a copy -- against it).
  * urf_sp_result_stream: the stream on which a call's slots become FINAL (order consumers -- an all-gather, a copy of the
@@ -452,11 +455,11 @@ int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols);
  * ref: NULL or n global frame indices (counted from the first submitted frame): frame j is matched
  * against frame ref[j] (-1 = its predecessor) -- the reference matches against the last keyframe
  * (src/tracking.cc:196-203).  A referenced frame must be in this batch or in one of the
- * 2 + history_batches batches before it.  At most `matchers` + 3 batches may be in flight: a submit enqueues its
+ * 2 + history_batches batches before it.  At most `matchers` + 4 batches may be in flight: a submit enqueues its
  * own SuperPoint, the match call of the batch two submits back and begins the fetch of the batch `matchers` + 1 submits
  * back (the only wait, for that batch's fast pass; a strict handle's exact redo of flagged pairs then runs beside the
  * next batches) -- the loop bench.py times, driven by the caller:
- *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 2 || urf_fe_ready() == 1) urf_fe_collect(...);
+ *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 3 || urf_fe_ready() == 1) urf_fe_collect(...);
  * A caller that collects right after every submit gets the synchronous behaviour (collect enqueues what is missing). */
 int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step, size_t frame_stride,
                   const long *ref);

@@ -325,6 +325,21 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     assert [l.split()[:2] for l in strict[1:]] == [l.split()[:2] for l in out[1:]]
     assert max(abs(float(a.split()[2]) - float(b.split()[2])) for a, b in zip(strict[1:], out[1:])) < 1e-3
     assert run("#precision=3") == strict
+    # row a21 at the boundary: "#outlier=opencv42" behind engine_file makes MatchingPoints(..., true) run the reference's own
+    # outlier call, cv::findFundamentalMat(FM_RANSAC, 3, 0.99) restated (urf_sg_config.outlier_stage = 1) -- the list a handle
+    # configured that way through the C ABI returns, tuple for tuple; suffixes combine in any order
+    cv_run = run("#outlier=opencv42")
+    pm_cv = F.PointMatching(F.SuperGlueConfig(), precision=3, outlier_stage=1)
+    assert pm_cv.build(sg_blob)
+    sp_s = F.SuperPoint(F.SuperPointConfig(max_keypoints=400), max_height=H, max_width=W, precision=3)
+    assert sp_s.build(sp_blob)
+    g0, g1 = sp_s.infer(fr[0]), sp_s.infer(fr[1])
+    want_cv = pm_cv.MatchingPoints(g0, g1, True)
+    assert cv_run[0] == f"K0={g0.shape[0]} K1={g1.shape[0]} matches={len(want_cv)}"
+    assert [tuple(l.split()[:2]) for l in cv_run[1:]] == [(str(q), str(t)) for q, t, _ in want_cv]
+    assert len(cv_run) > 100
+    assert run("#outlier=opencv42#precision=3") == cv_run and run("#precision=3#calibrate=0#outlier=opencv42") == cv_run
+    assert run("#outlier=8point") == strict
     for sfx in ("#precision=1", "#precision=2"):
         fast = run(sfx)
         # same counts; keypoint INDICES may differ where near-tied scores swap places in the score-sorted list
@@ -628,14 +643,14 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-@pytest.mark.parametrize("prec,depth", [(0, 3), (1, 3), (2, 3), (3, 3), (3, 5), (3, 1)])
+@pytest.mark.parametrize("prec,depth", [(0, 3), (1, 3), (2, 3), (3, 3), (3, 6), (3, 1)])
 def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec, depth):
     """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
     SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)
     (src/tracking.cc:321-377) as the CPU ORACLE runs it: O.sp_infer / O.match_points on the same 21 frames.
     Exact mode: features and match lists bit for bit; fast modes: the same keypoint sets, and correspondences that may differ
     in a pair whose decisive matching scores are a near-tie (measured on this stream: one pair of twenty differs in two of its
-    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 5 = matchers + 3 is the pipelined loop
+    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 6 = matchers + 4 is the pipelined loop
     bench.py times (SuperPoint two batches ahead of the matchers, fetches begun one step before they are ended), 1 = a collect
     right after every submit (integration/tracking.patch)."""
     from conftest import oracle_frames_and_pairs
@@ -713,16 +728,16 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
     assert _as_tuples(fs.collect()[1][3]) == olists[11]
-    # matchers + 3 batches may be in flight (SuperPoint two ahead of the matchers, one batch begun, one being handed out)
-    for _ in range(5):
+    # matchers + 4 batches may be in flight (SuperPoint two ahead of the matchers, one batch begun, two waiting to be handed out)
+    for _ in range(6):
         fs.submit(frames[4:8])
     with pytest.raises(RuntimeError, match="in flight"):
         fs.submit(frames[4:8])
-    assert fs.in_flight() == 5
+    assert fs.in_flight() == 6
     n = 0
     while fs.in_flight():
         n += len(fs.collect()[1])
-    assert n == 20
+    assert n == 24
 
 
 def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg_blob):

@@ -19,7 +19,7 @@ SYMBOLS = [
     "urf_pm_build", "urf_pm_build_file", "urf_pm_destroy", "urf_normalize_keypoints", "urf_sg_infer",
     "urf_match", "urf_match_device", "urf_match_device_async", "urf_pm_fetch", "urf_pm_fetch_begin", "urf_pm_fetch_ready", "urf_pm_fetch_end", "urf_pm_sync",
     "urf_ransac_find_F", "urf_sp_stage_ms", "urf_pm_stage_ms", "urf_set_profiling", "urf_probe_fma_gemm",
-    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_sp_result_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_pm_wait_for_sp", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
+    "urf_probe_math", "urf_probe_divsqrt", "urf_pm_share_stream", "urf_sp_stream", "urf_sp_result_stream", "urf_epipolar_reconstruct", "urf_probe_h2gemm", "urf_pm_wait_for_sp", "urf_pm_wait_event", "urf_sp_stage_ms_age", "urf_sp_wait_for_sinkhorn",
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync", "urf_cam_size",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",

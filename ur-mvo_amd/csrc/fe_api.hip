@@ -49,6 +49,7 @@ struct urf_fe {
   uint8_t *h_stage = nullptr;         // pinned, NB x B raw frames
   int *h_K = nullptr;                 // pinned, NB x B keypoint counts (copied on SuperPoint's stream right after SP(b))
   std::vector<hipEvent_t> ev_K;       // per ring entry: that copy has landed
+  std::vector<hipEvent_t> ev_in;      // per ring entry: the batch's frames are on the device (recorded on the copy stream)
   hipStream_t cst = nullptr;          // non-blocking stream for collect-time copies (a null-stream copy would
                                       // wait for every blocking stream, i.e. serialise the pipeline)
   long next_batch = 0;                // index of the next batch to submit
@@ -76,9 +77,12 @@ extern "C" int urf_fe_create(const urf_fe_config *cfg, urf_fe **out) {
   h->cfg = *cfg;
   h->B = cfg->batch;
   h->M = cfg->matchers <= 0 ? 2 : (cfg->matchers > kMaxMatchers ? kMaxMatchers : cfg->matchers);
-  // ring: entry k is refilled by SuperPoint(b) while every batch up to b - M - 2 has had its fetch begun (its fast pass is over);
-  // a match reads slots up to 2 + history_batches submits old: NB = M + 4 + history_batches
-  h->NB = h->M + 4 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
+  // ring: entry k is refilled by SuperPoint(b) while every batch up to b - M - 2 has had its fetch begun (its fast pass is over)
+  // and a match reads slots up to 2 + history_batches submits old (NB >= M + 4 + history_batches); up to M + 4 batches are in
+  // flight -- the oldest may wait for its redo one step longer than the loop needs it to (the hand-out lag of DESIGN.md
+  // section 12: one step of lag is worth 8 %, the second steadies it) -- and an entry is not refilled before its batch has been
+  // collected: NB = M + 5 + history_batches
+  h->NB = h->M + 5 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
   // a strict matcher promises the oracle's lists only on slots an exact SuperPoint made (include/urf.h): a configuration that
   // asks for precision 3 on one side alone would get a 2.2e-4 margin on noisy descriptors -- neither strict nor guarded
   if (cfg->sg.precision == 3 && (cfg->sp.precision == 1 || cfg->sp.precision == 2)) {
@@ -115,6 +119,8 @@ extern "C" int urf_fe_build(urf_fe *h, const float *sp_blob, size_t sp_floats, c
   URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
   h->ev_K.resize(h->NB);
   for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->ev_in.resize(h->NB);
+  for (auto &e : h->ev_in) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   URF_HIP(hipDeviceSynchronize());   // the null-stream memset above is not ordered against the handles' streams
   h->built = true;
   return 0;
@@ -133,6 +139,8 @@ extern "C" int urf_fe_build_files(urf_fe *h, const char *sp_engine_file, const c
   URF_HIP(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
   h->ev_K.resize(h->NB);
   for (auto &e : h->ev_K) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->ev_in.resize(h->NB);
+  for (auto &e : h->ev_in) URF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   URF_HIP(hipDeviceSynchronize());   // the null-stream memset above is not ordered against the handles' streams
   h->built = true;
   return 0;
@@ -150,6 +158,7 @@ extern "C" void urf_fe_destroy(urf_fe *h) {
   (void)hipHostFree(h->h_stage); (void)hipHostFree(h->h_K);
   if (h->cst) (void)hipStreamDestroy(h->cst);
   for (auto &e : h->ev_K) (void)hipEventDestroy(e);
+  for (auto &e : h->ev_in) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -173,7 +182,9 @@ extern "C" int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_
 static int fe_enqueue_match(urf_fe *h, urf_fe::Pending &p) {
   urf_pm *pm = h->pm[p.batch % h->M];
   if (!p.s0.empty()) {
-    if (urf_pm_wait_for_sp(pm, h->sp)) return -1;        // match(b) needs SP(b) (and every earlier slot)
+    // match(b) needs SP(b) (and every earlier slot) -- and nothing younger: the event recorded right behind SP(b) on the stream
+    // where its slots become final, not "everything enqueued so far" (SuperPoint runs two batches ahead of this call)
+    if (urf_pm_wait_event(pm, (void *)h->ev_K[p.batch % h->NB])) return -1;
     if (urf_match_device_async(pm, (int)p.s0.size(), p.s0.data(), p.s1.data(), h->cfg.outlier_rejection)) return -1;
   }
   p.matched = true;
@@ -211,13 +222,13 @@ static int fe_pump(urf_fe *h) {
 
 // Would the NEXT urf_fe_submit accept global frame `frame` as a reference?  The same test submit applies to a reference
 // outside its own batch: the frame sits in a ring entry that is not the one about to be refilled and is at most
-// NB - M - 2 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
+// NB - M - 3 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
 // drain --, so the window cannot be derived from a frame count; integration/tracking.patch asks here).
 static const uint8_t *fe_resident_slot(urf_fe *h, long want) {
   const long b = h->next_batch;
   const int k = (int)(b % h->NB);
   for (int e = 0; e < h->NB; ++e)
-    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 2) && want >= h->batch_first[e] &&
+    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 3) && want >= h->batch_first[e] &&
         want < h->batch_first[e] + h->batch_n[e])
       return slot_ptr(h, e, (int)(want - h->batch_first[e]));
   return nullptr;
@@ -236,7 +247,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
                              size_t frame_stride, const long *ref) {
   URF_CHECK(h && h->built, "urf_fe_submit: handle is not built");
   URF_CHECK(frames && n >= 1 && n <= h->B && rows > 0 && cols > 0 && step >= (size_t)cols, "urf_fe_submit: bad argument");
-  URF_CHECK((int)h->pending.size() <= h->M + 2, "urf_fe_submit: %d batches in flight, collect one first", h->M + 3);
+  URF_CHECK((int)h->pending.size() <= h->M + 3, "urf_fe_submit: %d batches in flight, collect one first", h->M + 4);
   URF_HIP(hipSetDevice(h->cfg.sp.device));
   if (!h->d_raw) {
     h->rows = rows; h->cols = cols;
@@ -262,7 +273,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
     if (want >= h->frames_seen) {
       src = slot_ptr(h, k, (int)(want - h->frames_seen));   // an earlier frame of this batch
     } else {
-      // window = the last NB - M - 2 batches: an older ring entry may be refilled by SuperPoint while
+      // window = the last NB - M - 3 batches: an older ring entry may be refilled by SuperPoint while
       // this batch's matcher (up to M + 1 submits behind) still reads it; entry k is being refilled now
       src = fe_resident_slot(h, want);
     }
@@ -272,13 +283,21 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
   }
   const size_t fr = (size_t)rows * cols;
   hipStream_t st = (hipStream_t)urf_sp_stream(h->sp);
-  // raw frames -> pinned staging -> device, on SuperPoint's stream.  The staging entry k was last
+  // raw frames -> pinned staging -> device.  The staging entry k was last
   // read by the copy of batch b - NB, which finished before match(b - NB) had its fetch begun.
   uint8_t *stage = h->h_stage + (size_t)k * h->B * fr;
-  for (int j = 0; j < n; ++j)
-    for (int r = 0; r < rows; ++r) memcpy(stage + (size_t)j * fr + (size_t)r * cols, frames + (size_t)j * frame_stride + (size_t)r * step, cols);
+  if (step == (size_t)cols && frame_stride == fr) memcpy(stage, frames, (size_t)n * fr);         // tight frames: one copy
+  else
+    for (int j = 0; j < n; ++j) {
+      if (step == (size_t)cols) { memcpy(stage + (size_t)j * fr, frames + (size_t)j * frame_stride, fr); continue; }
+      for (int r = 0; r < rows; ++r) memcpy(stage + (size_t)j * fr + (size_t)r * cols, frames + (size_t)j * frame_stride + (size_t)r * step, cols);
+    }
   uint8_t *d_raw = h->d_raw + (size_t)k * h->B * fr;
-  URF_HIP(hipMemcpyAsync(d_raw, stage, (size_t)n * fr, hipMemcpyHostToDevice, st));
+  // the PCIe transfer on the copy stream (entry k of d_raw was last read by SuperPoint(b - NB), collected long ago): SuperPoint's
+  // stream -- the busiest of the strict pipeline -- only waits for the event, it does not carry the copy
+  URF_HIP(hipMemcpyAsync(d_raw, stage, (size_t)n * fr, hipMemcpyHostToDevice, h->cst));
+  URF_HIP(hipEventRecord(h->ev_in[k], h->cst));
+  URF_HIP(hipStreamWaitEvent(st, h->ev_in[k], 0));
   const uint8_t *d_in = d_raw;
   if (h->cam) {
     uint8_t *d_und = h->d_und + (size_t)k * h->B * h->frows * h->fcols;

@@ -201,6 +201,7 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
     // fragments into the registers of the first after its twelve MFMAs, an LDS round trip in the middle of every chunk
     // (measured: +0.5 % in the pipeline, nothing serialised)
     __builtin_amdgcn_sched_barrier(0);
+    if (a.xflags & 8) __builtin_amdgcn_s_setprio(1);   // (experiments: the MFMA cluster at a raised wave priority)
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -215,6 +216,7 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
           acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
         }
       }
+    if (a.xflags & 8) __builtin_amdgcn_s_setprio(0);
   }
   GM_STAMP(3);
 #ifdef URF_GEMM_STAMPS
@@ -224,6 +226,7 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
   GM_STAMP(4);
 }
 
+#ifdef URF_EXPERIMENTS   // measured and not kept: only the experiments build carries it
 // ---------------------------------------------------------------------------------------------
 // Round 5: the same tile with the activations THREE chunks deep and the weights two (asymmetric ring, 80 KB: still two workgroups
 // per CU).  The two-stage loop above gives a chunk's DMA exactly one chunk of MFMAs to land (vmcnt(0) at the top of every chunk);
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(512, 4) h2gemm_ring_kernel(H2Args a) {
   else if ((int)blockIdx.y * 128 >= a.t_from) h2gemm_ring_tile<true, 2>(a, hsm, b, cout_base, row0);
   else h2gemm_ring_tile<false, 2>(a, hsm, b, cout_base, row0);
 }
+#endif
 
 template <bool TOUT>
 __device__ __forceinline__ void h2gemm_glds_body(const H2Args &a, _Float16 *hsm) {
@@ -509,14 +513,15 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
 #ifdef URF_EXPERIMENTS
   if (g_h2gemm_variant == -1) {  // tuning knob for A/B runs; the default is the LDS-DMA kernel
     const char *e = urf::exp_env("URF_H2GEMM_VARIANT");
-    g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
+    g_h2gemm_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 2;
   }
   const int variant = g_h2gemm_variant;
 #else
-  const int variant = 3;         // the product carries the LDS-DMA kernels only: 3 = the asymmetric ring (round 5), 2 = two stages (round 2)
+  const int variant = 2;         // the product carries the two-stage LDS-DMA kernel only (3 = the asymmetric ring of round 5: measured slower, experiments build)
 #endif
   URF_CHECK(a.t_from == 0 || (variant >= 2 && (a.t_from % 128) == 0 && a.ohT),
             "h2gemm: the dual epilogue needs the LDS-DMA kernel and a 128-aligned split");
+#ifdef URF_EXPERIMENTS
   if (variant == 3) {
     const size_t lds = sizeof(_Float16) * G3_LDS_HALFS;   // 80 KB: two workgroups per CU
     static DeviceOnce attr3;
@@ -538,6 +543,7 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     URF_HIP(hipGetLastError());
     return 0;
   }
+#endif
   if (variant == 2) {
     // 64 KiB: two stages of four planes (+ URF_H2GEMM_LDS_PAD bytes: occupancy experiments -- a padded workgroup keeps
     // its CU to itself and leaves registers / LDS for another stream's kernel)
@@ -566,7 +572,9 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     static int nt = -1;
     if (nt < 0) { const char *e = urf::exp_env("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;
-    b.xflags = g_h2gemm_xflags | nt;
+    static int prio = -1;
+    if (prio < 0) { const char *e = urf::exp_env("URF_H2GEMM_SETPRIO"); prio = e ? (atoi(e) != 0) : 0; }
+    b.xflags = g_h2gemm_xflags | nt | (prio ? 8 : 0);
 #ifdef URF_EXPERIMENTS
     if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768) {
       hipLaunchKernelGGL(h2gemm_glds_qkv_kernel, dim3((a.rows + 127) / 128, 4, batch), dim3(512), lds, st, b);

@@ -1020,6 +1020,8 @@ static int pm_upload_pair(urf_pm *h, const double *nf0, const double *raw0, int 
 static int pm_check(urf_pm *h, int n0, int n1) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(n0 >= 0 && n0 <= NP && n1 >= 0 && n1 <= NP, "keypoint counts (%d, %d) outside [0, %d]", n0, n1, NP);
+  // the one-pair host calls use the handle's buffers and result sets: not while a device batch is enqueued or waits for its fetch_end
+  URF_CHECK(h->pending_P == 0 && h->bq_n == 0, "a device batch of this handle has not been handed out yet (urf_pm_fetch / urf_pm_fetch_end first)");
   return 0;
 }
 
@@ -1369,6 +1371,7 @@ static int pm_find_F(urf_pm *h, const float *pts0, const float *pts1, int n, con
                      uint8_t *inliers, float *F21, float *score) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(pts0 && pts1 && inliers && F21 && score && n >= 0 && n <= NP, "urf_ransac_find_F: bad argument");
+  URF_CHECK(h->pending_P == 0 && h->bq_n == 0, "urf_ransac_find_F: a device batch of this handle has not been handed out yet (it shares the handle's buffers)");
   memset(inliers, 0, n);
   for (int k = 0; k < 9; ++k) F21[k] = 0.0f;
   *score = 0.0f;
@@ -1466,6 +1469,12 @@ extern "C" int urf_pm_wait_for_sp(urf_pm *h, urf_sp *sp) {
   if (ss == h->st) return 0;
   URF_HIP(hipEventRecord(h->ev_ext, ss));
   URF_HIP(hipStreamWaitEvent(h->st, h->ev_ext, 0));
+  return 0;
+}
+extern "C" int urf_pm_wait_event(urf_pm *h, void *event) {
+  URF_CHECK(h && h->built && event, "urf_pm_wait_event: bad argument");
+  URF_HIP(hipSetDevice(h->device));
+  URF_HIP(hipStreamWaitEvent(h->st, (hipEvent_t)event, 0));
   return 0;
 }
 extern "C" int urf_sp_wait_for_sinkhorn(urf_sp *sp, urf_pm *h) {
