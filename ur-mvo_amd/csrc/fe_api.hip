@@ -293,11 +293,10 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
       for (int r = 0; r < rows; ++r) memcpy(stage + (size_t)j * fr + (size_t)r * cols, frames + (size_t)j * frame_stride + (size_t)r * step, cols);
     }
   uint8_t *d_raw = h->d_raw + (size_t)k * h->B * fr;
-  // the PCIe transfer on the copy stream (entry k of d_raw was last read by SuperPoint(b - NB), collected long ago): SuperPoint's
-  // stream -- the busiest of the strict pipeline -- only waits for the event, it does not carry the copy
-  URF_HIP(hipMemcpyAsync(d_raw, stage, (size_t)n * fr, hipMemcpyHostToDevice, h->cst));
-  URF_HIP(hipEventRecord(h->ev_in[k], h->cst));
-  URF_HIP(hipStreamWaitEvent(st, h->ev_in[k], 0));
+  // on SuperPoint's own stream.  (Round 5 measured the transfer on a copy stream of its own, with an event for SuperPoint to wait
+  // for: 1013 -> 922 frames/s -- a seventh stream on the runtime's four hardware queues costs more than the 60 us of PCIe time it
+  // takes off the busiest stream)
+  URF_HIP(hipMemcpyAsync(d_raw, stage, (size_t)n * fr, hipMemcpyHostToDevice, st));
   const uint8_t *d_in = d_raw;
   if (h->cam) {
     uint8_t *d_und = h->d_und + (size_t)k * h->B * h->frows * h->fcols;

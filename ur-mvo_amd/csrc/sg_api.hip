@@ -182,6 +182,8 @@ struct urf_pm {
   int bq_head = 0, bq_n = 0;
   unsigned long long pairs_redone = 0, cause_thr = 0, cause_run = 0;
   float redo_ms = 0.0f;            // time from the start of the last redo until its results were waited for, profiling
+  float *h_up = nullptr;           // pinned staging of the one-pair host calls: kin | kxy | x (allocated by the first such call)
+  int up_n[2] = {0, 0};            //   rows of it the last call filled, per image
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
   bool flags_recorded = false;
   unsigned long long pairs_flagged = 0;
@@ -535,6 +537,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
     for (int k = 0; k < urf_pm::kSets; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
     for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipEventDestroy(h->bq[k].ev_in); (void)hipEventDestroy(h->bq[k].ev_done); }
     (void)hipHostFree(h->h_rs_err);
+    if (h->h_up) (void)hipHostFree(h->h_up);
     if (h->h_resid) (void)hipHostFree(h->h_resid);
     (void)hipHostFree((void *)h->h_slotptrs);
     for (int i = 0; i <= PT_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -990,30 +993,52 @@ extern "C" void urf_normalize_keypoints(const double *feat, int n, int width, in
   }
 }
 
-// upload one pair given as host f64 features with NORMALISED keypoints (nf) and,
-// optionally, the pixel coordinates for the outlier stage (raw, may be null)
-static int pm_upload_pair(urf_pm *h, const double *nf0, const double *raw0, int n0, const double *nf1,
-                          const double *raw1, int n1) {
-  std::vector<float> kin((size_t)2 * NP * 4, 0.0f), kxy((size_t)2 * NP * 2, 0.0f), x((size_t)2 * NP * 256, 0.0f);
-  const double *nf[2] = {nf0, nf1}, *raw[2] = {raw0, raw1};
+// upload one pair given as host f64 features (column-major 259 x n).  normalize: the keypoints are pixel coordinates and go
+// through PointMatching::NormalizeKeypoints on the way (src/point_matching.cc:63-76: (x - width / 2) / (max(width, height) * 0.7)
+// in double, narrowed like SuperGlue::process_input, src/super_glue.cpp:259-275) -- else they are normalised already
+// (SuperGlue::infer).  want_xy: keep the pixel coordinates for the outlier stage.  Staging is pinned memory of the handle
+// (allocated by the first host call): the conversion is the only pass over the features and the copies are true DMA.
+static int pm_upload_pair(urf_pm *h, const double *f0, int n0, const double *f1, int n1, bool normalize, bool want_xy) {
+  const size_t nk = (size_t)2 * NP * 4, nxy = (size_t)2 * NP * 2, nx = (size_t)2 * NP * 256;
+  if (!h->h_up) {
+    URF_HIP(hipHostMalloc((void **)&h->h_up, (nk + nxy + nx) * sizeof(float), hipHostMallocDefault));
+    memset(h->h_up, 0, (nk + nxy + nx) * sizeof(float));
+    h->up_n[0] = h->up_n[1] = 0;
+  }
+  float *kin = h->h_up, *kxy = kin + nk, *x = kxy + nxy;
+  const double *f[2] = {f0, f1};
   const int n[2] = {n0, n1};
-  for (int im = 0; im < 2; ++im)
+  const int W = h->cfg.image_width, H = h->cfg.image_height, mx = W > H ? W : H;
+  for (int im = 0; im < 2; ++im) {
     for (int j = 0; j < n[im]; ++j) {
-      const double *col = nf[im] + (size_t)259 * j;
-      float *k = kin.data() + ((size_t)im * NP + j) * 4;
-      k[0] = (float)col[1]; k[1] = (float)col[2]; k[2] = (float)col[0];  // src/super_glue.cpp:259-275
-      if (raw[im]) {
-        kxy[((size_t)im * NP + j) * 2] = (float)raw[im][(size_t)259 * j + 1];      // cv::Point2f, point_matching.cc:39-41
-        kxy[((size_t)im * NP + j) * 2 + 1] = (float)raw[im][(size_t)259 * j + 2];
+      const double *col = f[im] + (size_t)259 * j;
+      float *k = kin + ((size_t)im * NP + j) * 4;
+      if (normalize) {
+        k[0] = (float)((col[1] - W / 2) / (mx * 0.7));
+        k[1] = (float)((col[2] - H / 2) / (mx * 0.7));
+      } else {
+        k[0] = (float)col[1]; k[1] = (float)col[2];
       }
-      float *d = x.data() + ((size_t)im * NP + j) * 256;
+      k[2] = (float)col[0];
+      kxy[((size_t)im * NP + j) * 2] = want_xy ? (float)col[1] : 0.0f;        // cv::Point2f, point_matching.cc:39-41
+      kxy[((size_t)im * NP + j) * 2 + 1] = want_xy ? (float)col[2] : 0.0f;
+      float *d = x + ((size_t)im * NP + j) * 256;
       for (int c = 0; c < 256; ++c) d[c] = (float)col[3 + c];                   // :277-283
     }
+    // rows the previous call filled beyond this call's count go back to zero (the device buffers hold zeros past the counts)
+    const int was = h->up_n[im];
+    if (was > n[im]) {
+      memset(kin + ((size_t)im * NP + n[im]) * 4, 0, (size_t)(was - n[im]) * 4 * sizeof(float));
+      memset(kxy + ((size_t)im * NP + n[im]) * 2, 0, (size_t)(was - n[im]) * 2 * sizeof(float));
+      memset(x + ((size_t)im * NP + n[im]) * 256, 0, (size_t)(was - n[im]) * 256 * sizeof(float));
+    }
+    h->up_n[im] = n[im];
+  }
   URF_HIP(hipMemcpyAsync(h->counts, n, 2 * sizeof(int), hipMemcpyHostToDevice, h->st));
-  URF_HIP(hipMemcpyAsync(h->kin, kin.data(), kin.size() * 4, hipMemcpyHostToDevice, h->st));
-  URF_HIP(hipMemcpyAsync(h->kxy, kxy.data(), kxy.size() * 4, hipMemcpyHostToDevice, h->st));
-  URF_HIP(hipMemcpyAsync(h->x, x.data(), x.size() * 4, hipMemcpyHostToDevice, h->st));
-  URF_HIP(hipStreamSynchronize(h->st));  // staging vectors die with this frame
+  URF_HIP(hipMemcpyAsync(h->kin, kin, nk * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->kxy, kxy, nxy * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipMemcpyAsync(h->x, x, nx * 4, hipMemcpyHostToDevice, h->st));
+  URF_HIP(hipStreamSynchronize(h->st));  // (`n` lives on this frame; the pinned staging is free for the next call)
   return 0;
 }
 
@@ -1031,10 +1056,10 @@ extern "C" int urf_sg_infer(urf_pm *h, const double *f0, int n0, const double *f
   URF_CHECK(n0 >= 1 && n1 >= 1, "SuperGlue needs at least one keypoint per image (profile min, src/super_glue.cpp:63-66)");
   URF_CHECK(f0 && f1 && idx0 && idx1 && ms0 && ms1, "urf_sg_infer: null pointer");
   URF_HIP(hipSetDevice(h->device));
-  if (pm_upload_pair(h, f0, nullptr, n0, f1, nullptr, n1)) return -1;
+  if (pm_upload_pair(h, f0, n0, f1, n1, false, false)) return -1;
   if (h->calib_left > 0 && h->bq_n == 0 && h->pending_P == 0) {
     if (pm_auto_calibrated(h, 1, pm_calibrate_core(h, 1, 1.6f, nullptr))) return -1;
-    if (pm_upload_pair(h, f0, nullptr, n0, f1, nullptr, n1)) return -1;
+    if (pm_upload_pair(h, f0, n0, f1, n1, false, false)) return -1;
   }
   if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
   if (pm_pipeline(h, 1, Zout != nullptr, false)) return -1;
@@ -1061,13 +1086,10 @@ extern "C" int urf_match(urf_pm *h, const double *f0, int n0, const double *f1, 
   URF_CHECK(f0 && f1 && out, "urf_match: null pointer");
   if (n0 < 1 || n1 < 1) return 0;
   URF_HIP(hipSetDevice(h->device));
-  std::vector<double> nf0((size_t)259 * n0), nf1((size_t)259 * n1);
-  urf_normalize_keypoints(f0, n0, h->cfg.image_width, h->cfg.image_height, nf0.data());
-  urf_normalize_keypoints(f1, n1, h->cfg.image_width, h->cfg.image_height, nf1.data());
-  if (pm_upload_pair(h, nf0.data(), f0, n0, nf1.data(), f1, n1)) return -1;
+  if (pm_upload_pair(h, f0, n0, f1, n1, true, true)) return -1;      // NormalizeKeypoints on the way (src/point_matching.cc:22-23)
   if (h->calib_left > 0 && h->bq_n == 0 && h->pending_P == 0) {
     if (pm_auto_calibrated(h, 1, pm_calibrate_core(h, 1, 1.6f, nullptr))) return -1;
-    if (pm_upload_pair(h, nf0.data(), f0, n0, nf1.data(), f1, n1)) return -1;
+    if (pm_upload_pair(h, f0, n0, f1, n1, true, true)) return -1;
   }
   if (urf::g_profiling) (void)hipEventRecord(h->ev[PT_PREP], h->st);
   if (pm_pipeline(h, 1, false, outlier_rejection != 0)) return -1;
