@@ -39,9 +39,9 @@ def collinear_last(p, count):
     return False
 
 
-def get_subset(m1, m2, rng):
+def get_subset(m1, m2, rng, max_attempts=10000):
     n = len(m1)
-    for _ in range(10000):
+    for _ in range(max_attempts):
         idx = []
         for i in range(7):
             while True:
@@ -101,11 +101,37 @@ def update_iters(p, ep, max_iters):
     return max_iters if (denom >= 0 or -num >= max_iters * (-denom)) else int(round(num / denom))
 
 
+def lmeds_mask(m1, m2, conf=0.99):
+    """LMeDSPointSetRegistrator::run of OpenCV 4.2 (8 .. 14 points): outlier ratio 0.45, getSubset's default 1000 attempts, the
+    model with the least median error, sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median), the mask as findInliers leaves
+    it -- also when fewer than 7 points pass (run() then reports failure; the mask has been copied out)"""
+    n = len(m1)
+    rng = RNG()
+    niters = max(update_iters(conf, 0.45, 1000), 3)
+    best, min_median, it = None, float("inf"), 0
+    for it in range(niters):
+        idx = get_subset(m1, m2, rng, 1000)
+        if idx is None:
+            if it == 0:
+                return np.ones(n, np.uint8), 0
+            break
+        for F in run7(m1[idx], m2[idx]):
+            e = np.sort(errors(F, m1, m2))
+            med = float(e[n // 2]) if n % 2 else float(np.float32(e[n // 2 - 1] + e[n // 2])) * 0.5
+            if med < min_median:
+                min_median, best = med, F
+    if best is None:
+        return np.ones(n, np.uint8), it + 1
+    sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * math.sqrt(min_median), 0.001)
+    return (errors(best, m1, m2) <= np.float32(sigma * sigma)).astype(np.uint8), it + 1
+
+
 def find_fundamental_mask(m1, m2, thresh=3.0, conf=0.99):
     n = len(m1)
     if n <= 7:
-        return np.ones(n, np.uint8)
-    assert n >= 15, "the golden covers the RANSAC branch"
+        return np.ones(n, np.uint8), 0
+    if n < 15:
+        return lmeds_mask(m1, m2, conf)
     rng = RNG()
     t = np.float32(thresh * thresh)
     niters, max_good, best = 1000, 0, np.ones(n, np.uint8)
@@ -146,7 +172,10 @@ def scene(seed, n_in, n_out, noise):
 
 
 def main():
-    for name, args in (("a", (3, 300, 60, 0.3)), ("b", (4, 700, 20, 0.5)), ("c", (5, 40, 25, 0.2)), ("d", (6, 15, 3, 0.1))):
+    # e, f: the LMedS branch (8 .. 14 points) -- a clean set, and one so cluttered that fewer than 7 points pass its own threshold
+    for name, args in (("a", (3, 300, 60, 0.3)), ("b", (4, 700, 20, 0.5)), ("c", (5, 40, 25, 0.2)), ("d", (6, 15, 3, 0.1)),
+                       ("e", (7, 12, 2, 0.1)), ("f", (8, 6, 8, 0.1))):   # (14 points each: with 13 or fewer the median is the error
+        # of one of the seven sample points of a model, i.e. rounding noise, and which model "wins" is numerics, not algorithm)
         m0, m1, truth = scene(*args)
         mask, iters = find_fundamental_mask(m0, m1)
         np.savez_compressed(os.path.join(HERE, f"cvransac_{name}.npz"), m0=m0, m1=m1, truth=truth, mask=mask, iterations=iters)

@@ -1,7 +1,8 @@
 """Randomised sweep of the strict-parity matcher against the exact matcher on the GPU: random keypoint counts, random planted
 correspondences, random outlier-stage switch; the strict handle's DMatch list of EVERY pair must be the exact handle's, index for
 index (distances within 1e-3) -- whether the pair was flagged and redone or not.  Both handles get the same (exact) feature
-matrices, as in the strict mode's pipeline.    python tools/gpu_sweep_strict.py [n_cases=300] [seed=0]"""
+matrices, as in the strict mode's pipeline.    python tools/gpu_sweep_strict.py [n_cases=300] [seed=0] [weight seed=0] [gnn gain=0.5]
+(other weights: the strict handle calibrates its guard on its first 8 pairs, urf_sg_config.calibrate_pairs)"""
 import os
 import sys
 
@@ -17,7 +18,9 @@ U = load_pkg(); F, synth = U.frontend, U.synth
 print(U._lib.lib().urf_build_info().decode())
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-sgb = synth.pack_sg(synth.sg_weights(0))
+wseed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+gain = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
+sgb = synth.pack_sg(synth.sg_weights(wseed, gnn_gain=gain))
 pmx = F.PointMatching(F.SuperGlueConfig(), precision=0)
 pms = F.PointMatching(F.SuperGlueConfig(), precision=3)
 assert pmx.build(sgb) and pms.build(sgb)
@@ -41,6 +44,9 @@ for c in range(N):
         bad += 1
         print(f"case {c}: n0={n0} n1={n1} ransac={int(ransac)} flagged={fl}: {len(got)} vs {len(want)} matches, index lists equal {same}, max distance difference {dd:.3g}", flush=True)
 st = pms.near_tie_reruns()
+g = pms.guard_state()
+print(f"weights seed {wseed} gain {gain}: guard margin {g['margin']:.3g} (largest calibrated difference {g['measured']:.3g}, redo_all {g['redo_all']}); "
+      f"largest column-marginal residual integrity events {pms.sinkhorn_integrity()['events']}")
 print(f"{N} pairs, {tot} matches: pairs whose strict list differs from the exact list: {bad}; flagged and redone {flagged} ({st['redone']} by the counter); "
       f"largest distance difference on an unflagged pair {worst_d:.3g}")
 sys.exit(1 if bad else 0)
