@@ -57,7 +57,7 @@ __device__ long long g_attn_stamps[2][64][8];
 template <int QT, int NW>
 __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, const _Float16 *qkl,
                                                           const _Float16 *vth, const _Float16 *vtl, const int *counts,
-                                                          int cross, _Float16 *oh, _Float16 *ol, int xflags) {
+                                                          int cross, _Float16 *oh, _Float16 *ol) {
   constexpr int NT = 64 * NW, QB = 16 * QT * NW;   // threads, queries per workgroup
   constexpr int NV = 512 / NT;                     // staging roles per thread (512 = 2 tensors x 2 planes x 16 rows x 8 pieces)
   // [buffer][K planes | V planes]
@@ -191,7 +191,6 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       if (kt + 1 < 4) load_k(kt + 1);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[QT];
-      if (xflags & 1) __builtin_amdgcn_s_setprio(1);   // (experiments, URF_ATTN_SETPRIO: the MFMA clusters at a raised wave priority)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const f16x8 ah = kf[kt & 1][ks][0], al = kf[kt & 1][ks][1];
@@ -203,7 +202,6 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t][ks], acc[t], 0, 0, 0);
         }
       }
-      if (xflags & 1) __builtin_amdgcn_s_setprio(0);
       const int kb0 = ch * 64 + kt * 16 + 4 * g;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
@@ -288,14 +286,12 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         f16x8 ah, al;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ah[e] = vf[i % VR][0][e]; ah[4 + e] = vf[i % VR][1][e]; al[e] = vf[i % VR][2][e]; al[4 + e] = vf[i % VR][3][e]; }
-        if (xflags & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[t], oacc[t][dt], 0, 0, 0);
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pl[t], oacc[t][dt], 0, 0, 0);
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ph[t], oacc[t][dt], 0, 0, 0);
         }
-        if (xflags & 2) __builtin_amdgcn_s_setprio(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -333,10 +329,10 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 template <int QT, int NW>
 static int launch_attn_h2_t(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                             const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
-  static int prio = -1;
-  if (prio < 0) { const char *e = urf::exp_env("URF_ATTN_SETPRIO"); prio = e ? atoi(e) : 0; }
+  // (round 5 measured `s_setprio 1` around the MFMA clusters: +-0.5 %, and the run-time switch for it -- two branches inside the
+  // pinned schedule of the chunk -- cost 4 us per launch even when off: not kept in any build)
   hipLaunchKernelGGL((attn_h2_kernel<QT, NW>), dim3((ANP / (16 * QT * NW)) * 4 * nimg), dim3(64 * NW), 0, st, qkh, qkl, vth,
-                     vtl, counts, cross, oh, ol, prio);
+                     vtl, counts, cross, oh, ol);
   URF_HIP(hipGetLastError());
   return 0;
 }

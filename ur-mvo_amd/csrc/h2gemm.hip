@@ -201,7 +201,6 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
     // fragments into the registers of the first after its twelve MFMAs, an LDS round trip in the middle of every chunk
     // (measured: +0.5 % in the pipeline, nothing serialised)
     __builtin_amdgcn_sched_barrier(0);
-    if (a.xflags & 8) __builtin_amdgcn_s_setprio(1);   // (experiments: the MFMA cluster at a raised wave priority)
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -216,7 +215,6 @@ __device__ __forceinline__ void h2gemm_glds_tile(const H2Args &a, _Float16 *hsm,
           acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[r], acc[m][r], 0, 0, 0);
         }
       }
-    if (a.xflags & 8) __builtin_amdgcn_s_setprio(0);
   }
   GM_STAMP(3);
 #ifdef URF_GEMM_STAMPS
@@ -572,9 +570,7 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     static int nt = -1;
     if (nt < 0) { const char *e = urf::exp_env("URF_H2GEMM_NT"); nt = e ? (atoi(e) != 0) : 0; }
     H2Args b = a;
-    static int prio = -1;
-    if (prio < 0) { const char *e = urf::exp_env("URF_H2GEMM_SETPRIO"); prio = e ? (atoi(e) != 0) : 0; }
-    b.xflags = g_h2gemm_xflags | nt | (prio ? 8 : 0);
+    b.xflags = g_h2gemm_xflags | nt;
 #ifdef URF_EXPERIMENTS
     if ((balance & 1) && a.ohT && a.t_from == 512 && a.Cout == 768) {
       hipLaunchKernelGGL(h2gemm_glds_qkv_kernel, dim3((a.rows + 127) / 128, 4, batch), dim3(512), lds, st, b);

@@ -38,7 +38,7 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1, int *idx0, int *idx1, double *ms0,
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
-                  float *resid, float resid_bound, int *err, int P, hipStream_t st);
+                  float *resid_cols, float *resid, float resid_bound, int *err, int P, hipStream_t st);
 int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st);
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
                   float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
@@ -106,6 +106,7 @@ struct urf_pm {
   unsigned long long *rs_xin = nullptr, *rs_xbc = nullptr;
   unsigned rs_salt = 0;
   int *rs_err = nullptr, *h_rs_err = nullptr;   // [0]: 1 = a launch gave up, 2 = a result failed the integrity bound; [2..3]: those pairs
+  float *rs_resid_cols = nullptr;                  // per pair and column: |column marginal - 1| (argmax_kernel writes, decode_kernel reduces)
   float *rs_resid = nullptr, *h_resid = nullptr;   // per pair: largest |column marginal - 1| of the plan the decode read (fast modes)
   float resid_bound = 0.0f;                      // <= 0: no integrity check
   unsigned long long rs_integrity_pairs = 0;     // pairs whose Sinkhorn result failed the bound and was redone
@@ -423,7 +424,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
   memset(h->last_resid, 0, sizeof(h->last_resid));
   if (h->fast) {
     URF_CHECK(P <= 64, "fast modes: max_pairs %zu above 64", P);
-    if (dalloc(&h->rs_resid, P)) return -1;
+    if (dalloc(&h->rs_resid, P) || dalloc(&h->rs_resid_cols, P * NP)) return -1;
     URF_HIP(hipHostMalloc((void **)&h->h_resid, P * sizeof(float), hipHostMallocDefault));
     memset(h->h_resid, 0, P * sizeof(float));
     h->resid_bound = h->cfg.sinkhorn_residual_bound != 0.0f ? h->cfg.sinkhorn_residual_bound : kSinkhornResidBound;
@@ -530,7 +531,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->Ct, h->Z, h->u, h->v, h->mi0, h->mi1, h->mv0, h->mv1, h->idx0, h->idx1, h->ms0, h->ms1,
                     h->matches, h->fm_set[0], h->fm_set[1], h->fm_set[2], h->nmatch, h->nf_set[0], h->nf_set[1], h->nf_set[2], h->pts0, h->pts1, h->ps0, h->ps1, h->pn0, h->pn1, h->T, h->F,
                     h->score, h->Fbest, h->best_score, h->inliers, h->cv_scratch, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
-                    h->g_flags, h->rs_resid};
+                    h->g_flags, h->rs_resid, h->rs_resid_cols};
     for (void *p : bufs) (void)hipFree(p);
     for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipFree(h->bq[k].counts); (void)hipFree(h->bq[k].kxy); (void)hipFree(h->bq[k].x); }
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
@@ -770,11 +771,11 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
   if (guard) URF_HIP(hipMemsetAsync(h->g_flags, 0, P * sizeof(int), st));
   // integrity of the fast Sinkhorn's result: the decode's column pass sums every column of the plan it reads (the column marginals
   // are 1 in every correct result), a pair above the bound raises the handle's error word like a give-up does (pm_check_resident)
-  const bool integ = fast && !h->tail_exact && h->rs_resid != nullptr;
-  if (integ) URF_HIP(hipMemsetAsync(h->rs_resid, 0, P * sizeof(float), st));
+  static const int no_resid = [] { const char *e = urf::exp_env("URF_NO_RESID"); return e ? atoi(e) : 0; }();   // (experiments: what the integrity word costs)
+  const bool integ = fast && !h->tail_exact && h->rs_resid != nullptr && !no_resid;
   if (launch_decode(h->counts, h->C, h->Ct, h->u, h->v, h->cfg.matching_threshold, h->kxy, h->mi0, h->mv0, h->mi1,
                     h->mv1, h->idx0, h->idx1, h->ms0, h->ms1, h->matches, h->pts0, h->pts1, h->nmatch,
-                    want_Z ? h->Z : nullptr, guard ? h->g_flags : nullptr, h->g_z, integ ? h->rs_resid : nullptr,
+                    want_Z ? h->Z : nullptr, guard ? h->g_flags : nullptr, h->g_z, integ ? h->rs_resid_cols : nullptr, h->rs_resid,
                     (integ && h->resid_bound > 0.0f) ? h->resid_bound : FLT_MAX, h->rs_err, P, st))
     return -1;
   if (guard) URF_HIP(hipMemcpyAsync(h->h_gflags, h->g_flags, P * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(256) sinkhorn_half_kernel(const int *counts, c
 // iterations they still miss by up to 0.4 on the bench streams).  resid[p] = the largest |sum - 1| over the pair's columns: the
 // integrity word of the pair's Sinkhorn result (sg_api.hip, pm_check_resident) -- it catches a result whose last iteration, final
 // potentials or couplings were damaged, not a transient error of an earlier iteration that the later ones have absorbed.
+// (The kernel writes one word per column, resid[p][column]; decode_kernel reduces them.)
 template <bool ROWS, bool GUARD, bool RESID>
 __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const float *M, const float *u, const float *v,
                                                      int *midx, float *mval, float *Zout, int *gflags, float gz,
@@ -497,7 +498,9 @@ __global__ void __launch_bounds__(256) argmax_kernel(const int *counts, const fl
     if (lane == 0) rsum = rsum + __expf((ROWS ? ((mr[Cn] + up[row]) + vp[Cn]) : ((mr[Cn] + up[Cn]) + vp[row])) - norm);   // the dustbin entry
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) rsum = rsum + __shfl_xor(rsum, s, 64);
-    if (lane == 0 && resid) atomicMax((int *)(resid + p), __float_as_int(fabsf(rsum - 1.0f)));   // (non-negative floats order as ints)
+    // one word per column, reduced by the pair's decode workgroup (a thousand atomic maxima on one address per pair doubled this
+    // kernel's time: 55 -> 120 us per batch of eight, 2.8 % of the fast mode's step)
+    if (lane == 0 && resid) resid[(size_t)p * NP + row] = fabsf(rsum - 1.0f);
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -550,10 +553,12 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
                                                       const int *mi1, double thresh, const float *kxy,
                                                       int *idx0, int *idx1, double *ms0,
                                                       double *ms1, DMatch *matches, float *pts0, float *pts1,
-                                                      int *nmatch, const float *resid, float resid_bound, int *err) {
+                                                      int *nmatch, const float *resid_cols, float *resid, float resid_bound,
+                                                      int *err) {
   __shared__ int s_valid0[NP];
   __shared__ double s_ms0[NP];
   __shared__ int wsum[16];
+  __shared__ float wres[16];
   const int p = blockIdx.x, i = threadIdx.x;
   const int n0 = counts[2 * p], n1 = counts[2 * p + 1];
   const int *a0 = mi0 + (size_t)p * NP, *a1 = mi1 + (size_t)p * NP;
@@ -596,11 +601,27 @@ __global__ void __launch_bounds__(1024) decode_kernel(const int *counts, const i
     pts1[((size_t)p * NP + pos) * 2 + 1] = k1[2 * my0 + 1];
   }
   if (i == 0) nmatch[p] = total;
-  // integrity of the pair's Sinkhorn result (argmax_kernel, RESID): above the bound (or not a number) the launch is reported
-  // like a give-up -- err[0] = 2 unless a give-up (1) is already there, err[2..3] = the pairs -- and the host redoes the tail
-  if (i == 0 && resid && !(resid[p] <= resid_bound)) {
-    atomicCAS(err, 0, 2);
-    atomicOr(err + 2 + (p >> 5), 1 << (p & 31));
+  // integrity of the pair's Sinkhorn result (argmax_kernel, RESID): the largest column residual of the pair (a NaN wins: the
+  // comparisons below are written so); above the bound the launch is reported like a give-up -- err[0] = 2 unless a give-up (1)
+  // is already there, err[2..3] = the pairs -- and the host redoes the tail
+  if (resid_cols) {
+    float r = (i < n1) ? resid_cols[(size_t)p * NP + i] : 0.0f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float o = __shfl_xor(r, d, 64);
+      r = (o > r || o != o) ? o : r;
+    }
+    if ((i & 63) == 0) wres[i >> 6] = r;
+    __syncthreads();
+    if (i == 0) {
+      float m = wres[0];
+      for (int w = 1; w < 16; ++w) m = (wres[w] > m || wres[w] != wres[w]) ? wres[w] : m;
+      resid[p] = m;
+      if (!(m <= resid_bound)) {
+        atomicCAS(err, 0, 2);
+        atomicOr(err + 2 + (p >> 5), 1 << (p & 31));
+      }
+    }
   }
 }
 
@@ -676,21 +697,22 @@ int launch_sinkhorn(const int *counts, const float *C, const float *Ct, float *u
 int launch_decode(const int *counts, const float *C, const float *Ct, const float *u, const float *v, double thresh,
                   const float *kxy, int *mi0, float *mv0, int *mi1, float *mv1,
                   int *idx0, int *idx1, double *ms0, double *ms1, void *matches, float *pts0, float *pts1,
-                  int *nmatch, float *Zout, int *gflags, float gz, float *resid, float resid_bound, int *err, int P, hipStream_t st) {
+                  int *nmatch, float *Zout, int *gflags, float gz, float *resid_cols, float *resid, float resid_bound, int *err, int P,
+                  hipStream_t st) {
   const dim3 grid((NP + 1 + 3) / 4, P), block(256);
   const float log_thr = thresh > 0.0 ? (float)log(thresh) : -FLT_MAX;
   if (gflags) {
     hipLaunchKernelGGL((argmax_kernel<true, true, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
-    hipLaunchKernelGGL((argmax_kernel<false, true, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid);
-  } else if (resid) {
+    hipLaunchKernelGGL((argmax_kernel<false, true, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid_cols);
+  } else if (resid_cols) {
     hipLaunchKernelGGL((argmax_kernel<true, false, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
-    hipLaunchKernelGGL((argmax_kernel<false, false, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid);
+    hipLaunchKernelGGL((argmax_kernel<false, false, true>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, resid_cols);
   } else {
     hipLaunchKernelGGL((argmax_kernel<true, false, false>), grid, block, 0, st, counts, C, u, v, mi0, mv0, Zout, gflags, gz, log_thr, (float *)nullptr);
     hipLaunchKernelGGL((argmax_kernel<false, false, false>), grid, block, 0, st, counts, Ct, u, v, mi1, mv1, (float *)nullptr, gflags, gz, log_thr, (float *)nullptr);
   }
   hipLaunchKernelGGL(decode_kernel, dim3(P), dim3(1024), 0, st, counts, mi0, mv0, mi1, thresh, kxy, idx0,
-                     idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch, (const float *)resid, resid_bound, err);
+                     idx1, ms0, ms1, (DMatch *)matches, pts0, pts1, nmatch, (const float *)resid_cols, resid, resid_bound, err);
   URF_HIP(hipGetLastError());
   return 0;
 }
