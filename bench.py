@@ -163,7 +163,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
     assert fs.build(spb, sgb), U._lib.lib().urf_last_error()
     NB_ = 5
     fr = np.stack(synth.shift_stream(100, NB_ * batch, Hh, Ww))
-    depth = 2 + 3                        # matchers + 3 batches stay in flight behind a submit (include/urf.h)
+    depth = 2 + 4                        # matchers + 4 batches stay in flight behind a submit (include/urf.h)
     got = {}
     nsub = [0]
 
@@ -195,7 +195,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
     out = {"frames_per_s": round(steps * batch / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": batch, "steps": steps,
            "regions_frames_per_s": [round(steps * batch / r, 2) for r in regions],
            "what": "urf_fe_submit (host u8 frames: pinned staging + PCIe inside the timed region) / urf_fe_collect (host DMatch lists), "
-                   "two matcher handles, matchers + 3 batches in flight, batches handed out as soon as they are final"}
+                   "two matcher handles, matchers + 4 batches in flight, batches handed out as soon as they are final"}
     if kept_ref is not None:
         # batch index of lists[i] in the stream: warm-up batches came first; the stream is periodic in NB_ batches (the first
         # frame of a batch is matched against the last frame of the previous one, so from batch 1 on the lists repeat)
@@ -313,8 +313,11 @@ def main():
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
                       device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
+    # (N ranks: the gather of a batch's lists is fixed one step after its fetch has begun -- no step to spare for a redo that
+    # waits in the shared engine's pool for the next batch's flagged pairs: urf_sg_config.redo_merge = -1)
+    REDO_MERGE = -1 if world > 1 else int(os.environ.get("URF_BENCH_REDO_MERGE", "0"))
     pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank,
-                         precision=PREC, sinkhorn_iterations=SINK_ITERS)
+                         precision=PREC, sinkhorn_iterations=SINK_ITERS, redo_merge=REDO_MERGE)
     assert pm.build(sgb), U._lib.lib().urf_last_error()
 
     # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
@@ -347,7 +350,7 @@ def main():
     pms = [pm]
     for _ in range(MATCHERS - 1):
         pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                               device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS)
+                               device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS, redo_merge=REDO_MERGE)
         assert pm_b.build(sgb), U._lib.lib().urf_last_error()
         pms.append(pm_b)
 

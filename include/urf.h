@@ -196,6 +196,15 @@ typedef struct {
    * never.  Costs one exact pass per measured batch, once; reported on stderr.  Above 2.5e-3 a strict handle redoes EVERY pair
    * in the exact mode (still the oracle's lists, at the exact mode's speed) and says so. */
   int calibrate_pairs;
+  /* the redo engine of a strict handle (appended; all-zero = defaults).  Strict handles of one device that were built from the
+   * same weights with the same configuration SHARE one engine (a pipeline's two matcher handles, the matchers of a urf_fe), and
+   * the flagged pairs of consecutive batches -- which sit on different handles -- go through it in one pass: a batch's redo waits
+   * in the pool for the next urf_pm_fetch_begin of any sharing handle (one step of the loop) and is launched together with that
+   * batch's flagged pairs, or alone when there are none -- or at once when somebody asks for it (urf_pm_fetch_ready / _end).
+   * redo_merge < 0: launch every batch's redo at its own fetch_begin (round 4's behaviour); redo_private_engine != 0: an
+   * engine of this handle's own (48 MB of weights and an arena more). */
+  int redo_merge;
+  int redo_private_engine;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -376,6 +385,9 @@ int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n);
  * 0 = the pair's match set is the exact pipeline's; bit 0 = a best assignment within the margin of the threshold,
  * bit 1 = within the margin of its runner-up */
 int urf_pm_near_tie_flags(urf_pm *h, int *flags, int P);
+/* the redo engine this handle uses (strict mode): out[0] = passes it has run (for all the handles that share it), out[1] = pairs
+ * through them, out[2] = passes that served more than one batch, out[3] = handles sharing the engine (n <= 4 values) */
+int urf_pm_redo_engine_stats(urf_pm *h, double *out, int n);
 /* guarded fast mode: measure the fast matcher against the exact matcher on P pairs of device slots (as urf_match_device takes
  * them) -- the largest difference of the two log-assignment matrices over the entries a decision can rest on (probability above
  * 0.1 in either) -- and widen the handle's margin to 1.1 x (that + 2.4e-4, the share of the fast SuperPoint's descriptor noise)
@@ -455,11 +467,11 @@ int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols);
  * ref: NULL or n global frame indices (counted from the first submitted frame): frame j is matched
  * against frame ref[j] (-1 = its predecessor) -- the reference matches against the last keyframe
  * (src/tracking.cc:196-203).  A referenced frame must be in this batch or in one of the
- * 2 + history_batches batches before it.  At most `matchers` + 4 batches may be in flight: a submit enqueues its
+ * 2 + history_batches batches before it.  At most `matchers` + 5 batches may be in flight: a submit enqueues its
  * own SuperPoint, the match call of the batch two submits back and begins the fetch of the batch `matchers` + 1 submits
  * back (the only wait, for that batch's fast pass; a strict handle's exact redo of flagged pairs then runs beside the
  * next batches) -- the loop bench.py times, driven by the caller:
- *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 3 || urf_fe_ready() == 1) urf_fe_collect(...);
+ *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 4 || urf_fe_ready() == 1) urf_fe_collect(...);
  * A caller that collects right after every submit gets the synchronous behaviour (collect enqueues what is missing). */
 int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step, size_t frame_stride,
                   const long *ref);

@@ -643,14 +643,14 @@ def _as_tuples(m):
     return [(int(q), int(t), float(d)) for q, t, d in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
 
 
-@pytest.mark.parametrize("prec,depth", [(0, 3), (1, 3), (2, 3), (3, 3), (3, 6), (3, 1)])
+@pytest.mark.parametrize("prec,depth", [(0, 3), (1, 3), (2, 3), (3, 3), (3, 7), (3, 1)])
 def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_blob, sg_blob, prec, depth):
     """urf_fe (batches, device-resident slots, 3 streams, ragged last batch) == the reference's loop
     SuperPoint::infer(frame) ; PointMatching::MatchingPoints(features_prev, features, matches, true)
     (src/tracking.cc:321-377) as the CPU ORACLE runs it: O.sp_infer / O.match_points on the same 21 frames.
     Exact mode: features and match lists bit for bit; fast modes: the same keypoint sets, and correspondences that may differ
     in a pair whose decisive matching scores are a near-tie (measured on this stream: one pair of twenty differs in two of its
-    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 6 = matchers + 4 is the pipelined loop
+    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 7 = matchers + 5 is the pipelined loop
     bench.py times (SuperPoint two batches ahead of the matchers, fetches begun one step before they are ended), 1 = a collect
     right after every submit (integration/tracking.patch)."""
     from conftest import oracle_frames_and_pairs
@@ -728,16 +728,16 @@ def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg
     assert fs.in_flight() == 0                          # a rejected submit enqueues nothing
     fs.submit(frames[0:4], ref=[-1, -1, -1, 9])         # ... and leaves the stream usable
     assert _as_tuples(fs.collect()[1][3]) == olists[11]
-    # matchers + 4 batches may be in flight (SuperPoint two ahead of the matchers, one batch begun, two waiting to be handed out)
-    for _ in range(6):
+    # matchers + 5 batches may be in flight (SuperPoint two ahead of the matchers, one batch begun, three waiting to be handed out)
+    for _ in range(7):
         fs.submit(frames[4:8])
     with pytest.raises(RuntimeError, match="in flight"):
         fs.submit(frames[4:8])
-    assert fs.in_flight() == 6
+    assert fs.in_flight() == 7
     n = 0
     while fs.in_flight():
         n += len(fs.collect()[1])
-    assert n == 24
+    assert n == 28
 
 
 def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg_blob):

@@ -32,7 +32,7 @@ for (H, W) in sizes:
                                  sinkhorn_residual_bound=float(os.environ.get("URF_SOAK_RESID_BOUND", "0")))
             assert pm.build(sgb)
             pms.append(pm)
-        pipe = P.SlotRingPipeline(sp, pms, d_frames, 8, H, W, device=dev, defer=int(os.environ.get('URF_BENCH_DEFER', '2')), sp_ahead=int(os.environ.get('URF_BENCH_SP_AHEAD', '2')))
+        pipe = P.SlotRingPipeline(sp, pms, d_frames, 8, H, W, device=dev, defer=int(os.environ.get('URF_BENCH_DEFER', '3')), sp_ahead=int(os.environ.get('URF_BENCH_SP_AHEAD', '2')))
         pipe.prologue()
         lists, slots = {}, {}
         bad = [0]

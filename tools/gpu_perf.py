@@ -76,7 +76,7 @@ for with_cam in (False, True):
         ta = time.perf_counter()
         fs.submit(frames_h[k * B:(k + 1) * B])
         tb = time.perf_counter()
-        while fs.in_flight() > 5 or (fs.in_flight() and fs.ready()):     # the loop of include/urf.h: matchers + 3 stay in flight
+        while fs.in_flight() > 6 or (fs.in_flight() and fs.ready()):     # the loop of include/urf.h: matchers + 4 stay in flight
             fs.collect()
         t_sub += tb - ta
         t_col += time.perf_counter() - tb

@@ -26,7 +26,7 @@ SYMBOLS = [
     "urf_fe_collect", "urf_fe_in_flight", "urf_fe_ready", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
-    "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_guard_state", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_group_start", "urf_comm_group_end", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
+    "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_guard_state", "urf_pm_redo_engine_stats", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_group_start", "urf_comm_group_end", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
     "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_pm_sinkhorn_integrity", "urf_pm_sinkhorn_residuals",
     "urf_sg_debug_couplings", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
 ]
@@ -49,7 +49,8 @@ class SGConfig(C.Structure):
                 ("ransac_iterations", C.c_int), ("ransac_sigma", C.c_float), ("ransac_seed", C.c_uint32),
                 ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
                 ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int),
-                ("sinkhorn_residual_bound", C.c_float), ("calibrate_pairs", C.c_int)]
+                ("sinkhorn_residual_bound", C.c_float), ("calibrate_pairs", C.c_int), ("redo_merge", C.c_int),
+                ("redo_private_engine", C.c_int)]
 
 
 class EpiConfig(C.Structure):

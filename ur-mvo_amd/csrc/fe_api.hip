@@ -78,11 +78,11 @@ extern "C" int urf_fe_create(const urf_fe_config *cfg, urf_fe **out) {
   h->B = cfg->batch;
   h->M = cfg->matchers <= 0 ? 2 : (cfg->matchers > kMaxMatchers ? kMaxMatchers : cfg->matchers);
   // ring: entry k is refilled by SuperPoint(b) while every batch up to b - M - 2 has had its fetch begun (its fast pass is over)
-  // and a match reads slots up to 2 + history_batches submits old (NB >= M + 4 + history_batches); up to M + 4 batches are in
-  // flight -- the oldest may wait for its redo one step longer than the loop needs it to (the hand-out lag of DESIGN.md
-  // section 12: one step of lag is worth 8 %, the second steadies it) -- and an entry is not refilled before its batch has been
-  // collected: NB = M + 5 + history_batches
-  h->NB = h->M + 5 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
+  // and a match reads slots up to 2 + history_batches submits old (NB >= M + 4 + history_batches); up to M + 5 batches are in
+  // flight -- a flagged batch's redo waits one step in the shared engine's pool for the next batch's flagged pairs, then runs
+  // for about two (the hand-out lag of DESIGN.md section 12) -- and an entry is not refilled before its batch has been
+  // collected: NB = M + 6 + history_batches
+  h->NB = h->M + 6 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
   // a strict matcher promises the oracle's lists only on slots an exact SuperPoint made (include/urf.h): a configuration that
   // asks for precision 3 on one side alone would get a 2.2e-4 margin on noisy descriptors -- neither strict nor guarded
   if (cfg->sg.precision == 3 && (cfg->sp.precision == 1 || cfg->sp.precision == 2)) {
@@ -222,13 +222,13 @@ static int fe_pump(urf_fe *h) {
 
 // Would the NEXT urf_fe_submit accept global frame `frame` as a reference?  The same test submit applies to a reference
 // outside its own batch: the frame sits in a ring entry that is not the one about to be refilled and is at most
-// NB - M - 3 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
+// NB - M - 4 = 2 + history_batches SUBMITS old (batches are ragged -- a live queue usually holds one or two frames per
 // drain --, so the window cannot be derived from a frame count; integration/tracking.patch asks here).
 static const uint8_t *fe_resident_slot(urf_fe *h, long want) {
   const long b = h->next_batch;
   const int k = (int)(b % h->NB);
   for (int e = 0; e < h->NB; ++e)
-    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 3) && want >= h->batch_first[e] &&
+    if (e != k && h->batch_id[e] >= 0 && h->batch_id[e] >= b - (h->NB - h->M - 4) && want >= h->batch_first[e] &&
         want < h->batch_first[e] + h->batch_n[e])
       return slot_ptr(h, e, (int)(want - h->batch_first[e]));
   return nullptr;
@@ -247,7 +247,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
                              size_t frame_stride, const long *ref) {
   URF_CHECK(h && h->built, "urf_fe_submit: handle is not built");
   URF_CHECK(frames && n >= 1 && n <= h->B && rows > 0 && cols > 0 && step >= (size_t)cols, "urf_fe_submit: bad argument");
-  URF_CHECK((int)h->pending.size() <= h->M + 3, "urf_fe_submit: %d batches in flight, collect one first", h->M + 4);
+  URF_CHECK((int)h->pending.size() <= h->M + 4, "urf_fe_submit: %d batches in flight, collect one first", h->M + 5);
   URF_HIP(hipSetDevice(h->cfg.sp.device));
   if (!h->d_raw) {
     h->rows = rows; h->cols = cols;
@@ -273,7 +273,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
     if (want >= h->frames_seen) {
       src = slot_ptr(h, k, (int)(want - h->frames_seen));   // an earlier frame of this batch
     } else {
-      // window = the last NB - M - 3 batches: an older ring entry may be refilled by SuperPoint while
+      // window = the last NB - M - 4 batches: an older ring entry may be refilled by SuperPoint while
       // this batch's matcher (up to M + 1 submits behind) still reads it; entry k is being refilled now
       src = fe_resident_slot(h, want);
     }

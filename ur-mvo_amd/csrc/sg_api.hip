@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 namespace urf {
@@ -45,6 +46,7 @@ int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float
                   double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
                   uint8_t *inliers, float *Fbest, float *best_score, int P, hipStream_t st);
 
+struct RedoPool;
 constexpr int NP = kCap, LDC = 1028, SG_LAYERS = 18;
 enum { PT_PREP = 0, PT_KENC, PT_GNN, PT_SCORE, PT_SINKHORN, PT_DECODE, PT_RANSAC, PT_COUNT };
 // stage_ms[PT_COUNT] additionally reports the attention kernels' share of PT_GNN
@@ -162,7 +164,15 @@ struct urf_pm {
   // For that the result buffers exist three times (fm_set / nf_set on the device, hm_set / hn_set pinned): a handle may hold
   // TWO batches whose fetch has begun (their redos run, in order, on the engine) while a third is being computed; `fmatches` /
   // `nfinal` / `h_matches` / `h_n` alias the set of the batch enqueued last.
-  urf_pm *redo = nullptr;
+  // Round 5: the engine belongs to a POOL that the strict handles of a device share when they were built from the same weights
+  // with the same configuration (a pipeline's two matcher handles, the matchers of a urf_fe): one engine instead of one per
+  // handle, and the flagged pairs of CONSECUTIVE batches -- which sit on different handles -- go through it in ONE pass: a pass
+  // over three pairs costs 5.5 ms of kernel time, passes over two and over one 4.1 + 3.8 (profiles/r05_redo_chain_alone.txt).
+  // A batch's job waits in the pool until the next fetch_begin of ANY sharing handle (one step of the loop) and is launched
+  // together with that batch's job, if it has one -- or as soon as somebody asks for it (fetch_ready, fetch_end).
+  struct urf::RedoPool *pool = nullptr;
+  bool redo_merge = true;            // a job waits one step in the pool for a companion (urf_sg_config.redo_merge)
+  urf_pm *redo = nullptr;            // = pool->engine (borrowed)
   static constexpr int kSets = 3, kBegun = 2;
   urf_dmatch *fm_set[kSets] = {nullptr, nullptr, nullptr}, *hm_set[kSets] = {nullptr, nullptr, nullptr};
   int *nf_set[kSets] = {nullptr, nullptr, nullptr}, *hn_set[kSets] = {nullptr, nullptr, nullptr};
@@ -170,6 +180,8 @@ struct urf_pm {
   // batches whose fetch has begun (urf_pm_fetch_begin) and not ended, oldest first
   struct Begun {
     int P = 0, set = 0, n = 0;       // pairs, result set, pairs being redone (0: the lists were final at begin)
+    bool launched = false;           // the entry's redo pass has been enqueued on the engine's stream (else it waits in the pool)
+    bool want_Z = false, ransac = false;   // of the batch (a pass takes jobs that agree on them)
     int idx[64];                     // slot k of the engine = pair idx[k] of the batch
     float resid[64];                 // the batch's Sinkhorn residuals (urf_pm_sinkhorn_residuals)
     int flags[64];                   // the batch's guard words and stage times: what urf_pm_near_tie_flags / urf_pm_stage_ms
@@ -193,6 +205,30 @@ struct urf_pm {
   float calib_worst = 0.0f;
   bool redo_all = false;           // the measured error is above the cap: a strict handle redoes every pair in the exact mode
 };
+
+namespace urf {
+// The shared redo engine of the strict handles of one device (see urf_pm::pool).
+struct RedoPool {
+  std::mutex mu;
+  int refs = 0;
+  int device = 0, maxP = 0;
+  unsigned long long blob_hash = 0;
+  urf_sg_config key{};               // the engine's configuration (what a redo computes depends on all of it)
+  urf_pm *engine = nullptr;
+  struct Job { urf_pm *owner; int entry; };
+  std::vector<Job> queue;            // staged (inputs copied on the owner's stream, event recorded), not launched yet
+  unsigned long long passes = 0, pairs = 0, merged_passes = 0;   // statistics: engine passes, pairs through them, passes that took more than one job
+};
+static std::mutex g_pools_mu;
+static std::vector<RedoPool *> g_pools;
+// what a redo computes depends on every one of these (field by field: the structs' padding bytes are nobody's)
+static bool same_engine_config(const urf_sg_config &a, const urf_sg_config &b) {
+  return a.image_width == b.image_width && a.image_height == b.image_height && a.matching_threshold == b.matching_threshold &&
+         a.sinkhorn_iterations == b.sinkhorn_iterations && a.max_pairs == b.max_pairs && a.device == b.device &&
+         a.ransac_iterations == b.ransac_iterations && a.ransac_sigma == b.ransac_sigma && a.ransac_seed == b.ransac_seed &&
+         a.ransac_threshold_px == b.ransac_threshold_px && a.ransac_confidence == b.ransac_confidence && a.outlier_stage == b.outlier_stage;
+}
+}  // namespace urf
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 template <typename T>
@@ -411,6 +447,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // environment: they decide what the handle guarantees
     h->g_z = h->cfg.guard_margin > 0.0f ? h->cfg.guard_margin : (h->strict ? kGuardSgZStrict : kGuardSgZ);
     h->redo_pairs = h->cfg.redo_flagged_pairs != 0 ? (h->cfg.redo_flagged_pairs > 0) : (h->strict ? 1 : 0);
+    h->redo_merge = h->cfg.redo_merge >= 0;
+    if (const char *e = urf::exp_env("URF_REDO_MERGE")) h->redo_merge = atoi(e) != 0;   // (experiments build: A/B)
     if (const char *e = urf::exp_env("URF_REDO_OFF"); e && atoi(e) != 0) h->redo_pairs = 0;   // what-if timing runs (experiments build): results are NOT strict
     URF_CHECK(P <= 64, "guarded fast mode: max_pairs %zu above 64", P);
     memset(h->last_flags, 0, sizeof(h->last_flags));
@@ -496,17 +534,46 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // the redo engine (see urf_pm::redo): an exact-mode handle with the same configuration and weights, on THIS handle's stream
     urf_sg_config rc = h->cfg;
     rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
-    if (urf_pm_create(&rc, &h->redo)) return -1;
-    h->redo->is_engine = true;
-    if (urf_pm_build(h->redo, blob, n_floats)) return -1;
+    rc.calibrate_pairs = 0; rc.sinkhorn_residual_bound = 0.0f; rc.redo_merge = 0; rc.redo_private_engine = 0;
+    // FNV-1a over the weights: handles built from the same blob with the same configuration share one engine
+    unsigned long long hash = 1469598103934665603ull;
+    for (size_t i = 0; i < n_floats; ++i) {
+      unsigned w;
+      memcpy(&w, blob + i, 4);
+      hash = (hash ^ w) * 1099511628211ull;
+    }
+    const bool share = h->cfg.redo_private_engine == 0 && !urf::exp_env("URF_REDO_PRIVATE");
+    urf::RedoPool *pool = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(urf::g_pools_mu);
+      if (share)
+        for (urf::RedoPool *q : urf::g_pools)
+          if (q->device == h->device && q->maxP == h->maxP && q->blob_hash == hash && urf::same_engine_config(q->key, rc)) { pool = q; break; }
+      if (pool) {
+        std::lock_guard<std::mutex> l2(pool->mu);
+        pool->refs += 1;
+      }
+    }
+    if (!pool) {
+      pool = new urf::RedoPool();
+      pool->device = h->device; pool->maxP = h->maxP; pool->blob_hash = hash; pool->key = rc; pool->refs = 1;
+      if (urf_pm_create(&rc, &pool->engine)) { delete pool; return -1; }
+      pool->engine->is_engine = true;
+      if (urf_pm_build(pool->engine, blob, n_floats)) { urf_pm_destroy(pool->engine); delete pool; return -1; }
+      if (const char *e = urf::exp_env("URF_REDO_PRIORITY")) {   // experiments build: the engine's stream at another priority
+        (void)hipStreamDestroy(pool->engine->st);
+        URF_HIP(hipStreamCreateWithPriority(&pool->engine->st, hipStreamNonBlocking, atoi(e)));
+      }
+      if (share) {
+        std::lock_guard<std::mutex> lock(urf::g_pools_mu);
+        urf::g_pools.push_back(pool);
+      }
+    }
+    h->pool = pool;
+    h->redo = pool->engine;
     for (int k = 0; k < urf_pm::kBegun; ++k)
       if (dalloc(&h->bq[k].counts, NI) || dalloc(&h->bq[k].kxy, NI * NP * 2) || dalloc(&h->bq[k].x, NI * NP * 256)) return -1;
     URF_HIP(hipDeviceSynchronize());
-    if (const char *e = urf::exp_env("URF_REDO_PRIORITY")) {   // experiments build: the engine's stream at another priority
-      (void)hipStreamDestroy(h->redo->st);
-      URF_HIP(hipStreamCreateWithPriority(&h->redo->st, hipStreamNonBlocking, atoi(e)));
-    }
-
   }
   return 0;
 }
@@ -520,9 +587,30 @@ extern "C" int urf_pm_build_file(urf_pm *h, const char *path) {
 extern "C" void urf_pm_destroy(urf_pm *h) {
   if (!h) return;
   if (h->built && h->st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->st); }
-  if (h->built && h->redo && h->redo->built) (void)hipStreamSynchronize(h->redo->st);   // (a redo still running)
-  urf_pm_destroy(h->redo);
-  h->redo = nullptr;
+  if (h->pool) {
+    urf::RedoPool *pool = h->pool;
+    bool last = false;
+    {
+      std::lock_guard<std::mutex> registry(urf::g_pools_mu);   // (the order of urf_pm_build: registry, then pool)
+      {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        for (size_t i = 0; i < pool->queue.size();)      // this handle's jobs that were never launched go with it
+          if (pool->queue[i].owner == h) pool->queue.erase(pool->queue.begin() + (long)i); else ++i;
+        if (pool->engine && pool->engine->built) (void)hipStreamSynchronize(pool->engine->st);   // (a pass that still writes into this handle's sets)
+        pool->refs -= 1;
+        last = pool->refs == 0;
+      }
+      if (last)
+        for (size_t i = 0; i < urf::g_pools.size(); ++i)
+          if (urf::g_pools[i] == pool) { urf::g_pools.erase(urf::g_pools.begin() + (long)i); break; }
+    }
+    if (last) {
+      urf_pm_destroy(pool->engine);
+      delete pool;
+    }
+    h->pool = nullptr;
+    h->redo = nullptr;
+  }
   if (h->built) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->st);
@@ -804,11 +892,83 @@ static int pm_tail(urf_pm *h, int P, bool want_Z, bool ransac, bool prof, bool f
 // runs over those n pairs on its own stream; its lists replace the fast ones in the batch's result set (device and pinned
 // mirror) -- and, for the one-pair host calls, its index vectors, scores and log-assignment those of this handle.
 // pm_begin_batch pushes the batch onto the begun queue and returns 1 when a redo was started for it, 0 when its lists are final.
+// Launch what waits in the pool (its mutex is held): passes over as many jobs as the engine has room for and that agree on the
+// batch's options; slot k0 .. k0 + n - 1 of the engine = the job's flagged pairs.
+static int pool_flush(urf::RedoPool *pool) {
+  urf_pm *r = pool->engine;
+  URF_CHECK(r && r->built, "the redo engine is not built");
+  hipStream_t st = r->st;
+  while (!pool->queue.empty()) {
+    std::vector<urf::RedoPool::Job> pass;
+    int N = 0;
+    const urf_pm::Begun &first = pool->queue.front().owner->bq[pool->queue.front().entry];
+    for (size_t i = 0; i < pool->queue.size();) {
+      const urf::RedoPool::Job j = pool->queue[i];
+      const urf_pm::Begun &e = j.owner->bq[j.entry];
+      if (e.want_Z == first.want_Z && e.ransac == first.ransac && N + e.n <= pool->maxP && (!first.want_Z || pass.empty())) {
+        pass.push_back(j);
+        N += e.n;
+        pool->queue.erase(pool->queue.begin() + (long)i);
+      } else {
+        ++i;
+      }
+    }
+    int k0 = 0;
+    for (const auto &j : pass) {
+      urf_pm::Begun &e = j.owner->bq[j.entry];
+      URF_HIP(hipStreamWaitEvent(st, e.ev_in, 0));
+      URF_HIP(hipMemcpyAsync(r->counts + 2 * k0, e.counts, (size_t)2 * e.n * sizeof(int), hipMemcpyDeviceToDevice, st));
+      URF_HIP(hipMemcpyAsync(r->kxy + (size_t)2 * k0 * NP * 2, e.kxy, (size_t)2 * e.n * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+      URF_HIP(hipMemcpyAsync(r->x + (size_t)2 * k0 * NP * 256, e.x, (size_t)2 * e.n * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
+      k0 += e.n;
+    }
+    // the exact layers, the final projection and the tail over N pairs (grids sized for N, not for a batch)
+    if (pm_gnn_exact(r, 2 * N, false)) return -1;
+    if (sg_linear(r, 2 * N, r->x, 256, 256, nullptr, 0, 0, r->wf, r->bf, 256, r->mdesc, 256, false, nullptr)) return -1;
+    r->last_P = N; r->last_Z = first.want_Z; r->last_ransac = first.ransac;
+    if (pm_tail(r, N, first.want_Z, first.ransac, false, false)) return -1;
+    k0 = 0;
+    for (const auto &j : pass) {
+      urf_pm *h = j.owner;
+      urf_pm::Begun &e = h->bq[j.entry];
+      const int set = e.set;
+      for (int k = 0; k < e.n; ++k) {
+        const int p = e.idx[k], q = k0 + k;
+        URF_HIP(hipMemcpyAsync(h->nf_set[set] + p, r->nfinal + q, sizeof(int), hipMemcpyDeviceToDevice, st));
+        URF_HIP(hipMemcpyAsync(h->fm_set[set] + (size_t)p * NP, r->fmatches + (size_t)q * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
+        URF_HIP(hipMemcpyAsync(h->hn_set[set] + p, r->nfinal + q, sizeof(int), hipMemcpyDeviceToHost, st));
+        URF_HIP(hipMemcpyAsync(h->hm_set[set] + (size_t)p * NP, r->fmatches + (size_t)q * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, st));
+      }
+      if (e.P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
+        URF_HIP(hipMemcpyAsync(h->idx0, r->idx0 + (size_t)k0 * NP, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
+        URF_HIP(hipMemcpyAsync(h->idx1, r->idx1 + (size_t)k0 * NP, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
+        URF_HIP(hipMemcpyAsync(h->ms0, r->ms0 + (size_t)k0 * NP, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+        URF_HIP(hipMemcpyAsync(h->ms1, r->ms1 + (size_t)k0 * NP, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (e.want_Z) URF_HIP(hipMemcpyAsync(h->Z, r->Z + (size_t)k0 * (NP + 1) * LDC, (size_t)(NP + 1) * LDC * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+      URF_HIP(hipEventRecord(e.ev_done, st));
+      e.launched = true;
+      k0 += e.n;
+    }
+    pool->passes += 1;
+    pool->pairs += (unsigned long long)N;
+    pool->merged_passes += pass.size() > 1;
+  }
+  return 0;
+}
+// the entry's redo must be on the engine's stream before anybody waits for (or asks about) its event
+static int pm_ensure_launched(urf_pm *h, urf_pm::Begun &e) {
+  if (e.n == 0 || e.launched) return 0;
+  std::lock_guard<std::mutex> lock(h->pool->mu);
+  return e.launched ? 0 : pool_flush(h->pool);
+}
+
 static int pm_begin_batch(urf_pm *h) {
   URF_CHECK(h->bq_n < urf_pm::kBegun, "two batches of this handle are waiting for their urf_pm_fetch_end already");
-  urf_pm::Begun &e = h->bq[(h->bq_head + h->bq_n) % urf_pm::kBegun];
+  const int entry = (h->bq_head + h->bq_n) % urf_pm::kBegun;
+  urf_pm::Begun &e = h->bq[entry];
   const int P = h->last_P;
-  e.P = P; e.set = h->cur_set; e.n = 0;
+  e.P = P; e.set = h->cur_set; e.n = 0; e.launched = false; e.want_Z = h->last_Z; e.ransac = h->last_ransac;
   e.t0 = std::chrono::steady_clock::now();
   h->bq_n += 1;       // (rolled back below when a launch or copy of the redo fails: the entry must not stay queued half-made)
   struct Rollback { urf_pm *h; bool armed; ~Rollback() { if (armed) h->bq_n -= 1; } } rollback{h, true};
@@ -827,13 +987,18 @@ static int pm_begin_batch(urf_pm *h) {
   for (int p = 0; p < P; ++p)
     if (h->h_gflags[p] || h->redo_all) e.idx[n++] = p;
   for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
-  if (!h->redo_pairs || n == 0) { rollback.armed = false; return 0; }
-  urf_pm *r = h->redo;
-  URF_CHECK(r && r->built, "the redo engine of this handle is not built");
-  const int set = e.set;
+  urf::RedoPool *pool = h->pool;
+  if (!h->redo_pairs || !pool) { rollback.armed = false; return 0; }
+  if (n == 0) {
+    // nothing of this batch to redo: what an earlier batch (of any sharing handle) left in the pool has waited its one step
+    std::lock_guard<std::mutex> lock(pool->mu);
+    if (!pool->queue.empty() && pool_flush(pool)) return -1;
+    rollback.armed = false;
+    return 0;
+  }
   // the inputs leave this handle's buffers on its OWN stream (idle: the host has waited for the batch's fast pass), into the
-  // entry's staging: the handle's next batch, in order behind these copies, never waits for the engine -- where an earlier redo
-  // of this handle may still be running; this one queues behind it
+  // entry's staging: the handle's next batch, in order behind these copies, never waits for the engine -- where an earlier
+  // pass may still be running
   for (int k = 0; k < n; ++k) {
     const int p = e.idx[k];
     h->cause_thr += (e.flags[p] & 1) != 0;
@@ -843,32 +1008,18 @@ static int pm_begin_batch(urf_pm *h) {
     URF_HIP(hipMemcpyAsync(e.x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   }
   URF_HIP(hipEventRecord(e.ev_in, h->st));
-  hipStream_t st = r->st;
-  URF_HIP(hipStreamWaitEvent(st, e.ev_in, 0));
-  URF_HIP(hipMemcpyAsync(r->counts, e.counts, (size_t)2 * n * sizeof(int), hipMemcpyDeviceToDevice, st));
-  URF_HIP(hipMemcpyAsync(r->kxy, e.kxy, (size_t)2 * n * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  URF_HIP(hipMemcpyAsync(r->x, e.x, (size_t)2 * n * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  // the exact layers, the final projection and the tail over n pairs (grids sized for n, not for the batch)
-  if (pm_gnn_exact(r, 2 * n, false)) return -1;
-  if (sg_linear(r, 2 * n, r->x, 256, 256, nullptr, 0, 0, r->wf, r->bf, 256, r->mdesc, 256, false, nullptr)) return -1;
-  r->last_P = n; r->last_Z = h->last_Z; r->last_ransac = h->last_ransac;
-  if (pm_tail(r, n, h->last_Z, h->last_ransac, false, false)) return -1;
-  for (int k = 0; k < n; ++k) {
-    const int p = e.idx[k];
-    URF_HIP(hipMemcpyAsync(h->nf_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->fm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->hn_set[set] + p, r->nfinal + k, sizeof(int), hipMemcpyDeviceToHost, st));
-    URF_HIP(hipMemcpyAsync(h->hm_set[set] + (size_t)p * NP, r->fmatches + (size_t)k * NP, (size_t)NP * sizeof(urf_dmatch), hipMemcpyDeviceToHost, st));
-  }
-  if (P == 1) {   // the one-pair host calls read these as well (urf_sg_infer: index vectors, scores, the log-assignment)
-    URF_HIP(hipMemcpyAsync(h->idx0, r->idx0, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->idx1, r->idx1, NP * sizeof(int), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->ms0, r->ms0, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
-    URF_HIP(hipMemcpyAsync(h->ms1, r->ms1, NP * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (h->last_Z) URF_HIP(hipMemcpyAsync(h->Z, r->Z, (size_t)(NP + 1) * LDC * sizeof(float), hipMemcpyDeviceToDevice, st));
-  }
-  URF_HIP(hipEventRecord(e.ev_done, st));
   e.n = n;
+  {
+    std::lock_guard<std::mutex> lock(pool->mu);
+    const bool older = !pool->queue.empty();       // a job of the previous step is waiting: this one joins it, both go now
+    pool->queue.push_back({h, entry});
+    if ((older || !h->redo_merge) && pool_flush(pool)) {
+      for (size_t i = 0; i < pool->queue.size();)          // (this entry is rolled back: it must not stay queued)
+        if (pool->queue[i].owner == h && pool->queue[i].entry == entry) pool->queue.erase(pool->queue.begin() + (long)i); else ++i;
+      e.n = 0;
+      return -1;
+    }
+  }
   rollback.armed = false;
   return 1;
 }
@@ -878,6 +1029,7 @@ static int pm_end_batch(urf_pm *h, int *set, int *P) {
   urf_pm::Begun &e = h->bq[h->bq_head];
   h->redo_ms = 0.0f;
   if (e.n > 0) {
+    if (pm_ensure_launched(h, e)) return -1;
     URF_HIP(hipEventSynchronize(e.ev_done));
     h->pairs_redone += (unsigned long long)e.n;
     h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e.t0).count();
@@ -1247,6 +1399,17 @@ extern "C" int urf_pm_near_tie_reruns(urf_pm *h, unsigned long long *out, int n)
   return 0;
 }
 
+extern "C" int urf_pm_redo_engine_stats(urf_pm *h, double *out, int n) {
+  URF_CHECK(h && h->built && out && n >= 1, "urf_pm_redo_engine_stats: bad argument");
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (h->pool) {
+    std::lock_guard<std::mutex> lock(h->pool->mu);
+    v[0] = (double)h->pool->passes; v[1] = (double)h->pool->pairs; v[2] = (double)h->pool->merged_passes; v[3] = (double)h->pool->refs;
+  }
+  for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
+  return 0;
+}
+
 extern "C" int urf_pm_guard_state(urf_pm *h, double *out, int n) {
   URF_CHECK(h && h->built && out && n >= 1, "urf_pm_guard_state: bad argument");
   const double v[4] = {(double)h->g_z, (double)h->calib_worst, (double)h->calib_left, h->redo_all ? 1.0 : 0.0};
@@ -1345,9 +1508,10 @@ extern "C" int urf_pm_fetch_begin(urf_pm *h, int P) {
 extern "C" int urf_pm_fetch_ready(urf_pm *h) {
   URF_CHECK(h && h->built, "PointMatching handle is not built");
   URF_CHECK(h->bq_n > 0, "urf_pm_fetch_ready: no fetch has begun (urf_pm_fetch_begin first)");
-  const urf_pm::Begun &e = h->bq[h->bq_head];
+  urf_pm::Begun &e = h->bq[h->bq_head];
   if (e.n == 0) return 1;
   URF_HIP(hipSetDevice(h->device));
+  if (pm_ensure_launched(h, e)) return -1;        // (a job that waited in the pool for a companion: nobody came, it goes now)
   const hipError_t q = hipEventQuery(e.ev_done);
   if (q == hipSuccess) return 1;
   if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }

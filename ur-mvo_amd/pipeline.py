@@ -31,7 +31,7 @@ MAX_BEGUN = 2      # begun batches a PointMatching handle holds (include/urf.h: 
 
 class SlotRingPipeline:
     def __init__(self, sp, pms, d_frames, batch, H, W, *, device, rank=0, world=1, comm=None, gloo=False, overlap=2,
-                 outlier_rejection=True, keep_gathered=False, sp_ahead=2, defer=2):
+                 outlier_rejection=True, keep_gathered=False, sp_ahead=2, defer=3):
         """sp / pms: built SuperPoint / PointMatching handles on `device` (max_batch = max_pairs = batch).
         d_frames: u8 tensor [NB * batch, H, W] on the device, this rank's frames of NB consecutive global batches
         (cycled); NB >= len(pms) + 1 + sp_ahead.  comm: this rank's D.Comm (RCCL, world-of-one RCCL, or loopback) -- with it
@@ -41,8 +41,10 @@ class SlotRingPipeline:
         matcher that takes long over one batch (the strict mode's exact redo of a flagged pair: ~5 ms of dependent launches)
         does not drain SuperPoint's stream -- the critical path -- while the host waits; 1 = the round-3 loop.
         defer: how many steps the hand-out of a batch whose flagged pairs are being redone may lag (0: the host waits for
-        the redo in the step that finds it).  With the exchange the lists of batch g are shipped in step g + len(pms), which
-        bounds the lag at 1."""
+        the redo in the step that finds it).  3 since round 5: a strict handle's redo waits one step in the shared engine's pool
+        for the next batch's flagged pairs (urf_sg_config.redo_merge), then runs for about two.  With the exchange the lists of
+        batch g are shipped in step g + len(pms), which bounds the lag at 1 -- build the handles of a multi-rank pipeline with
+        redo_merge = -1."""
         self.sp, self.pms = sp, list(pms)
         self.B, self.H, self.W = int(batch), int(H), int(W)
         self.dev, self.rank, self.world = device, int(rank), int(world)
