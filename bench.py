@@ -313,11 +313,8 @@ def main():
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=MAX_KP), max_height=H, max_width=W, max_batch=BATCH,
                       device=local_rank, precision=PREC)
     assert sp.build(spb), U._lib.lib().urf_last_error()
-    # (N ranks: the gather of a batch's lists is fixed one step after its fetch has begun -- no step to spare for a redo that
-    # waits in the shared engine's pool for the next batch's flagged pairs: urf_sg_config.redo_merge = -1)
-    REDO_MERGE = -1 if world > 1 else int(os.environ.get("URF_BENCH_REDO_MERGE", "0"))
     pm = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH, device=local_rank,
-                         precision=PREC, sinkhorn_iterations=SINK_ITERS, redo_merge=REDO_MERGE)
+                         precision=PREC, sinkhorn_iterations=SINK_ITERS)
     assert pm.build(sgb), U._lib.lib().urf_last_error()
 
     # ONE synthetic stream, resident in HBM before the timed region.  Global batch k
@@ -350,7 +347,7 @@ def main():
     pms = [pm]
     for _ in range(MATCHERS - 1):
         pm_b = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=BATCH,
-                               device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS, redo_merge=REDO_MERGE)
+                               device=local_rank, precision=PREC, sinkhorn_iterations=SINK_ITERS)
         assert pm_b.build(sgb), U._lib.lib().urf_last_error()
         pms.append(pm_b)
 

@@ -196,15 +196,15 @@ typedef struct {
    * never.  Costs one exact pass per measured batch, once; reported on stderr.  Above 2.5e-3 a strict handle redoes EVERY pair
    * in the exact mode (still the oracle's lists, at the exact mode's speed) and says so. */
   int calibrate_pairs;
-  /* the redo engine of a strict handle (appended; all-zero = defaults).  Strict handles of one device that were built from the
-   * same weights with the same configuration SHARE one engine (a pipeline's two matcher handles, the matchers of a urf_fe), and
-   * the flagged pairs of consecutive batches -- which sit on different handles -- go through it in one pass: a batch's redo waits
-   * in the pool for the next urf_pm_fetch_begin of any sharing handle (one step of the loop) and is launched together with that
-   * batch's flagged pairs, or alone when there are none -- or at once when somebody asks for it (urf_pm_fetch_ready / _end).
-   * redo_merge < 0: launch every batch's redo at its own fetch_begin (round 4's behaviour); redo_private_engine != 0: an
-   * engine of this handle's own (48 MB of weights and an arena more). */
+  /* the redo engine of a strict handle (appended; all-zero = defaults: an engine of the handle's own, every batch's redo launched
+   * at its urf_pm_fetch_begin -- the fastest).  redo_shared_engine != 0: the strict handles of one device
+   * that were built from the same weights with the same configuration share ONE engine (48 MB of weights and an arena less per
+   * extra handle; 7 % slower in the benched loop: the handles' redo passes then queue on one stream).  redo_merge > 0 (shared
+   * engines only): a batch's redo waits in the engine's pool for the next urf_pm_fetch_begin of any sharing handle and goes
+   * through the engine together with that batch's flagged pairs -- fewer, larger passes; launched at once when somebody asks
+   * for it (urf_pm_fetch_ready / _end).  Measured slower still (one more step of latency). */
   int redo_merge;
-  int redo_private_engine;
+  int redo_shared_engine;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */

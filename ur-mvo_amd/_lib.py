@@ -50,7 +50,7 @@ class SGConfig(C.Structure):
                 ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
                 ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int),
                 ("sinkhorn_residual_bound", C.c_float), ("calibrate_pairs", C.c_int), ("redo_merge", C.c_int),
-                ("redo_private_engine", C.c_int)]
+                ("redo_shared_engine", C.c_int)]
 
 
 class EpiConfig(C.Structure):

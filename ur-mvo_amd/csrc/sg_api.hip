@@ -164,14 +164,17 @@ struct urf_pm {
   // For that the result buffers exist three times (fm_set / nf_set on the device, hm_set / hn_set pinned): a handle may hold
   // TWO batches whose fetch has begun (their redos run, in order, on the engine) while a third is being computed; `fmatches` /
   // `nfinal` / `h_matches` / `h_n` alias the set of the batch enqueued last.
-  // Round 5: the engine belongs to a POOL that the strict handles of a device share when they were built from the same weights
-  // with the same configuration (a pipeline's two matcher handles, the matchers of a urf_fe): one engine instead of one per
-  // handle, and the flagged pairs of CONSECUTIVE batches -- which sit on different handles -- go through it in ONE pass: a pass
-  // over three pairs costs 5.5 ms of kernel time, passes over two and over one 4.1 + 3.8 (profiles/r05_redo_chain_alone.txt).
-  // A batch's job waits in the pool until the next fetch_begin of ANY sharing handle (one step of the loop) and is launched
-  // together with that batch's job, if it has one -- or as soon as somebody asks for it (fetch_ready, fetch_end).
+  // Round 5: the engine sits in a POOL.  By default the pool is the handle's own (one engine per handle, every batch's redo
+  // launched at its fetch_begin: round 4's behaviour, and the fastest).  urf_sg_config.redo_shared_engine: the strict handles
+  // of a device that were built from the same weights with the same configuration (a pipeline's two matcher handles, the
+  // matchers of a urf_fe) share ONE engine -- 48 MB of weights and an arena less per extra handle; with redo_merge the flagged
+  // pairs of CONSECUTIVE batches, which sit on different handles, go through it in ONE pass (a pass over three pairs costs 5.5 ms
+  // of kernel time alone, passes over two and over one 4.1 + 3.8): a batch's job waits in the pool until the next fetch_begin
+  // of ANY sharing handle and is launched together with that batch's job, if it has one -- or as soon as somebody asks for it
+  // (fetch_ready, fetch_end).  Measured in the benched loop: 1118 frames/s with private engines, 1042 shared, 1026 shared and
+  // merged -- the two handles' passes must run side by side, on two streams.
   struct urf::RedoPool *pool = nullptr;
-  bool redo_merge = true;            // a job waits one step in the pool for a companion (urf_sg_config.redo_merge)
+  bool redo_merge = false;           // a job waits one step in the pool for a companion (urf_sg_config.redo_merge; shared engines only)
   urf_pm *redo = nullptr;            // = pool->engine (borrowed)
   static constexpr int kSets = 3, kBegun = 2;
   urf_dmatch *fm_set[kSets] = {nullptr, nullptr, nullptr}, *hm_set[kSets] = {nullptr, nullptr, nullptr};
@@ -447,7 +450,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // environment: they decide what the handle guarantees
     h->g_z = h->cfg.guard_margin > 0.0f ? h->cfg.guard_margin : (h->strict ? kGuardSgZStrict : kGuardSgZ);
     h->redo_pairs = h->cfg.redo_flagged_pairs != 0 ? (h->cfg.redo_flagged_pairs > 0) : (h->strict ? 1 : 0);
-    h->redo_merge = h->cfg.redo_merge >= 0;
+    h->redo_merge = h->cfg.redo_merge > 0 && h->cfg.redo_shared_engine != 0;
     if (const char *e = urf::exp_env("URF_REDO_MERGE")) h->redo_merge = atoi(e) != 0;   // (experiments build: A/B)
     if (const char *e = urf::exp_env("URF_REDO_OFF"); e && atoi(e) != 0) h->redo_pairs = 0;   // what-if timing runs (experiments build): results are NOT strict
     URF_CHECK(P <= 64, "guarded fast mode: max_pairs %zu above 64", P);
@@ -534,7 +537,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // the redo engine (see urf_pm::redo): an exact-mode handle with the same configuration and weights, on THIS handle's stream
     urf_sg_config rc = h->cfg;
     rc.precision = 0; rc.redo_flagged_pairs = 0; rc.guard_margin = 0.0f; rc.max_pairs = h->maxP;
-    rc.calibrate_pairs = 0; rc.sinkhorn_residual_bound = 0.0f; rc.redo_merge = 0; rc.redo_private_engine = 0;
+    rc.calibrate_pairs = 0; rc.sinkhorn_residual_bound = 0.0f; rc.redo_merge = 0; rc.redo_shared_engine = 0;
     // FNV-1a over the weights: handles built from the same blob with the same configuration share one engine
     unsigned long long hash = 1469598103934665603ull;
     for (size_t i = 0; i < n_floats; ++i) {
@@ -542,7 +545,8 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       memcpy(&w, blob + i, 4);
       hash = (hash ^ w) * 1099511628211ull;
     }
-    const bool share = h->cfg.redo_private_engine == 0 && !urf::exp_env("URF_REDO_PRIVATE");
+    bool share = h->cfg.redo_shared_engine != 0;           // default: an engine of the handle's own (measured: DESIGN.md section 12)
+    if (const char *e = urf::exp_env("URF_REDO_SHARED")) share = atoi(e) != 0;   // (experiments build: A/B)
     urf::RedoPool *pool = nullptr;
     {
       std::lock_guard<std::mutex> lock(urf::g_pools_mu);

@@ -181,7 +181,7 @@ PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
                  ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0,
-                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0, sinkhorn_residual_bound=0.0, calibrate_pairs=0, redo_merge=0, redo_private_engine=0):
+                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0, sinkhorn_residual_bound=0.0, calibrate_pairs=0, redo_merge=0, redo_shared_engine=0):
         """outlier stage: all-zero = the reference call's parameters (3 px, confidence 0.99, src/point_matching.cc:50);
         ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count.
         precision: 0 exact, 1 fast, 2 guarded fast (flagged pairs reported), 3 strict parity (flagged pairs redone in the
@@ -191,7 +191,7 @@ class _PM:
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
                            max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision,
                            ransac_threshold_px, ransac_confidence, redo_flagged_pairs, guard_margin, outlier_stage,
-                           sinkhorn_residual_bound, calibrate_pairs, redo_merge, redo_private_engine)
+                           sinkhorn_residual_bound, calibrate_pairs, redo_merge, redo_shared_engine)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 

@@ -41,10 +41,9 @@ class SlotRingPipeline:
         matcher that takes long over one batch (the strict mode's exact redo of a flagged pair: ~5 ms of dependent launches)
         does not drain SuperPoint's stream -- the critical path -- while the host waits; 1 = the round-3 loop.
         defer: how many steps the hand-out of a batch whose flagged pairs are being redone may lag (0: the host waits for
-        the redo in the step that finds it).  3 since round 5: a strict handle's redo waits one step in the shared engine's pool
-        for the next batch's flagged pairs (urf_sg_config.redo_merge), then runs for about two.  With the exchange the lists of
-        batch g are shipped in step g + len(pms), which bounds the lag at 1 -- build the handles of a multi-rank pipeline with
-        redo_merge = -1."""
+        the redo in the step that finds it).  3 since round 5 (2 and 3 measure the same with an engine per handle; a shared,
+        merging engine -- urf_sg_config.redo_shared_engine / redo_merge -- starts a batch's redo one step later).  With the
+        exchange the lists of batch g are shipped in step g + len(pms), which bounds the lag at 1."""
         self.sp, self.pms = sp, list(pms)
         self.B, self.H, self.W = int(batch), int(H), int(W)
         self.dev, self.rank, self.world = device, int(rank), int(world)
