@@ -730,15 +730,19 @@ def test_strict_handle_calibrates_itself_on_other_weights(U, F):
     off = F.PointMatching(F.SuperGlueConfig(), precision=3, calibrate_pairs=-1)
     assert ex.build(sgw) and st.build(sgw) and off.build(sgw)
     assert st.guard_state()["pairs_left"] == 8 and off.guard_state()["pairs_left"] == 0
-    redone = 0
+    redone, left = 0, 8
     for i, (f0, f1) in enumerate(pairs):
         want = ex.MatchingPoints(f0, f1, True)
         got = st.MatchingPoints(f0, f1, True)
         assert [(q, t) for q, t, _ in got] == [(q, t) for q, t, _ in want], i
         assert not want or max(abs(a[2] - b[2]) for a, b in zip(got, want)) < 1e-3
         g = st.guard_state()
-        assert g["pairs_left"] == max(0, 8 - (i + 1))
+        # (a pair whose resident Sinkhorn result fails the integrity bound -- these weights do that to a few per cent of random
+        # pairs -- is not measured: the calibration moves on to the next pair)
+        assert max(0, 8 - (i + 1)) <= g["pairs_left"] <= left
+        left = g["pairs_left"]
     g = st.guard_state()
+    assert g["pairs_left"] == 0
     assert g["measured"] > 0.0 and g["margin"] >= max(2.2e-4, 1.6 * g["measured"]) - 1e-9 and not g["redo_all"]
     assert abs(off.guard_state()["margin"] - 2.2e-4) < 1e-9 and off.guard_state()["measured"] == 0.0
     redone = st.near_tie_reruns()["redone"]
