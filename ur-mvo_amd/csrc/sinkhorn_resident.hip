@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (tid < RW_ROWS) pcvec[tid] = (i0 + tid < n0) ? __expf((float)(((double)alpha + u0vec[tid]) + v0d)) : 0.0f;
-    if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; }
+    if (tid == 0) { misc[0] = 1.0f; misc[1] = 0.0f; misc[3] = 0.0f; }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       pd[c] = ok[c] ? __expf((float)(((double)alpha + u0d) + v0c[c])) : 0.0f;
@@ -985,6 +985,24 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     // ---------------- row pass: a_i = mu / (sum_j P_ij b_j + pc_i b_dust); 2 x 32 wave sums, 8 partials per row through LDS
     rs_sync();                      // misc[0] of the previous iteration (or of absorb) is in place; rowpart / avec are free
     bdust = misc[0];
+    // Re-absorption out of schedule (round 5): the scalings live in fp32 between two re-absorptions, and with couplings of a large
+    // range a column scaling can run away by more than the schedule (after iterations 1, 2, 4 ... 64) allows for -- inf, then NaN
+    // (seen with weights of three times the default residual gain; the integrity word of the decode catches the result).  Every
+    // workgroup of a pair computes the same b from the same reduced column sums, so "some b has left [2^-48, 2^48]" is the same
+    // decision everywhere: the flag was raised at the end of the previous iteration, everybody reads it here, behind the barrier.
+    // The scheduled re-absorption (after iterations 1, 2, 4 ... 64) happens here as well, at the top of the NEXT iteration: the
+    // same state, one barrier less, and ONE site for both.
+    const bool scheduled = k - 1 == next_absorb;
+    if (scheduled || ((k & 3) == 1 && misc[3] != 0.0f)) {     // (the flag is looked at every fourth iteration)
+      if (scheduled) next_absorb *= 2;
+      if (tid < RW_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
+      u0d = u0d + (double)__logf(ad);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (ok[c]) v0c[c] = v0c[c] + (double)__logf(bc[c]);
+      v0d = v0d + (double)__logf(bdust);
+      absorb();
+    }
     {
       const float s0 = rs_rows32_sum([&](int r) { return fma_rn(P[0][r], bc[0], P[1][r] * bc[1]); }, lane);
       if ((lane & 1) == 0) rowpart[wv][rs_row_of_lane(lane)] = s0;
@@ -1072,19 +1090,16 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
       if (dust[c]) csum_dust = cs;
     }
     if (own_dust) misc[0] = nu_d / fma_rn(ad, Pdd, csum_dust);
-    // ---------------- re-absorb the scalings into (u0, v0) and rebuild P from the couplings
-    if (k == next_absorb && k < a.iters) {
-      next_absorb *= 2;
-      rs_sync();                    // misc[0] written
-      bdust = misc[0];
-      if (tid < RW_ROWS && i0 + tid < n0) u0vec[tid] = u0vec[tid] + (double)__logf(avec[tid]);
-      u0d = u0d + (double)__logf(ad);
+    if ((k & 3) == 0) {
+      bool far = false;             // a column scaling more than 2^48 away from 1 (exponent field of the fp32 word; 0 and inf are far)
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
-        if (ok[c]) v0c[c] = v0c[c] + (double)__logf(bc[c]);
-      v0d = v0d + (double)__logf(bdust);
-      absorb();
+      for (int c = 0; c < NC; ++c) {
+        const int e = (int)((__float_as_uint(bc[c]) >> 23) & 0xFFu) - 127;
+        far = far || (ok[c] && (e > 48 || e < -48));
+      }
+      if (__any(far) && lane == 0) misc[3] = 1.0f;
     }
+    // (the re-absorption of the scalings into (u0, v0) happens at the top of the next iteration)
   }
   // ---------------- u = u0 + log a, v = v0 + log b
   rs_sync();
