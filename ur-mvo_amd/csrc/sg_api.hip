@@ -205,7 +205,7 @@ struct urf_pm {
   bool flags_recorded = false;
   unsigned long long pairs_flagged = 0;
   // automatic calibration of the guard's margin (urf_sg_config.calibrate_pairs): pairs still to be measured, the largest difference seen
-  int calib_left = 0;
+  int calib_left = 0, calib_failures = 0;
   float calib_worst = 0.0f;
   bool redo_all = false;           // the measured error is above the cap: a strict handle redoes every pair in the exact mode
 };
@@ -1382,8 +1382,14 @@ static int pm_auto_calibrated(urf_pm *h, int P, int rc) {
   if (rc) {   // (a give-up of the resident Sinkhorn, no memory for the scratch copy): the caller's batch does not fail for it -- the next one is measured
     static bool said = false;
     if (!said) { said = true; fprintf(stderr, "liburf_front: the automatic guard calibration could not run (%s); it is tried again with the next pairs\n", urf_last_error()); }
+    if (++h->calib_failures >= 16) {   // ... but not for ever: every attempt costs a fast and an exact pass
+      h->calib_left = 0;
+      fprintf(stderr, "liburf_front: the automatic guard calibration failed %d times in a row; the handle keeps the margin %.3g (urf_pm_calibrate_guard remains)\n",
+              h->calib_failures, (double)h->g_z);
+    }
     return 0;
   }
+  h->calib_failures = 0;
   h->calib_left -= P;
   if (h->calib_left <= 0) {
     h->calib_left = 0;
