@@ -1,7 +1,7 @@
-"""Bit-equality of the attention kernel variants of the experiments build (URF_ATTN_PP=0 one-rhythm, default ping-pong):
+"""Bit-equality of the attention kernel variants of the experiments build (URF_ATTN_IL=0: the product's, 1 / 2: software-pipelined):
 runs the fast matcher (precision 1) on seeded feature pairs of ragged sizes and prints a sha256 of every pair's log-assignment
-matrix and index lists.  Run twice (URF_LIB=.../liburf_front_exp.so, URF_ATTN_PP=0 / 1) and diff the output:
-    tools/gpu_attn_pp_check.sh"""
+matrix and index lists.  Run per variant (URF_LIB=.../liburf_front_exp.so) and diff the output:
+    tools/gpu_attn_il_check.sh"""
 import hashlib
 import os
 import sys

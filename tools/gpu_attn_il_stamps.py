@@ -1,5 +1,7 @@
 """Where an iteration (one 64-key chunk) of attn_h2_il_kernel goes: s_memtime stamps of wave 0 (and wave 4) of workgroup 0 at
-MFMA gaps 0, 16, 32, 48, 64, 80, after gap 95, after the barrier.  Needs the diagnostic build (see tools/gpu_attn_pp_stamps.py)."""
+MFMA gaps 0, 16, 32, 48, 64, 80, after gap 95, after the barrier.  Needs the diagnostic build:
+    make -C ur-mvo_amd/csrc BUILD=build_stamps OUT=../liburf_front_stamps.so EXTRA="-DURF_EXPERIMENTS -DURF_ATTN_STAMPS"
+    URF_LIB=$PWD/ur-mvo_amd/liburf_front_stamps.so URF_ATTN_VARIANT=2 URF_ATTN_IL=1 python tools/gpu_attn_il_stamps.py"""
 import ctypes as C
 import os
 import sys

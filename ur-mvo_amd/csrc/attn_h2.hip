@@ -328,21 +328,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same arithmetic with the two waves of every SIMD half a chunk out of phase ("ping-pong").
-// attn_h2_kernel keeps its eight waves in ONE barrier rhythm, so both waves of a SIMD run their 96 MFMAs at the same time and
-// their softmax VALU instructions at the same time: the matrix pipe idles while the issue port is fought over, and the
-// other way round (tools/gpu_attn_stamps.py: 6 350 cycles per chunk against 3 072 of matrix-pipe time).  Here a chunk is cut
-// into two half-steps with one barrier each:
-//   M(c): O^T += V^T(c-1) P^T(c-1)  and  S^T(c) = K(c) Q^T       -- 96 MFMAs, fragment reads from LDS, next to no VALU
-//   X(c): running maximum, rescale, p = 2^(s - m), hi/lo split of P(c), row sums -- VALU only, no LDS reads
-// Every wave runs M(0) X(0) M(1) X(1) ... X(n-1) M(n); waves NW/2..NW-1 (group B; same SIMDs as waves 0..NW/2-1, a
-// workgroup's waves go to the SIMDs cyclically) start one half-step late, so in every half-step one wave of a SIMD feeds the
-// matrix pipe while the other one owns the VALU.  Per query the sequence of operations -- and therefore every bit of the
-// output -- is attn_h2_kernel's: O(c) = O(c-1) * alpha(c) + P(c) V(c), the product of chunk c-1 added before alpha(c).
-// LDS schedule (half-step h ends with a barrier): K(c) is read in h = 2c (A) and 2c+1 (B), V^T(c) in h = 2c+2 and 2c+3;
-// K(c) is loaded and committed during h = 2c-1, V^T(c) during h = 2c: two buffers each, as before.  All 512 threads stage
-// one tensor per half-step (two 16-byte pieces each) whatever their group's step is.
+#ifdef URF_EXPERIMENTS
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) (a fold, not the unroller:
@@ -354,288 +340,6 @@ __device__ __forceinline__ void static_for_impl(Fn &&f, std::integer_sequence<in
 template <int N, typename Fn>
 __device__ __forceinline__ void static_for(Fn &&f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-#ifndef URF_ATTN_PP_VR
-#define URF_ATTN_PP_VR 3     // V^T fragment ring of M: a lone wave has no second wave to hide the LDS round trip
-#endif
-
-template <int QT, int NW>
-__global__ void __launch_bounds__(64 * NW) attn_h2_pp_kernel(const _Float16 *qkh, const _Float16 *qkl,
-                                                             const _Float16 *vth, const _Float16 *vtl, const int *counts,
-                                                             int cross, _Float16 *oh, _Float16 *ol) {
-  constexpr int NT = 64 * NW, QB = 16 * QT * NW;
-  static_assert(NT == 512, "staging roles below are written for 512 threads");
-  __shared__ __attribute__((aligned(16))) _Float16 kbuf[2][2][64 * AS];
-  __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][64 * VS];
-  int qb, grp;
-  xcd_group_map(blockIdx.x, ANP / QB, (int)gridDim.x / (ANP / QB), qb, grp);
-  const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
-  const int head = grp & 3;
-  const int nq = counts[im], ns = counts[sm];
-  const int q0 = qb * QB;
-  if (q0 >= nq) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gb = wave >= NW / 2 ? 1 : 0;
-  const int px = lane & 15, g = lane >> 4;
-  const int nchunk = (ns + 63) >> 6, nfull = ns >> 6;
-
-  // staging: one tensor per half-step, a [64 rows][64 halfs] tile per plane: 256 roles (plane sp, row sr (+16u), 16-byte
-  // piece sj) x 4 rows u, two rows per thread.  K(c): row = key, source row stride 512; V^T(c): row = d, stride ANP.
-  // Plane and row group are wave-uniform, so the loads go through one buffer resource per tensor with the chunk in the
-  // scalar offset: no address arithmetic per half-step, and K rows beyond the count read as zero (num_records).
-  const int st_sp = (wave >> 1) & 1, st_u0 = (wave >> 2) * 2;
-  const int st_rl = (tid & 127) >> 3, st_sj = tid & 7;
-  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((st_sp ? qkl : qkh) + ((size_t)sm * ANP) * 512 + 256 + head * 64), 0, (unsigned)ns * 1024u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((st_sp ? vtl : vth) + ((size_t)sm * 256 + head * 64) * ANP), 0, 64u * ANP * 2u, 0x00020000);
-  const unsigned k_vo = (unsigned)(st_rl * 1024 + st_sj * 16), v_vo = (unsigned)(st_rl * (ANP * 2) + st_sj * 16);
-  _Float16 *const k_dst = &kbuf[0][st_sp][(st_rl + 16 * st_u0) * AS + 8 * st_sj];
-  _Float16 *const v_dst = &vbuf[0][st_sp][(st_rl + 16 * st_u0) * VS + 8 * st_sj];
-  u32x4 pf[2];
-  // half-step h: odd -> K((h + 1) / 2), even -> V^T(h / 2); nothing past the last chunk
-  auto stage_issue = [&](int h) __attribute__((always_inline)) {
-    const int c = (h + 1) >> 1;
-    if (c >= nchunk) return;
-    if (h & 1) {
-      const unsigned so = (unsigned)(c * 64 + 16 * st_u0) * 1024u;
-      pf[0] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, k_vo, so, 0);
-      pf[1] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, k_vo, so + 16u * 1024u, 0);
-    } else {
-      const unsigned so = (unsigned)(16 * st_u0) * (ANP * 2u) + (unsigned)c * 128u;
-      pf[0] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, v_vo, so, 0);
-      pf[1] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, v_vo, so + 16u * (ANP * 2u), 0);
-    }
-  };
-  auto stage_commit = [&](int h) __attribute__((always_inline)) {
-    const int c = (h + 1) >> 1;
-    if (c >= nchunk) return;
-    if (h & 1) {
-      _Float16 *dst = k_dst + (c & 1) * (2 * 64 * AS);
-      *(u32x4 *)dst = pf[0];
-      *(u32x4 *)(dst + 16 * AS) = pf[1];
-    } else {
-      if (c >= nfull) {      // the partial chunk: stale tokens beyond the count are zeroed (0 x NaN would not be)
-        const int key0 = c * 64 + 8 * st_sj;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f16x8 x = __builtin_bit_cast(f16x8, pf[u]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (key0 + e >= ns) x[e] = (_Float16)0.0f;
-          pf[u] = __builtin_bit_cast(u32x4, x);
-        }
-      }
-      _Float16 *dst = v_dst + (c & 1) * (2 * 64 * VS);
-      *(u32x4 *)dst = pf[0];
-      *(u32x4 *)(dst + 16 * VS) = pf[1];
-    }
-  };
-
-  f16x8 qh[QT][2], ql[QT][2];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const size_t qo = ((size_t)im * ANP + q0 + (wave * QT + t) * 16 + px) * 512 + head * 64 + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qh[t][ks] = *(const f16x8 *)(qkh + qo + 32 * ks);
-      ql[t][ks] = *(const f16x8 *)(qkl + qo + 32 * ks);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  stage_issue(-1);      // K(0)
-  stage_commit(-1);
-  __syncthreads();
-
-  float m[QT], part[QT];
-  f32x4 oacc[QT][4];
-  f32x4 s[QT][4];               // S^T(c): written by M(c), read by X(c)
-  f16x8 ph[QT][2], pl[QT][2];   // P(c) as split f16 B operands [tile][32-key step]: written by X(c), read by M(c + 1)
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    m[t] = -FLT_MAX; part[t] = 0.0f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
-
-  // ---- M(c): P V of chunk c - 1 (if any), then K Q^T of chunk c (if any)
-  auto mstep = [&](int c, auto pv_tag, auto s_tag, auto mask_tag) __attribute__((always_inline)) {
-    constexpr bool DO_PV = decltype(pv_tag)::value, DO_S = decltype(s_tag)::value, MASK = decltype(mask_tag)::value;
-    if (DO_PV) {
-      const int buf = (c - 1) & 1;
-      const _Float16 *vph = vbuf[buf][0] + px * VS + 4 * g;
-      const _Float16 *vpl = vbuf[buf][1] + px * VS + 4 * g;
-      constexpr int VR = URF_ATTN_PP_VR;
-      f16x4 vf[VR][4];     // [ring][hi keys 0-3 | hi keys 16-19 | lo keys 0-3 | lo keys 16-19]
-      auto load_v = [&](int i) __attribute__((always_inline)) {
-        const int kp = i >> 2, dt = i & 3, o = (2 * kp) * 16 + dt * 16 * VS;
-        vf[i % VR][0] = *(const f16x4 *)(vph + o); vf[i % VR][1] = *(const f16x4 *)(vph + o + 16);
-        vf[i % VR][2] = *(const f16x4 *)(vpl + o); vf[i % VR][3] = *(const f16x4 *)(vpl + o + 16);
-      };
-#pragma unroll
-      for (int i = 0; i + 1 < VR; ++i) load_v(i);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kp = i >> 2, dt = i & 3;
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + VR - 1 < 8) load_v(i + VR - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        f16x8 ah, al;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ah[e] = vf[i % VR][0][e]; ah[4 + e] = vf[i % VR][1][e]; al[e] = vf[i % VR][2][e]; al[4 + e] = vf[i % VR][3][e]; }
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[t][kp], oacc[t][dt], 0, 0, 0);
-          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pl[t][kp], oacc[t][dt], 0, 0, 0);
-          oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ph[t][kp], oacc[t][dt], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (DO_S) {
-      const int buf = c & 1;
-      const _Float16 *kph = kbuf[buf][0] + px * AS + 8 * g;
-      const _Float16 *kpl = kbuf[buf][1] + px * AS + 8 * g;
-      f16x8 kf[2][2][2];   // [ring][ks][plane]
-      auto load_k = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          kf[kt & 1][ks][0] = *(const f16x8 *)(kph + kt * 16 * AS + 32 * ks);
-          kf[kt & 1][ks][1] = *(const f16x8 *)(kpl + kt * 16 * AS + 32 * ks);
-        }
-      };
-      load_k(0);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        if (kt + 1 < 4) load_k(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[QT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const f16x8 ah = kf[kt & 1][ks][0], al = kf[kt & 1][ks][1];
-#pragma unroll
-          for (int t = 0; t < QT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t][ks], ks == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[t][ks], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t][ks], acc[t], 0, 0, 0);
-          }
-        }
-        const int kb0 = c * 64 + kt * 16 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          if (MASK) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = (kb0 + r < ns) ? acc[t][r] : -FLT_MAX;
-          }
-          s[t][kt] = acc[t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  // ---- X(c): online softmax update of chunk c (per query = per px; the 4 lanes g share it) and P(c) as MFMA operands
-  auto xstep = [&](auto mask_tag) __attribute__((always_inline)) {
-    constexpr bool MASK = decltype(mask_tag)::value;
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      float cm = -FLT_MAX;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cm = fmaxf(cm, s[t][kt][r]);
-      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-      const float mn = fmaxf(m[t], cm);
-      if (!__all(mn == m[t])) {
-        const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
-        m[t] = mn;
-        part[t] = part[t] * alpha;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[t][dt][r] = oacc[t][dt][r] * alpha;
-      }
-      const f32x2 mn2 = {mn, mn};
-#pragma unroll
-      for (int kp = 0; kp < 2; ++kp) {
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          const int e = 2 * e2;
-          const f32x2 sv = {s[t][2 * kp + (e >> 2)][e & 3], s[t][2 * kp + (e >> 2)][(e & 3) + 1]};
-          const f32x2 d = sv - mn2;                  // v_pk_add_f32: the same two differences
-          float p0 = __builtin_amdgcn_exp2f(d[0]), p1 = __builtin_amdgcn_exp2f(d[1]);
-          if (MASK) {
-            p0 = (sv[0] == -FLT_MAX) ? 0.0f : p0;
-            p1 = (sv[1] == -FLT_MAX) ? 0.0f : p1;
-          }
-          part[t] = part[t] + p0;
-          part[t] = part[t] + p1;
-          split_pair(p0, p1, hw[e2], lw[e2]);
-        }
-        ph[t][kp] = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
-        pl[t][kp] = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
-      }
-    }
-  };
-#ifdef URF_ATTN_STAMPS
-#define PP_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && h < 64) g_attn_stamps[wave >> 2][h][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PP_STAMP(i) do { } while (0)
-#endif
-  // one half-step: stage, the step, commit, barrier.  h = the wave's position in its sequence + gb.
-#define PP_HALF(h_, STEP, BARRIER)     \
-  do {                                 \
-    const int h = (h_);                \
-    PP_STAMP(0);                       \
-    stage_issue(h);                    \
-    PP_STAMP(1);                       \
-    STEP;                              \
-    PP_STAMP(2);                       \
-    stage_commit(h);                   \
-    PP_STAMP(3);                       \
-    if (BARRIER) __syncthreads();      \
-    PP_STAMP(4);                       \
-  } while (0)
-  const std::true_type T{};
-  const std::false_type F{};
-  if (gb) PP_HALF(0, (void)0, true);                           // group B idles through half-step 0 (it still stages)
-  if (nfull > 0) PP_HALF(gb, mstep(0, F, T, F), true);
-  else PP_HALF(gb, mstep(0, F, T, T), true);
-  int c = 0;
-  for (; c + 1 < nfull; ++c) {                                 // X(c), M(c + 1) on full chunks: straight-line
-    PP_HALF(2 * c + 1 + gb, xstep(F), true);
-    PP_HALF(2 * c + 2 + gb, mstep(c + 1, T, T, F), true);
-  }
-  for (; c < nchunk; ++c) {                                    // the last full chunk, the partial one, the closing product
-    if (c < nfull) PP_HALF(2 * c + 1 + gb, xstep(F), true);
-    else PP_HALF(2 * c + 1 + gb, xstep(T), true);
-    if (c + 1 < nchunk) PP_HALF(2 * c + 2 + gb, mstep(c + 1, T, T, T), true);
-    else PP_HALF(2 * c + 2 + gb, mstep(c + 1, T, F, F), !gb);  // 2 nchunk + 1 barriers for everybody
-  }
-#undef PP_HALF
-#undef PP_STAMP
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    float l = part[t] + __shfl_xor(part[t], 16, 64);
-    l = l + __shfl_xor(l, 32, 64);
-    const int q = q0 + (wave * QT + t) * 16 + px;
-    const size_t oo = ((size_t)im * ANP + q) * 256 + head * 64 + 4 * g;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f16x4 h, lo;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = oacc[t][dt][r] / l;
-        h[r] = (_Float16)v;
-        lo[r] = (_Float16)(v - (float)h[r]);
-      }
-      *(f16x4 *)(oh + oo + dt * 16) = h;
-      *(f16x4 *)(ol + oo + dt * 16) = lo;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -671,7 +375,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_il_kernel(const _Float16 *qkh
   const int px = lane & 15, g = lane >> 4;
   const int nchunk = (ns + 63) >> 6, nfull = ns >> 6;
 
-  // staging (see attn_h2_pp_kernel): half of the waves stage K, the other half V^T; a wave = one plane x 64 rows (NW = 4) or x 32
+  // staging: half of the waves stage K, the other half V^T; a wave = one plane x 64 rows (NW = 4) or x 32
   // rows (NW = 8), a lane = a 16-byte piece of NP rows (+8u).  Buffer resources: the chunk goes into the scalar offset.
   constexpr int NP = 32 / NW;                                              // 16-byte pieces per thread and chunk
   const int st_v = wave / (NW / 2), st_sp = NW == 8 ? (wave >> 1) & 1 : wave & 1;
@@ -961,20 +665,23 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_il_kernel(const _Float16 *qkh
   }
 }
 
+#endif  // URF_EXPERIMENTS
+
 template <int QT, int NW>
 static int launch_attn_h2_t(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                             const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
   // (round 5 measured `s_setprio 1` around the MFMA clusters: +-0.5 %, and the run-time switch for it -- two branches inside the
   // pinned schedule of the chunk -- cost 4 us per launch even when off: not kept in any build)
-  // the ping-pong form (the two waves of a SIMD half a chunk out of phase) is the product's; URF_ATTN_PP=0 in the experiments
-  // build selects the one-rhythm form it is bit-identical to (tests/test_gpu_parity.py compares the two)
-  static int pp = -1;
-  if (pp < 0) {
-    const char *e = urf::exp_env("URF_ATTN_PP");
-    pp = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;   // measured: no form beats the one-rhythm kernel
+#ifdef URF_EXPERIMENTS
+  // URF_ATTN_IL=1 / 2 (experiments build): the software-pipelined form on eight waves (two per SIMD) / on four waves (one per
+  // SIMD, twice the workgroups).  Bit-identical to this kernel and no faster: DESIGN.md section 8, round 5
+  static int il = -1;
+  if (il < 0) {
+    const char *e = urf::exp_env("URF_ATTN_IL");
+    il = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
   }
-  if (NW == 8 && QT == 2 && pp >= 2) {   // 2: eight waves (two per SIMD), 3: four waves (one per SIMD, twice the workgroups)
-    if (pp == 2)
+  if (NW == 8 && QT == 2 && il) {
+    if (il == 1)
       hipLaunchKernelGGL((attn_h2_il_kernel<2, 8>), dim3((ANP / 256) * 4 * nimg), dim3(512), 0, st, qkh, qkl, vth, vtl, counts,
                          cross, oh, ol);
     else
@@ -983,12 +690,7 @@ static int launch_attn_h2_t(const _Float16 *qkh, const _Float16 *qkl, const _Flo
     URF_HIP(hipGetLastError());
     return 0;
   }
-  if (NW == 8 && pp == 1) {
-    hipLaunchKernelGGL((attn_h2_pp_kernel<QT, 8>), dim3((ANP / (16 * QT * 8)) * 4 * nimg), dim3(512), 0, st, qkh, qkl, vth, vtl,
-                       counts, cross, oh, ol);
-    URF_HIP(hipGetLastError());
-    return 0;
-  }
+#endif
   hipLaunchKernelGGL((attn_h2_kernel<QT, NW>), dim3((ANP / (16 * QT * NW)) * 4 * nimg), dim3(64 * NW), 0, st, qkh, qkl, vth,
                      vtl, counts, cross, oh, ol);
   URF_HIP(hipGetLastError());
