@@ -109,6 +109,28 @@ def pmc_traffic(kernel_label, resolution, prec):
                                            f"Infinity-Cache hits; {os.path.basename(files[-1])}")
 
 
+def pmc_mfma_busy(kernel_label, prec):
+    """the matrix pipe's busy fraction of a kernel family while it runs ALONE (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+    GRBM_GUI_ACTIVE serialises the dispatches), from the committed summary (tools/pmc_mfma_summary.py) taken on THESE kernel
+    sources; None otherwise.  Counter evidence beside the computed `mfma_issue_frac`, not a replacement for it."""
+    tag = {0: "_exact", 1: "_fast", 2: "_guarded", 3: ""}[prec]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_mfma{tag}.json")))
+    if not files:
+        return None, "no committed matrix-pipe PMC summary for this mode"
+    d = json.load(open(files[-1]))
+    if d.get("source_sha") != kernel_source_sha():
+        return None, f"{os.path.basename(files[-1])} was taken on other kernel sources: refused"
+    fam = ("conv_mfma_kernel<9,pool,fuse1a>" if "conv_mfma_kernel<9" in kernel_label else "linear_exact" if "gemm128" in kernel_label
+           else "attn_kernel" if "(attn_kernel)" in kernel_label
+           else "h2gemm" if "h2gemm" in kernel_label else "attn_h2_kernel" if "attn_h2" in kernel_label
+           else "h2conv_kernel<pool,fuse1a>" if "h2conv" in kernel_label else None)
+    k = d["kernels"].get(fam) if fam else None
+    if not k:
+        return None, f"{os.path.basename(files[-1])} has no matrix-core kernel for {kernel_label}"
+    return k["mfma_busy_frac"], (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs) over the {k['launches']} {fam} launches of "
+                                 f"{os.path.basename(files[-1])} (each kernel alone on the chip)")
+
+
 def stream_run(U, spb, sgb, dev, device_index, prec, Hh, Ww, batch, steps, repeats, warmup=5, keep=False):
     """One more configuration through the SAME loop as the headline (ur-mvo_amd/pipeline.py, two matcher handles, SuperPoint two
     batches ahead): `repeats` timed regions of `steps` steps, median reported.  keep=True also returns every fetched list."""
@@ -526,6 +548,7 @@ def main():
         bound, t_mfma, t_hbm, peak_tf = roofs(dom, ms, gf, gb)
         issue = 3 if on_f16(dom) else 1
         traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
+        mfma_busy, mfma_busy_src = pmc_mfma_busy(dom, PREC) if args.resolution == "640x480" else (None, "matrix-pipe counters are taken at 640x480")
         if bound == "hbm":
             achieved, peak, unit = gb / ms * 1e3, HBM_PEAK_GBS, "GB/s"
         else:
@@ -533,6 +556,7 @@ def main():
         roofline = {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
                     "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_note": traffic_src,
+                    "mfma_busy_counter": mfma_busy, "mfma_busy_counter_note": mfma_busy_src,
                     "why_this_bound": f"SURVEY 8(d): dense contractions on the MFMA roof, Sinkhorn on HBM; for this family the minimum "
                                       f"time at the MFMA roof is {t_mfma:.3f} ms (algorithmic {gf:.1f} GFLOP counted once; x{issue} MFMA "
                                       f"instructions per product) and at the HBM roof {t_hbm:.3f} ms (byte model: {gb:.2f} GB per step)",

@@ -2,6 +2,8 @@
 the CPU oracle on the same seeded inputs (bit-exact), against the committed
 golden fixtures made from the reference graph, and through size-independent
 properties at the full BASELINE sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -958,3 +960,27 @@ def test_ransac_does_not_depend_on_the_order_of_the_matches(F, O, pm):
         perm = rng.permutation(n)
         s, inl, Fm = pm.find_F(p0[perm], p1[perm])
         assert s == s_ref and np.array_equal(Fm, F_ref) and np.array_equal(inl, inl_ref[perm])
+
+
+@pytest.mark.gpu
+def test_attention_kernel_forms_of_the_experiments_build_are_bit_identical():
+    """attn_h2_il_kernel (round 5's software-pipelined re-scheduling of the fast attention kernel, experiments build only,
+    URF_ATTN_IL=1 eight waves / 2 four waves) must give the product kernel's bits: ragged sizes through SuperGlue::infer and
+    the batched device path (tools/gpu_attn_il_check.py prints a sha256 per case; the knob is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "ur-mvo_amd", "liburf_front_exp.so")
+    if not os.path.exists(so):
+        pytest.skip("liburf_front_exp.so is not built")
+    outs = {}
+    for v in ("0", "1", "2"):
+        env = dict(os.environ, URF_LIB=so, URF_ATTN_IL=v)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_attn_il_check.py")], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs[v] = r.stdout
+    assert len(outs["0"].splitlines()) >= 12
+    assert outs["1"] == outs["0"]
+    assert outs["2"] == outs["0"]
+

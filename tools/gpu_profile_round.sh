@@ -1,7 +1,8 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made of, in one call on the GPU box (results under gpurun_out/$1/, copy them to profiles/):
 #   gpurun --timeout 3000 -- 'bash tools/gpu_profile_round.sh r04p r04'
-# PMC passes (FETCH_SIZE, WRITE_SIZE; two separate passes each, never combined with other traces) + tools/pmc_summary.py for the
+# PMC passes (FETCH_SIZE, WRITE_SIZE; two separate passes each, never combined with other traces; round 5: a third pass for the
+# matrix pipe's busy cycles, tools/pmc_mfma_summary.py) + tools/pmc_summary.py for the
 # strict-parity mode (the default of bench.py) on the 640x480 and the 1241x376 stream, the guarded fast and the exact mode; the
 # kernel-trace statistics of the strict mode on both streams and of the exact mode; the bench lines.  Run it after the LAST edit
 # of ur-mvo_amd/csrc: bench.py refuses a PMC summary whose source_sha differs from the kernel sources.
@@ -20,6 +21,13 @@ pmc() {   # $1 = suffix of the summary file, rest = extra bench arguments
   rm -rf $R/$OUT/pmc_FETCH_SIZE $R/$OUT/pmc_WRITE_SIZE
   cp $R/$OUT/${TAG}_pmc_hbm$SUF.json $R/profiles/ 2>/dev/null    # so that the bench lines below carry roofline.traffic
 }
+pmc_mfma() {   # the matrix pipe's busy cycles per kernel (one pass: SQ and GRBM counters share no slots); $1 = suffix
+  SUF=$1; shift
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_F32 --kernel-trace -d $R/$OUT/pmc_mfma -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --repeats 1 $QUICK "$@" > $R/$OUT/pmc_mfma$SUF.log 2>&1
+  (cd $R/tools && python pmc_mfma_summary.py $(find $R/$OUT/pmc_mfma -name "*.db" | head -1) $R/$OUT/${TAG}_pmc_mfma$SUF.json "python3 bench.py --steps 5 --warmup 1 --repeats 1 $QUICK $*")
+  rm -rf $R/$OUT/pmc_mfma
+  cp $R/$OUT/${TAG}_pmc_mfma$SUF.json $R/profiles/ 2>/dev/null
+}
 stats() {  # $1 = name, rest = bench arguments
   NAME=$1; shift
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_$NAME -o st -- python3 $R/bench.py --steps 20 --warmup 2 --repeats 1 $QUICK "$@" > $R/$OUT/stats_$NAME.log 2>&1
@@ -29,6 +37,9 @@ pmc ""
 pmc _1241x376 --resolution 1241x376
 pmc _guarded --precision 2
 pmc _exact --precision 0
+pmc_mfma ""
+pmc_mfma _guarded --precision 2
+pmc_mfma _exact --precision 0
 stats strict
 # the same command with everything on ONE in-order stream: the serialised kernel durations that bench.py's roofline pass
 # measures with HIP events (with three streams the tracer records every kernel's begin -> end while the others co-run)

@@ -964,7 +964,10 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
   };
   absorb();
 
-  // ---- the launch's workgroups check in (a launch that cannot become co-resident gives up here, like in the loop)
+  // ---- the launch's workgroups check in (a launch that cannot become co-resident gives up here, like in the loop), and agree on
+  // the granule stores' scope: every workgroup publishes its XCC id with the always-valid agent-scope form and reads all 16 -- the
+  // same 16 values everywhere, so the same decision everywhere (`near`: rs_store above; opt-in, speed only)
+  bool near = false;
   {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -973,10 +976,13 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     if (wv == 0) {
       float ids = 0.0f;
       const bool alive = rs_sweep<1, true>(xbc + 1056, RW_WG, tag0, ids, nullptr, lane, a.err);
-      if (lane == 0 && !alive) misc[1] = 1.0f;
+      const float first = __shfl(ids, 0, 64);
+      const bool same = __all(lane >= RW_WG || ids == first);
+      if (lane == 0) { misc[2] = same ? 1.0f : 0.0f; if (!alive) misc[1] = 1.0f; }
     }
     rs_sync();
     if (misc[1] != 0.0f) return;
+    near = misc[2] != 0.0f && a.allow_near != 0;
   }
 
   int next_absorb = 1;
@@ -1058,19 +1064,19 @@ __global__ void __launch_bounds__(RW_T, 2) sinkhorn_wide_kernel(RsArgs a) {
     // hop-1 granule [reducer][source][column % 64]; the dustbin column's sums at the end of the region, reduced by workgroup 15
 #pragma unroll
     for (int c = 0; c < NC; ++c)
-      rs_store(xin + ((size_t)((col[c] >> 6) * RW_WG + w) * 64 + (col[c] & 63)), tag, dust[c] ? cdust : creg[c], false);
-    if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, false);
+      rs_store(xin + ((size_t)((col[c] >> 6) * RW_WG + w) * 64 + (col[c] & 63)), tag, dust[c] ? cdust : creg[c], near);
+    if (tid == 0) rs_store(xin + (size_t)RS_WG * RS_WG * 32 + w, tag, (n1 == RS_NP) ? cdust : 0.0f, near);
     if (wv == 0) {
       bool alive = true;
       {
         float x = 0.0f;
         alive = rs_sweep<16, true>(xin + (size_t)w * RW_WG * 64, RW_WG * 64, tag, x, nullptr, lane, a.err);   // x = sum over the sources, in order
-        if (alive) rs_store(xbc + 64 * w + lane, tag, x, false);
+        if (alive) rs_store(xbc + 64 * w + lane, tag, x, near);
         if (alive && w == RW_WG - 1) {
           float y = 0.0f;
           alive = rs_sweep<1, true>(xin + (size_t)RS_WG * RS_WG * 32, RW_WG, tag, y, nullptr, lane, a.err);
           const float ys = half_sum32(lane < RW_WG ? y : 0.0f);
-          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, false);
+          if (alive && lane == 0) rs_store(xbc + 1024, tag, ys, near);
         }
       }
       if (alive) {
