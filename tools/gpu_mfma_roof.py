@@ -6,6 +6,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# urf_probe_mfma_roof is exported by the experiments build only (include/urf.h, #ifdef URF_EXPERIMENTS)
+os.environ.setdefault("URF_LIB", os.path.join(ROOT, "ur-mvo_amd", "liburf_front_exp.so"))
 from __graft_entry__ import load_pkg  # noqa: E402
 
 L = load_pkg()._lib.lib()

@@ -56,5 +56,5 @@ python tools/gpu_timeline.py 3 60 2 2 > $OUT/${TAG}_timeline_strict.txt 2>&1
 python tools/gpu_redo_bench.py > $OUT/${TAG}_redo_chain_alone.txt 2>&1
 python tools/gpu_sp_layers.py > $OUT/${TAG}_superpoint_exact_layers.txt 2>&1
 python tools/gpu_strict_margins.py 40 > $OUT/${TAG}_strict_margins.txt 2>&1
-python tools/gpu_mfma_roof.py > $OUT/${TAG}_mfma_roof.txt 2>&1
+URF_LIB=$R/ur-mvo_amd/liburf_front_exp.so python tools/gpu_mfma_roof.py > $OUT/${TAG}_mfma_roof.txt 2>&1   # (experiments build: urf_probe_mfma_roof)
 ls -la $OUT
