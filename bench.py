@@ -109,14 +109,14 @@ def pmc_traffic(kernel_label, resolution, prec):
                                            f"Infinity-Cache hits; {os.path.basename(files[-1])}")
 
 
-def pmc_mfma_busy(kernel_label, prec):
+def pmc_mfma_busy(kernel_label, resolution, prec):
     """the matrix pipe's busy fraction of a kernel family while it runs ALONE (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
     GRBM_GUI_ACTIVE serialises the dispatches), from the committed summary (tools/pmc_mfma_summary.py) taken on THESE kernel
     sources; None otherwise.  Counter evidence beside the computed `mfma_issue_frac`, not a replacement for it."""
-    tag = {0: "_exact", 1: "_fast", 2: "_guarded", 3: ""}[prec]
+    tag = ("" if resolution == "640x480" else "_" + resolution) + {0: "_exact", 1: "_fast", 2: "_guarded", 3: ""}[prec]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_mfma{tag}.json")))
     if not files:
-        return None, "no committed matrix-pipe PMC summary for this mode"
+        return None, "no committed matrix-pipe PMC summary for this resolution and mode"
     d = json.load(open(files[-1]))
     if d.get("source_sha") != kernel_source_sha():
         return None, f"{os.path.basename(files[-1])} was taken on other kernel sources: refused"
@@ -548,7 +548,7 @@ def main():
         bound, t_mfma, t_hbm, peak_tf = roofs(dom, ms, gf, gb)
         issue = 3 if on_f16(dom) else 1
         traffic, traffic_src = pmc_traffic(dom, args.resolution, PREC)
-        mfma_busy, mfma_busy_src = pmc_mfma_busy(dom, PREC) if args.resolution == "640x480" else (None, "matrix-pipe counters are taken at 640x480")
+        mfma_busy, mfma_busy_src = pmc_mfma_busy(dom, args.resolution, PREC)
         if bound == "hbm":
             achieved, peak, unit = gb / ms * 1e3, HBM_PEAK_GBS, "GB/s"
         else:

@@ -38,6 +38,7 @@ pmc _1241x376 --resolution 1241x376
 pmc _guarded --precision 2
 pmc _exact --precision 0
 pmc_mfma ""
+pmc_mfma _1241x376 --resolution 1241x376
 pmc_mfma _guarded --precision 2
 pmc_mfma _exact --precision 0
 stats strict
