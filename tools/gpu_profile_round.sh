@@ -41,6 +41,7 @@ pmc_mfma ""
 pmc_mfma _1241x376 --resolution 1241x376
 pmc_mfma _guarded --precision 2
 pmc_mfma _exact --precision 0
+(cd $R && bash tools/gpu_pmc_waves.sh ${1:-prof} $TAG > $OUT/pmc_waves_all.log 2>&1)   # wave states, VALU beside MFMA, LDS conflicts (needs the ${TAG}_pmc_mfma*.json above in profiles/)
 stats strict
 # the same command with everything on ONE in-order stream: the serialised kernel durations that bench.py's roofline pass
 # measures with HIP events (with three streams the tracer records every kernel's begin -> end while the others co-run)
