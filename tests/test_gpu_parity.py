@@ -974,7 +974,7 @@ def test_attention_kernel_forms_of_the_experiments_build_are_bit_identical():
     if not os.path.exists(so):
         pytest.skip("liburf_front_exp.so is not built")
     outs = {}
-    for v in ("0", "1", "2"):
+    for v in ("0", "1"):       # (URF_ATTN_IL=2, the four-wave form, is compared by tools/gpu_attn_il_check.sh: a third of this test's time)
         env = dict(os.environ, URF_LIB=so, URF_ATTN_IL=v)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_attn_il_check.py")], env=env, capture_output=True,
                            text=True, timeout=600)
@@ -982,5 +982,4 @@ def test_attention_kernel_forms_of_the_experiments_build_are_bit_identical():
         outs[v] = r.stdout
     assert len(outs["0"].splitlines()) >= 12
     assert outs["1"] == outs["0"]
-    assert outs["2"] == outs["0"]
 
