@@ -37,12 +37,6 @@ __device__ __forceinline__ void split_pair(float p0, float p1, unsigned &hi, uns
 constexpr int ANP = kCap;
 constexpr int AS = 80;       // K rows: 160 B, conflict-free ds_read_b128
 constexpr int VS = 72;       // V^T rows: 144 B, conflict-free ds_read_b64
-// attn_h2_kernel keeps the V^T chunk PERMUTED in LDS (round 5): within a 32-key block, key 16 t + 4 g + e sits at position
-// 8 g + 4 t + e, so the eight keys a lane feeds to one MFMA (4g..4g+3 of two consecutive 16-key score tiles: the layout the S^T
-// accumulators hand back as the B operand) are 16 contiguous bytes -- ONE ds_read_b128 per plane and step, conflict-free at the K
-// rows' stride, instead of two 8-byte reads 32 B apart that the compiler fuses into a ds_read2_b64 (32-bank mode: rows px and
-// px + 8 collide at the 144-byte stride; rocprofv3: SQ_LDS_BANK_CONFLICT = 34 % of the kernel's LDS cycles before)
-constexpr int VSP = 80;
 
 // One pass over the keys with an online softmax (running max / running sum,
 // flash-attention style): per 64-key chunk a wave holds only a 16 x 64 score block
@@ -69,7 +63,7 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
   constexpr int NV = 512 / NT;                     // staging roles per thread (512 = 2 tensors x 2 planes x 16 rows x 8 pieces)
   // [buffer][K planes | V planes]
   __shared__ __attribute__((aligned(16))) _Float16 kbuf[2][2][64 * AS];
-  __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][64 * VSP];
+  __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][64 * VS];
   int qb, grp;
   xcd_group_map(blockIdx.x, ANP / QB, (int)gridDim.x / (ANP / QB), qb, grp);   // the query tiles of a head on one XCD
   const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
@@ -133,15 +127,8 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       const int sj = st & 7, sr = st >> 3;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (sk == 0) {
-          *(f16x8 *)(kbuf[buf][sp] + (sr + 16 * u) * AS + 8 * sj) = pf[v][u];
-        } else {
-          // keys 8 sj .. 8 sj + 7 of row d: block sj >> 2, t = (sj & 3) >> 1, g = 2 (sj & 1) and g + 1 (permutation above)
-          _Float16 *dst = vbuf[buf][sp] + (sr + 16 * u) * VSP + (sj >> 2) * 32 + 16 * (sj & 1) + 4 * ((sj & 3) >> 1);
-          const f16x8 x = pf[v][u];
-          *(f16x4 *)dst = f16x4{x[0], x[1], x[2], x[3]};
-          *(f16x4 *)(dst + 8) = f16x4{x[4], x[5], x[6], x[7]};
-        }
+        if (sk == 0) *(f16x8 *)(kbuf[buf][sp] + (sr + 16 * u) * AS + 8 * sj) = pf[v][u];
+        else *(f16x8 *)(vbuf[buf][sp] + (sr + 16 * u) * VS + 8 * sj) = pf[v][u];
       }
     }
   };
@@ -228,14 +215,14 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
       __builtin_amdgcn_sched_barrier(0);
     }
     // V^T fragments of step i = 4 kp + dt (32 keys x 16 d): ring of three, two in flight
-    const _Float16 *vph = vbuf[buf][0] + px * VSP + 8 * g;
-    const _Float16 *vpl = vbuf[buf][1] + px * VSP + 8 * g;
+    const _Float16 *vph = vbuf[buf][0] + px * VS + 4 * g;
+    const _Float16 *vpl = vbuf[buf][1] + px * VS + 4 * g;
     constexpr int VR = 2;   // ring depth (3 = two steps in flight costs 8 more VGPRs: 200, over the co-residency budget)
-    f16x8 vf[VR][2];     // [ring][hi | lo]: keys 4g..4g+3 and 16+4g..16+4g+3 of the 32-key step (contiguous in the permuted chunk)
+    f16x4 vf[VR][4];     // [ring][hi keys 0-3 | hi keys 16-19 | lo keys 0-3 | lo keys 16-19]
     auto load_v = [&](int i) {
-      const int kp = i >> 2, dt = i & 3, o = kp * 32 + dt * 16 * VSP;
-      vf[i % VR][0] = *(const f16x8 *)(vph + o);
-      vf[i % VR][1] = *(const f16x8 *)(vpl + o);
+      const int kp = i >> 2, dt = i & 3, o = (2 * kp) * 16 + dt * 16 * VS;
+      vf[i % VR][0] = *(const f16x4 *)(vph + o); vf[i % VR][1] = *(const f16x4 *)(vph + o + 16);
+      vf[i % VR][2] = *(const f16x4 *)(vpl + o); vf[i % VR][3] = *(const f16x4 *)(vpl + o + 16);
     };
 #pragma unroll
     for (int i = 0; i + 1 < VR; ++i) load_v(i);
@@ -297,7 +284,9 @@ __global__ void __launch_bounds__(64 * NW) attn_h2_kernel(const _Float16 *qkh, c
         __builtin_amdgcn_sched_barrier(0);
         if (i + VR - 1 < 8) load_v(i + VR - 1);
         __builtin_amdgcn_sched_barrier(0);
-        const f16x8 ah = vf[i % VR][0], al = vf[i % VR][1];
+        f16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ah[e] = vf[i % VR][0][e]; ah[4 + e] = vf[i % VR][1][e]; al[e] = vf[i % VR][2][e]; al[4 + e] = vf[i % VR][3][e]; }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[t], oacc[t][dt], 0, 0, 0);
