@@ -557,6 +557,15 @@ int urf_search_by_projection_slot(const urf_sbp_config *cfg, const void *d_slot,
                                   const double *mp_pos, const double *mp_desc, const uint8_t *mp_valid, int M,
                                   int *best_idx);
 
+/* cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, thresh (3), confidence (0.99), mask) on raw point arrays:
+ * what /root/reference/src/point_matching.cc:50 calls, as the outlier stage 1 above runs it (cvransac.hip; the restatement
+ * of OpenCV 4.2.0's published algorithm -- PARITY UNPINNED, no OpenCV binary in this image).  pts0 / pts1: n x 2 f32 (n <= 1024),
+ * host arrays; mask: n bytes, 1 = inlier (all ones when no model is found, as the reference then filters nothing);
+ * F9 (optional): the row-major model behind the mask, untouched when there is none; iterations (optional): hypothesis rounds
+ * run.  Touches no handle. */
+int urf_cv_find_fundamental(const float *pts0, const float *pts1, int n, double thresh, double confidence, uint8_t *mask,
+                            double *F9, int *iterations, int device);
+
 /* arithmetic taps of the GPU parity tests: pure functions of their arguments (the fp32 matrix core as an ordered fma chain, the
  * canonical exp / log, IEEE division and square root, the split-f16 GEMM, one f16 matrix-core instruction).  They touch no handle. */
 int urf_probe_fma_gemm(const float *A, const float *B, const float *bias, int M, int N, int K, float *C, int device);

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liburf_oracle.so")
+# URF_ORACLE_SO: the sanitizer build (`make -C oracle asan`), picked by the sanitizer test's subprocess only
+_SO = os.environ.get("URF_ORACLE_SO") or os.path.join(_HERE, "liburf_oracle.so")
 
 
 def build(force=False):
@@ -18,7 +19,7 @@ def build(force=False):
                                               "urf_oracle.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liburf_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     return _SO
 
 

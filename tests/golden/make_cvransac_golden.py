@@ -121,20 +121,20 @@ def lmeds_mask(m1, m2, conf=0.99):
             if med < min_median:
                 min_median, best = med, F
     if best is None:
-        return np.ones(n, np.uint8), it + 1
+        return np.ones(n, np.uint8), it + 1, None
     sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * math.sqrt(min_median), 0.001)
-    return (errors(best, m1, m2) <= np.float32(sigma * sigma)).astype(np.uint8), it + 1
+    return (errors(best, m1, m2) <= np.float32(sigma * sigma)).astype(np.uint8), it + 1, best
 
 
 def find_fundamental_mask(m1, m2, thresh=3.0, conf=0.99):
     n = len(m1)
     if n <= 7:
-        return np.ones(n, np.uint8), 0
+        return np.ones(n, np.uint8), 0, None
     if n < 15:
         return lmeds_mask(m1, m2, conf)
     rng = RNG()
     t = np.float32(thresh * thresh)
-    niters, max_good, best = 1000, 0, np.ones(n, np.uint8)
+    niters, max_good, best, bestF = 1000, 0, np.ones(n, np.uint8), None
     it = 0
     while it < niters:
         idx = get_subset(m1, m2, rng)
@@ -144,10 +144,10 @@ def find_fundamental_mask(m1, m2, thresh=3.0, conf=0.99):
             cur = (errors(F, m1, m2) <= t).astype(np.uint8)
             good = int(cur.sum())
             if good > max(max_good, 6):
-                best, max_good = cur, good
+                best, max_good, bestF = cur, good, F
                 niters = update_iters(conf, (n - good) / n, niters)
         it += 1
-    return best, it
+    return best, it, bestF
 
 
 def scene(seed, n_in, n_out, noise):
@@ -177,8 +177,10 @@ def main():
                        ("e", (7, 12, 2, 0.1)), ("f", (8, 6, 8, 0.1))):   # (14 points each: with 13 or fewer the median is the error
         # of one of the seven sample points of a model, i.e. rounding noise, and which model "wins" is numerics, not algorithm)
         m0, m1, truth = scene(*args)
-        mask, iters = find_fundamental_mask(m0, m1)
-        np.savez_compressed(os.path.join(HERE, f"cvransac_{name}.npz"), m0=m0, m1=m1, truth=truth, mask=mask, iterations=iters)
+        mask, iters, Fbest = find_fundamental_mask(m0, m1)
+        # F: the model behind the mask as numpy's SVD / roots give it (scale and sign are the solver's: compare up to both)
+        np.savez_compressed(os.path.join(HERE, f"cvransac_{name}.npz"), m0=m0, m1=m1, truth=truth, mask=mask, iterations=iters,
+                            F=np.zeros((3, 3)) if Fbest is None else np.asarray(Fbest, np.float64).reshape(3, 3))
         print(name, len(m0), "points,", int(truth.sum()), "true inliers,", int(mask.sum()), "in the mask,", iters, "iterations")
 
 

@@ -776,8 +776,8 @@ def test_frame_stream_ragged_submits_past_the_reference_window(U, F, sp_blob, sg
 def test_opencv42_outlier_stage_equals_the_oracle(U, F, O, sp_blob, sg_blob, sp640):
     """urf_sg_config.outlier_stage = 1: cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask) restated from
     OpenCV 4.2 (cvransac.hip) against the oracle's restatement of the same written arithmetic (oracle/cvransac_oracle.c),
-    bit for bit: through MatchingPoints on frame pairs of a stream (host API and device batch), and on the golden scenes
-    through the matcher's own buffers (a match list whose keypoints are the scene's points)."""
+    bit for bit: through MatchingPoints on frame pairs of a stream (host API and device batch).  (That checker restates the
+    kernel's own text; the INDEPENDENT one is test_opencv42_kernel_vs_the_independent_numpy_golden below.)"""
     import torch
     frames = U.synth.shift_stream(41, 5, 480, 640)
     feats = [sp640.infer(f) for f in frames]
@@ -804,6 +804,56 @@ def test_opencv42_outlier_stage_equals_the_oracle(U, F, O, sp_blob, sg_blob, sp6
         assert got == O.match_points(sg_blob, O.SGConfig(640, 512, 0.5, 100), rc, feats[0][:n], feats[0][:n], True), n
     with pytest.raises(RuntimeError, match="outlier_stage"):
         F.PointMatching(F.SuperGlueConfig(), outlier_stage=2)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e", "f"])
+def test_opencv42_kernel_vs_the_independent_numpy_golden(U, F, O, name):
+    """a21 with a checker that is NOT the kernel's twin: the golden scenes of tests/golden/make_cvransac_golden.py -- an
+    independent numpy / LAPACK restatement of cv::findFundamentalMat(FM_RANSAC, 3, 0.99) of OpenCV 4.2 (numpy.linalg.svd for the
+    null space, numpy.roots for the cubic, math.log for the iteration count; same cv::RNG stream) -- fed straight through
+    cvransac.hip (urf_cv_find_fundamental = the kernel of outlier stage 1 on one correspondence list): the inlier mask, the
+    number of hypothesis rounds (it depends on every accepted model's inlier count on the way) and the winning model F up to
+    scale.  The kernel's numerics differ from numpy's (Gauss-Jordan, bisection, a multiplication chain), so a borderline
+    correspondence could legitimately differ; none does on these scenes.  src/point_matching.cc:43-58.  PARITY UNPINNED
+    against an OpenCV binary (none in this image)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"cvransac_{name}.npz"))
+    mask, Fm, its = F.findFundamentalMat(g["m0"], g["m1"], 3.0, 0.99)
+    assert mask.shape == g["mask"].shape and np.array_equal(mask, g["mask"]), (name, int(mask.sum()), int(g["mask"].sum()))
+    assert its == int(g["iterations"]), (name, its, int(g["iterations"]))
+    assert np.array_equal(mask, O.cv_find_fundamental_mask(g["m0"], g["m1"], 3.0, 0.99))     # ... and the C restatement agrees
+    assert Fm is not None
+    a, b = Fm / np.linalg.norm(Fm), g["F"] / np.linalg.norm(g["F"])
+    if (a * b).sum() < 0:
+        b = -b
+    # RANSAC scenes: the same minimal set, so the same model to the solvers' rounding; the LMedS scenes (e, f: 14 points) pick
+    # the least median among ~900 models, where two numerics may crown different near-equal models -- their F must at least
+    # explain the same inliers (the mask equality above)
+    if name in "abcd":
+        assert np.abs(a - b).max() < 1e-6, (name, np.abs(a - b).max())
+    # a rank-2 matrix either way (the 7-point cubic enforces det F = 0)
+    assert abs(np.linalg.det(a)) < 1e-9
+
+
+def test_opencv42_kernel_small_counts_and_the_oracle_on_random_scenes(U, F, O):
+    """the dispatch on the point count (fewer than 7 / exactly 7: nothing rejected; 8..14: LMedS) and 20 random scenes between
+    15 and 1024 correspondences against the C restatement, mask for mask"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvransac_a.npz"))
+    keep = np.nonzero(g["truth"])[0]
+    for n in (0, 3, 7):
+        m, Fm, its = F.findFundamentalMat(g["m0"][keep[:n]], g["m1"][keep[:n]])
+        assert m.shape == (n,) and m.all() and Fm is None
+    rng = np.random.default_rng(5)
+    for t in range(20):
+        n = int(rng.integers(8, 1025)) if t else 1024
+        idx = rng.integers(0, len(g["m0"]), n)
+        jit = rng.integers(-2, 3, (n, 2)).astype(np.float32)
+        m0, m1 = g["m0"][idx] + jit, g["m1"][idx] + rng.integers(-1, 2, (n, 2)).astype(np.float32)
+        bad = rng.random(n) < 0.3
+        m1[bad] = rng.uniform(0, 480, (int(bad.sum()), 2)).astype(np.float32).round()
+        m, _, _ = F.findFundamentalMat(m0, m1)
+        assert np.array_equal(m, O.cv_find_fundamental_mask(m0, m1)), (t, n)
+    with pytest.raises(RuntimeError, match="1024"):
+        F.findFundamentalMat(np.zeros((1025, 2), np.float32), np.zeros((1025, 2), np.float32))
 
 
 # ------------------------------------------------------------------ error behaviour of the boundary

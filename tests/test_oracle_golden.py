@@ -1,6 +1,8 @@
 """CPU tests: the oracle against the golden vectors made from the reference's
 own SuperPoint graph (tests/golden/make_golden.py) and against independent
 restatements of the reference's host code.  No GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -598,3 +600,43 @@ def test_opencv42_find_fundamental_small_counts(O):
     idx = np.r_[keep[:11], np.nonzero(g["truth"] == 0)[0][:2]]           # 11 inliers + 2 outliers: the LMedS branch
     m = O.cv_find_fundamental_mask(g["m0"][idx], g["m1"][idx])
     assert m.shape == (13,) and 7 <= m.sum() <= 13      # (a least-median threshold is tight: 2.5 x 1.4826 x (1 + 5 / 6) x sqrt(median))
+
+
+# ------------------------------------------------------------------ sanitizer build of the CPU side
+SANITIZED = ("sparse_240 or sg_n96 or reconstruct_vs or opencv42 or pose_stage or camera or search_by or postprocess_edge or decode "
+             "or nms or not_multiple or confidence_stop or pnp_ransac or frame_optimization or wave_sum or exp_log or which_oracle")
+
+
+def test_which_oracle_library_is_loaded(O):
+    """inside the sanitizer run (URF_ORACLE_SO set): the library the tests call IS the instrumented one"""
+    want = os.environ.get("URF_ORACLE_SO")
+    O.lib()
+    maps = open("/proc/self/maps").read()
+    if want:
+        assert os.path.basename(want) in maps and "libasan" in maps
+    else:
+        assert "liburf_oracle.so" in maps
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make -C oracle asan` (gcc -fsanitize=address,undefined, UB fatal) and the oracle's golden-fixture tests once more on that
+    build, in a subprocess with the sanitizer runtimes preloaded: every restated stage (SuperPoint post-processing, the
+    SuperGlue graph at n = 96, both RANSAC forms, the pose stage, camera maps, SearchByProjection) walks its buffers within
+    bounds and without undefined arithmetic on the fixtures.  The reference builds without sanitizers
+    (/root/reference/CMakeLists.txt:11); GPU AddressSanitizer is not available on the pool, so this is the CPU side only."""
+    import subprocess
+    import sys
+    if os.environ.get("URF_ORACLE_SO"):
+        pytest.skip("already inside the sanitizer run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    rt = [subprocess.check_output(["gcc", f"-print-file-name={n}"], text=True).strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(r) and os.path.exists(r) for r in rt):
+        pytest.skip("no sanitizer runtime beside this gcc")
+    env = dict(os.environ, LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", URF_ORACLE_SO=os.path.join(root, "oracle", "liburf_oracle_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", SANITIZED],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=850)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail
+

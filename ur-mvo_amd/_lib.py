@@ -28,7 +28,7 @@ SYMBOLS = [
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
     "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_guard_state", "urf_pm_redo_engine_stats", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_group_start", "urf_comm_group_end", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",
     "urf_comm_allgather_slots", "urf_comm_gather", "urf_comm_plan_pairs", "urf_pm_device_results", "urf_pm_sinkhorn_fallbacks", "urf_pm_sinkhorn_integrity", "urf_pm_sinkhorn_residuals",
-    "urf_sg_debug_couplings", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
+    "urf_sg_debug_couplings", "urf_cv_find_fundamental", "urf_pose_create", "urf_pose_destroy", "urf_solve_pnp_ransac", "urf_frame_optimization", "urf_frame_optimization_stereo",
 ]
 # exported by the experiments build only (#ifdef URF_EXPERIMENTS in include/urf.h): fault injection, kernel A/B switches, diagnostics
 EXPERIMENT_SYMBOLS = [

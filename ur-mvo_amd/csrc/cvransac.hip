@@ -230,7 +230,7 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 // one wave per pair.  mask / cur: [P][NP] bytes of scratch; out lists in match order
 __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const float *pts0, const float *pts1, double thresh,
                                                        double confidence, int enable, const DMatchC *matches, DMatchC *out,
-                                                       int *nout, uint8_t *mask_g, uint8_t *cur_g) {
+                                                       int *nout, uint8_t *mask_g, uint8_t *cur_g, double *F_out, int *iters_out) {
   __shared__ double sA[7][9];
   __shared__ double sF[27];
   __shared__ double sBest[9];
@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
     rng.state = 0xffffffffffffffffull;
     if (n >= 15) {
       const float t = (float)(thresh * thresh);
-      int niters = 1000, max_good = 0;
-      for (int iter = 0; iter < niters; ++iter) {
+      int niters = 1000, max_good = 0, iter = 0;
+      for (; iter < niters; ++iter) {
         if (lane == 0) {
           int idx[7];
           int nm = -1;
@@ -274,10 +274,12 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
             for (int i = lane; i < n; i += 64) mask[i] = cur[i];
             max_good = good;
             niters = cv_update_num_iters(confidence, (double)(n - good) / n, niters);
+            if (F_out && lane < 9) F_out[9 * p + lane] = sF[9 * k + lane];   // (diagnostic output of urf_cv_find_fundamental: the model behind the mask)
           }
         }
         __syncthreads();
       }
+      if (iters_out && lane == 0) iters_out[p] = iter;
       if (max_good <= 0)                      // no model (or no admissible subset at all): nothing is rejected
         for (int i = lane; i < n; i += 64) mask[i] = 1;
     } else {
@@ -286,7 +288,8 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
       if (niters < 3) niters = 3;
       double min_median = DBL_MAX;
       bool failed = false;
-      for (int iter = 0; iter < niters; ++iter) {
+      int iter = 0;
+      for (; iter < niters; ++iter) {
         if (lane == 0) {
           int idx[7];
           int nm = -1;
@@ -316,6 +319,8 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
           __syncthreads();
         }
       }
+      if (iters_out && lane == 0) iters_out[p] = iter;
+      if (F_out && !failed && min_median < DBL_MAX && lane < 9) F_out[9 * p + lane] = sBest[lane];
       if (!failed && min_median < DBL_MAX) {
         double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (n - 7)) * sqrt(min_median);
         if (sigma < 0.001) sigma = 0.001;
@@ -344,11 +349,52 @@ __global__ void __launch_bounds__(64) cv_ransac_kernel(const int *nmatch, const 
 
 // the outlier stage of a batch of P pairs in OpenCV's form.  inliers: [P][kCap] (the mask), scratch: [P][kCap] bytes
 int launch_cv_ransac(const int *nmatch, const float *pts0, const float *pts1, double thresh, double confidence, int enable,
-                     const void *matches, void *out, int *nout, uint8_t *inliers, uint8_t *scratch, int P, hipStream_t st) {
+                     const void *matches, void *out, int *nout, uint8_t *inliers, uint8_t *scratch, int P, hipStream_t st,
+                     double *F_out, int *iters_out) {
   hipLaunchKernelGGL(cv_ransac_kernel, dim3(P), dim3(64), 0, st, nmatch, pts0, pts1, thresh, confidence, enable,
-                     (const DMatchC *)matches, (DMatchC *)out, nout, inliers, scratch);
+                     (const DMatchC *)matches, (DMatchC *)out, nout, inliers, scratch, F_out, iters_out);
   URF_HIP(hipGetLastError());
   return 0;
 }
 
 }  // namespace urf
+
+// cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, thresh, confidence, mask) on raw point arrays (host in, host out): the
+// kernel of the matcher's outlier stage over ONE correspondence list.  What src/point_matching.cc:50 calls, behind the C ABI;
+// F9 (row-major, the model behind the mask; untouched when there is none) and iterations are optional.
+extern "C" int urf_cv_find_fundamental(const float *pts0, const float *pts1, int n, double thresh, double confidence,
+                                       uint8_t *mask, double *F9, int *iterations, int device) {
+  using namespace urf;
+  URF_CHECK(n >= 0 && n <= kCap && (n == 0 || (pts0 && pts1 && mask)), "urf_cv_find_fundamental: 0 <= n <= %d points, non-null arrays", kCap);
+  if (n == 0) { if (iterations) *iterations = 0; return 0; }
+  if (thresh <= 0.0) thresh = 3.0;
+  if (!(confidence > 0.0 && confidence < 1.0)) confidence = 0.99;
+  URF_HIP(hipSetDevice(device));
+  char *d = nullptr;
+  // [nmatch | iters | F 9 f64 | pts0 | pts1 | matches | out | nout | mask | scratch], every block 16-byte aligned
+  const size_t o_n = 0, o_it = 16, o_F = 32, o_p0 = 32 + 80, o_p1 = o_p0 + sizeof(float) * 2 * kCap, o_m = o_p1 + sizeof(float) * 2 * kCap,
+               o_out = o_m + sizeof(DMatchC) * kCap, o_no = o_out + sizeof(DMatchC) * kCap, o_mask = o_no + 16, o_cur = o_mask + kCap,
+               total = o_cur + kCap;
+  URF_HIP(hipMalloc((void **)&d, total));
+  int rc = 0;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && rc == 0) { set_error("urf_cv_find_fundamental: %s", hipGetErrorString(e)); rc = -1; } };
+  fail(hipMemset(d, 0, total));
+  fail(hipMemcpy(d + o_n, &n, sizeof(int), hipMemcpyHostToDevice));
+  fail(hipMemcpy(d + o_p0, pts0, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  fail(hipMemcpy(d + o_p1, pts1, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  double F0[9];
+  for (int i = 0; i < 9; ++i) F0[i] = F9 ? F9[i] : 0.0;
+  fail(hipMemcpy(d + o_F, F0, sizeof(F0), hipMemcpyHostToDevice));
+  if (rc == 0 && launch_cv_ransac((const int *)(d + o_n), (const float *)(d + o_p0), (const float *)(d + o_p1), thresh, confidence, 1,
+                                  d + o_m, d + o_out, (int *)(d + o_no), (uint8_t *)(d + o_mask), (uint8_t *)(d + o_cur), 1, 0,
+                                  (double *)(d + o_F), (int *)(d + o_it)))
+    rc = -1;
+  fail(hipDeviceSynchronize());
+  if (rc == 0) {
+    fail(hipMemcpy(mask, d + o_mask, (size_t)n, hipMemcpyDeviceToHost));
+    if (F9) fail(hipMemcpy(F9, d + o_F, sizeof(double) * 9, hipMemcpyDeviceToHost));
+    if (iterations) fail(hipMemcpy(iterations, d + o_it, sizeof(int), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d);
+  return rc;
+}

@@ -16,7 +16,8 @@
 
 namespace urf {
 int launch_cv_ransac(const int *nmatch, const float *pts0, const float *pts1, double thresh, double confidence, int enable,
-                     const void *matches, void *out, int *nout, uint8_t *inliers, uint8_t *scratch, int P, hipStream_t st);
+                     const void *matches, void *out, int *nout, uint8_t *inliers, uint8_t *scratch, int P, hipStream_t st,
+                     double *F_out = nullptr, int *iters_out = nullptr);
 extern int g_profiling;
 int weights_load(const char *path, int kind, std::vector<float> &out);
 int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, hipStream_t st);

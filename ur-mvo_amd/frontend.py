@@ -586,6 +586,22 @@ def SearchByProjection(camera_fxfycxcy, image_size, pose, features, mappoint_pos
     return out
 
 
+def findFundamentalMat(points0, points1, thresh=3.0, confidence=0.99, device=0):
+    """cv::findFundamentalMat(points0, points1, cv::FM_RANSAC, 3, 0.99, mask) (src/point_matching.cc:50) as the outlier stage 1
+    runs it on the GPU (cvransac.hip; OpenCV 4.2's published algorithm restated, parity unpinned):
+    -> (mask uint8[n], F float64[3, 3] or None when no model was found, hypothesis rounds run)"""
+    p0 = np.ascontiguousarray(points0, np.float32).reshape(-1, 2)
+    p1 = np.ascontiguousarray(points1, np.float32).reshape(-1, 2)
+    assert p0.shape == p1.shape
+    n = p0.shape[0]
+    mask = np.zeros(max(n, 1), np.uint8)
+    Fm = np.zeros(9, np.float64)
+    it = C.c_int(-1)
+    check(_lib.lib().urf_cv_find_fundamental(_p(p0), _p(p1), n, C.c_double(thresh), C.c_double(confidence), _p(mask), _p(Fm),
+                                             C.byref(it), int(device)), "urf_cv_find_fundamental")
+    return mask[:n].copy(), (Fm.reshape(3, 3) if np.any(Fm != 0.0) else None), it.value
+
+
 def slot_to_host(d_slot_ptr):
     feat = np.zeros((CAP, 259), np.float64)
     K = C.c_int(0)
