@@ -185,7 +185,7 @@ def native_frame_stream_run(U, spb, sgb, device_index, prec, Hh, Ww, batch, step
     assert fs.build(spb, sgb), U._lib.lib().urf_last_error()
     NB_ = 5
     fr = np.stack(synth.shift_stream(100, NB_ * batch, Hh, Ww))
-    depth = 2 + 4                        # matchers + 4 batches stay in flight behind a submit (include/urf.h)
+    depth = fs.max_in_flight() - 1       # (matchers + 4 = 6) batches stay in flight behind a submit (include/urf.h)
     got = {}
     nsub = [0]
 

@@ -467,11 +467,13 @@ int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_cols);
  * ref: NULL or n global frame indices (counted from the first submitted frame): frame j is matched
  * against frame ref[j] (-1 = its predecessor) -- the reference matches against the last keyframe
  * (src/tracking.cc:196-203).  A referenced frame must be in this batch or in one of the
- * 2 + history_batches batches before it.  At most `matchers` + 5 batches may be in flight: a submit enqueues its
+ * 2 + history_batches batches before it.  At most urf_fe_max_in_flight() = min(matchers + 5, 3 matchers + 2) batches may be
+ * in flight (a matcher handle holds two begun batches and one enqueued one; 7 with the default two matchers, 5 with one): a
+ * submit enqueues its
  * own SuperPoint, the match call of the batch two submits back and begins the fetch of the batch `matchers` + 1 submits
  * back (the only wait, for that batch's fast pass; a strict handle's exact redo of flagged pairs then runs beside the
  * next batches) -- the loop bench.py times, driven by the caller:
- *     urf_fe_submit(b);  while (urf_fe_in_flight() > matchers + 4 || urf_fe_ready() == 1) urf_fe_collect(...);
+ *     urf_fe_submit(b);  while (urf_fe_in_flight() >= urf_fe_max_in_flight() || urf_fe_ready() == 1) urf_fe_collect(...);
  * A caller that collects right after every submit gets the synchronous behaviour (collect enqueues what is missing). */
 int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, size_t step, size_t frame_stride,
                   const long *ref);
@@ -480,6 +482,8 @@ int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, int cols, s
  * feat: NULL or nframes matrices of 259 x URF_MAX_KEYPOINTS f64 (column-major). */
 int urf_fe_collect(urf_fe *h, int *nframes, int *K, urf_dmatch *matches, int cap, int *nmatch, double *feat);
 int urf_fe_in_flight(urf_fe *h);
+/* the most batches urf_fe_submit accepts before one must be collected (see urf_fe_submit) */
+int urf_fe_max_in_flight(urf_fe *h);
 /* 1 when urf_fe_collect would hand out the oldest batch without waiting for the GPU, 0 when it would wait, <0 on error */
 int urf_fe_ready(urf_fe *h);
 /* 1 if the NEXT urf_fe_submit may name global frame `frame` in `ref` (its slot is still in the ring: one of the last

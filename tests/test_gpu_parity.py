@@ -386,10 +386,12 @@ def test_cpp_drop_in_api_equals_ctypes_path(U, F, sp_blob, sg_blob, pm, tmp_path
     assert np.allclose([float(c) for _, _, c in got], [d for _, _, d in m], rtol=0, atol=1e-7)
 
 
-def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
+@pytest.mark.parametrize("extra,batch,port", [([], 8, "29533"), (["--resolution", "1241x376", "--batch-per-gpu", "4"], 4, "29537")])
+def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path, extra, batch, port):
     """bench.py --gpus 2 with both ranks on cuda:0 (gloo): exercises the frame
-    sharding, the slot all-gather and the cross-rank pairs.  Every pair of the
-    single synthetic stream must still find its ~700 true matches."""
+    sharding, the slot all-gather and the cross-rank pairs in the strict-parity mode (bench.py's default).  Every pair of the
+    single synthetic stream must still find its ~700 true matches.  Second leg: the geometry of BASELINE configs[3] per GPU
+    (1241x376, four frames per rank and step)."""
     import json
     import os
     import subprocess
@@ -398,12 +400,13 @@ def test_bench_multi_rank_control_flow_on_shared_gpu(tmp_path):
     env = dict(os.environ, URF_BENCH_SHARED_GPU="1")
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-         "--warmup", "1", "--repeats", "1"], env=env, text=True, stderr=subprocess.DEVNULL)
+         "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+         "--warmup", "1", "--repeats", "1"] + extra, env=env, text=True, stderr=subprocess.DEVNULL)
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
-    assert d["matches_per_step"] > 8 * 600          # rank 0's 8 pairs, incl. the pair that crosses the batch seam
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * batch and d["scaling"] == "weak"
+    assert d["config"]["precision"] == "strict parity"
+    assert d["matches_per_step"] > batch * 600      # rank 0's pairs, incl. the pair that crosses the batch seam
 
 
 def test_bench_event_ordered_rccl_exchange_in_a_one_rank_group():
@@ -652,7 +655,7 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
     (src/tracking.cc:321-377) as the CPU ORACLE runs it: O.sp_infer / O.match_points on the same 21 frames.
     Exact mode: features and match lists bit for bit; fast modes: the same keypoint sets, and correspondences that may differ
     in a pair whose decisive matching scores are a near-tie (measured on this stream: one pair of twenty differs in two of its
-    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 7 = matchers + 5 is the pipelined loop
+    ~700 correspondences).  depth: batches the caller keeps in flight before it collects -- 7 = urf_fe_max_in_flight() is the pipelined loop
     bench.py times (SuperPoint two batches ahead of the matchers, fetches begun one step before they are ended), 1 = a collect
     right after every submit (integration/tracking.patch)."""
     from conftest import oracle_frames_and_pairs
@@ -697,6 +700,42 @@ def test_frame_stream_equals_the_per_frame_calls_of_the_reference(U, F, O, sp_bl
     # equally good partners -- scores 0.508240 and 0.508241 -- and the descriptor noise of the fast SuperPoint decides between
     # them; the guarded matcher flags that pair, tools/gpu_pairdiag.py)
     assert differing <= 1
+
+
+@pytest.mark.parametrize("matchers,prec", [(1, 3), (1, 0), (3, 3), (4, 2)])
+def test_frame_stream_at_full_depth_with_one_three_and_four_matchers(U, F, O, sp_blob, sg_blob, matchers, prec):
+    """the in-flight limit is min(matchers + 5, 3 matchers + 2) (a handle holds two begun batches and one enqueued one): with ONE
+    matcher every batch shares a handle, and round 5's loop began a third batch on it once six were in flight (deferred error at
+    the next collect).  Fill the stream to urf_fe_max_in_flight(), check that one more submit is refused, and compare every
+    list with the oracle's (strict / exact: index lists; guarded: pairs may differ in a near-tie)."""
+    from conftest import oracle_frames_and_pairs
+    frames = np.stack(U.synth.shift_stream(31, 18, 240, 320))
+    ofeats, olists = oracle_frames_and_pairs(list(frames), [(t - 1, t) for t in range(1, 18)], max_kp=300)
+    fs = F.FrameStream(F.SuperPointConfig(max_keypoints=300), F.SuperGlueConfig(), batch=2, max_height=240, max_width=320,
+                       precision=prec, matchers=matchers)
+    assert fs.build(sp_blob, sg_blob)
+    cap = fs.max_in_flight()
+    assert cap == min(matchers + 5, 3 * matchers + 2)
+    got = []
+    nb = 0
+    for b0 in range(0, 18, 2):
+        if fs.in_flight() == cap:
+            with pytest.raises(RuntimeError, match="in flight"):
+                fs.submit(frames[b0:b0 + 2])
+            got += fs.collect()[1]
+        fs.submit(frames[b0:b0 + 2]); nb += 1
+    assert fs.in_flight() == min(cap, nb)
+    while fs.in_flight():
+        got += fs.collect()[1]
+    assert len(got) == 18 and len(got[0]) == 0
+    for t in range(1, 18):
+        a, ref = _as_tuples(got[t]), olists[t - 1]
+        if prec == 0:
+            assert a == ref, t
+        elif prec == 3:
+            assert [(q, t_) for q, t_, _ in a] == [(q, t_) for q, t_, _ in ref], t
+        else:
+            assert len({(q, t_) for q, t_, _ in a} & {(q, t_) for q, t_, _ in ref}) >= 0.97 * len(ref), t
 
 
 def test_frame_stream_keyframe_references_camera_and_errors(U, F, O, sp_blob, sg_blob, sp640, pm):

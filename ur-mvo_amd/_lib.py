@@ -23,7 +23,7 @@ SYMBOLS = [
     "urf_cam_create", "urf_cam_create_from_maps", "urf_cam_destroy", "urf_cam_maps", "urf_cam_undistort",
     "urf_cam_undistort_device", "urf_cam_sync", "urf_cam_size",
     "urf_fe_create", "urf_fe_build", "urf_fe_build_files", "urf_fe_destroy", "urf_fe_set_camera", "urf_fe_submit",
-    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_ready", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
+    "urf_fe_collect", "urf_fe_in_flight", "urf_fe_max_in_flight", "urf_fe_ready", "urf_fe_frame_resident", "urf_fe_superpoint", "urf_fe_matcher", "urf_pm_stream",
     "urf_search_by_projection", "urf_search_by_projection_slot", "urf_probe_mfma_f16",
     "urf_ransac_find_F_sets", "urf_minimal_sets", "urf_epipolar_reconstruct_sets",
     "urf_comm_unique_id", "urf_comm_init", "urf_sp_near_tie_reruns", "urf_sp_calibrate_guard", "urf_sp_calibrate_guard_device", "urf_pm_near_tie_reruns", "urf_pm_calibrate_guard", "urf_pm_guard_state", "urf_pm_redo_engine_stats", "urf_pm_near_tie_flags", "urf_comm_init_all", "urf_comm_group_start", "urf_comm_group_end", "urf_comm_init_loopback", "urf_comm_destroy", "urf_comm_world", "urf_comm_rank",

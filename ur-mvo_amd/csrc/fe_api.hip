@@ -78,8 +78,8 @@ extern "C" int urf_fe_create(const urf_fe_config *cfg, urf_fe **out) {
   h->B = cfg->batch;
   h->M = cfg->matchers <= 0 ? 2 : (cfg->matchers > kMaxMatchers ? kMaxMatchers : cfg->matchers);
   // ring: entry k is refilled by SuperPoint(b) while every batch up to b - M - 2 has had its fetch begun (its fast pass is over)
-  // and a match reads slots up to 2 + history_batches submits old (NB >= M + 4 + history_batches); up to M + 5 batches are in
-  // flight -- a flagged batch's redo waits one step in the shared engine's pool for the next batch's flagged pairs, then runs
+  // and a match reads slots up to 2 + history_batches submits old (NB >= M + 4 + history_batches); up to min(M + 5, 3 M + 2) batches are in
+  // flight (fe_max_in_flight) -- a flagged batch's redo waits one step in the shared engine's pool for the next batch's flagged pairs, then runs
   // for about two (the hand-out lag of DESIGN.md section 12) -- and an entry is not refilled before its batch has been
   // collected: NB = M + 6 + history_batches
   h->NB = h->M + 6 + (cfg->history_batches > 0 ? cfg->history_batches : 0);
@@ -179,6 +179,16 @@ extern "C" int urf_fe_set_camera(urf_fe *h, urf_cam *cam, int map_rows, int map_
   return 0;
 }
 
+// Batches that may be in flight: min(M + 5, 3 M + 2).  A matcher handle holds at most TWO begun batches and one whose match
+// call is enqueued (sg_api.hip: kBegun, "a second un-fetched batch is refused"), and the two newest batches have SuperPoint
+// only: 3 M + 2 -- which is below M + 5 for ONE matcher (5, not 6: the sixth submit's match(b - 2) would need a third begun batch).
+static int fe_max_in_flight(const urf_fe *h) { return h->M + 5 < 3 * h->M + 2 ? h->M + 5 : 3 * h->M + 2; }
+static int fe_begun_on_handle(const urf_fe *h, long batch) {
+  int n = 0;
+  for (const auto &q : h->pending) n += (q.batch % h->M == batch % h->M && q.begun && !q.s0.empty()) ? 1 : 0;
+  return n;
+}
+
 static int fe_enqueue_match(urf_fe *h, urf_fe::Pending &p) {
   urf_pm *pm = h->pm[p.batch % h->M];
   if (!p.s0.empty()) {
@@ -215,7 +225,8 @@ static int fe_pump(urf_fe *h) {
     if (h->pending[i].batch <= b - 2 && !h->pending[i].matched && fe_force(h, i)) return -1;
   for (size_t i = 0; i < h->pending.size(); ++i) {
     urf_fe::Pending &q = h->pending[i];
-    if (q.batch <= b - h->M - 1 && q.matched && !q.begun && fe_begin(h, q)) return -1;
+    // (opportunistic: only while the handle has room for another begun batch -- fe_force begins it when a match call needs it)
+    if (q.batch <= b - h->M - 1 && q.matched && !q.begun && fe_begun_on_handle(h, q.batch) < 2 && fe_begin(h, q)) return -1;
   }
   return 0;
 }
@@ -247,7 +258,7 @@ extern "C" int urf_fe_submit(urf_fe *h, const uint8_t *frames, int n, int rows, 
                              size_t frame_stride, const long *ref) {
   URF_CHECK(h && h->built, "urf_fe_submit: handle is not built");
   URF_CHECK(frames && n >= 1 && n <= h->B && rows > 0 && cols > 0 && step >= (size_t)cols, "urf_fe_submit: bad argument");
-  URF_CHECK((int)h->pending.size() <= h->M + 4, "urf_fe_submit: %d batches in flight, collect one first", h->M + 5);
+  URF_CHECK((int)h->pending.size() < fe_max_in_flight(h), "urf_fe_submit: %d batches in flight, collect one first", fe_max_in_flight(h));
   URF_HIP(hipSetDevice(h->cfg.sp.device));
   if (!h->d_raw) {
     h->rows = rows; h->cols = cols;
@@ -369,5 +380,6 @@ extern "C" int urf_fe_ready(urf_fe *h) {
 }
 
 extern "C" int urf_fe_in_flight(urf_fe *h) { return h ? (int)h->pending.size() : 0; }
+extern "C" int urf_fe_max_in_flight(urf_fe *h) { return h ? fe_max_in_flight(h) : 0; }
 extern "C" urf_sp *urf_fe_superpoint(urf_fe *h) { return h ? h->sp : nullptr; }
 extern "C" urf_pm *urf_fe_matcher(urf_fe *h, int i) { return (h && i >= 0 && i < h->M) ? h->pm[i] : nullptr; }

@@ -185,7 +185,8 @@ struct urf_pm {
   // batches whose fetch has begun (urf_pm_fetch_begin) and not ended, oldest first
   struct Begun {
     int P = 0, set = 0, n = 0;       // pairs, result set, pairs being redone (0: the lists were final at begin)
-    bool launched = false;           // the entry's redo pass has been enqueued on the engine's stream (else it waits in the pool)
+    std::atomic<bool> launched{false};   // the entry's redo pass has been enqueued on the engine's stream (else it waits in the pool); written under the pool's mutex by whichever sharing handle flushes, read by the owner
+    std::atomic<bool> failed{false};     // its pass could not be enqueued (a launch or copy failed): urf_pm_fetch_end reports an error instead of handing out un-redone lists
     bool want_Z = false, ransac = false;   // of the batch (a pass takes jobs that agree on them)
     int idx[64];                     // slot k of the engine = pair idx[k] of the batch
     float resid[64];                 // the batch's Sinkhorn residuals (urf_pm_sinkhorn_residuals)
@@ -203,8 +204,10 @@ struct urf_pm {
   float *h_up = nullptr;           // pinned staging of the one-pair host calls: kin | kxy | x (allocated by the first such call)
   int up_n[2] = {0, 0};            //   rows of it the last call filled, per image
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
+  int fast_flags[64];              // guard words of the batch whose fast pass was enqueued last, recorded by its first begin (a retried begin reads these: the pinned words are cleared once)
   bool flags_recorded = false;
   unsigned long long pairs_flagged = 0;
+  bool calib_said = false;         // "the automatic guard calibration could not run" has been said for THIS handle (no process-global state: the reference calls from fresh threads)
   // automatic calibration of the guard's margin (urf_sg_config.calibrate_pairs): pairs still to be measured, the largest difference seen
   int calib_left = 0, calib_failures = 0;
   float calib_worst = 0.0f;
@@ -596,13 +599,21 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
   if (h->pool) {
     urf::RedoPool *pool = h->pool;
     bool last = false;
+    hipStream_t engine_st = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(pool->mu);
+      for (size_t i = 0; i < pool->queue.size();)      // this handle's jobs that were never launched go with it
+        if (pool->queue[i].owner == h) pool->queue.erase(pool->queue.begin() + (long)i); else ++i;
+      if (pool->engine && pool->engine->built) engine_st = pool->engine->st;
+    }
+    // a pass that still writes into this handle's sets: waited for OUTSIDE the registry's and the pool's locks (no job of this
+    // handle can be launched any more; the engine lives until its last owner -- which this handle still is one of -- lets go), so
+    // that other handles' builds, destroys and flushes do not stall behind a device wait
+    if (engine_st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(engine_st); }
     {
       std::lock_guard<std::mutex> registry(urf::g_pools_mu);   // (the order of urf_pm_build: registry, then pool)
       {
         std::lock_guard<std::mutex> lock(pool->mu);
-        for (size_t i = 0; i < pool->queue.size();)      // this handle's jobs that were never launched go with it
-          if (pool->queue[i].owner == h) pool->queue.erase(pool->queue.begin() + (long)i); else ++i;
-        if (pool->engine && pool->engine->built) (void)hipStreamSynchronize(pool->engine->st);   // (a pass that still writes into this handle's sets)
         pool->refs -= 1;
         last = pool->refs == 0;
       }
@@ -920,6 +931,13 @@ static int pool_flush(urf::RedoPool *pool) {
         ++i;
       }
     }
+    // a pass that fails half-way has taken its jobs out of the queue: mark every job of it that was not launched, so that its
+    // owner's urf_pm_fetch_end reports the failure instead of waiting on an event that was never recorded and handing out the
+    // un-redone fast lists (the jobs of OTHER owners in a shared pool included)
+    struct MarkFailed {
+      std::vector<urf::RedoPool::Job> &pass; bool armed;
+      ~MarkFailed() { if (armed) for (const auto &j : pass) { urf_pm::Begun &e = j.owner->bq[j.entry]; if (!e.launched) e.failed = true; } }
+    } mark{pass, true};
     int k0 = 0;
     for (const auto &j : pass) {
       urf_pm::Begun &e = j.owner->bq[j.entry];
@@ -957,6 +975,7 @@ static int pool_flush(urf::RedoPool *pool) {
       e.launched = true;
       k0 += e.n;
     }
+    mark.armed = false;
     pool->passes += 1;
     pool->pairs += (unsigned long long)N;
     pool->merged_passes += pass.size() > 1;
@@ -965,9 +984,15 @@ static int pool_flush(urf::RedoPool *pool) {
 }
 // the entry's redo must be on the engine's stream before anybody waits for (or asks about) its event
 static int pm_ensure_launched(urf_pm *h, urf_pm::Begun &e) {
-  if (e.n == 0 || e.launched) return 0;
-  std::lock_guard<std::mutex> lock(h->pool->mu);
-  return e.launched ? 0 : pool_flush(h->pool);
+  if (e.n == 0) return 0;
+  if (!e.launched && !e.failed) {
+    std::lock_guard<std::mutex> lock(h->pool->mu);
+    if (!e.launched && !e.failed && pool_flush(h->pool)) return -1;
+  }
+  URF_CHECK(!e.failed, "the exact redo of this batch's flagged pairs could not be enqueued (an earlier launch or copy on the redo "
+            "engine failed): its lists are NOT the strict mode's and are withheld");
+  URF_CHECK(e.launched, "the exact redo of this batch's flagged pairs is neither queued nor launched");
+  return 0;
 }
 
 static int pm_begin_batch(urf_pm *h) {
@@ -975,7 +1000,7 @@ static int pm_begin_batch(urf_pm *h) {
   const int entry = (h->bq_head + h->bq_n) % urf_pm::kBegun;
   urf_pm::Begun &e = h->bq[entry];
   const int P = h->last_P;
-  e.P = P; e.set = h->cur_set; e.n = 0; e.launched = false; e.want_Z = h->last_Z; e.ransac = h->last_ransac;
+  e.P = P; e.set = h->cur_set; e.n = 0; e.launched = false; e.failed = false; e.want_Z = h->last_Z; e.ransac = h->last_ransac;
   e.t0 = std::chrono::steady_clock::now();
   h->bq_n += 1;       // (rolled back below when a launch or copy of the redo fails: the entry must not stay queued half-made)
   struct Rollback { urf_pm *h; bool armed; ~Rollback() { if (armed) h->bq_n -= 1; } } rollback{h, true};
@@ -983,17 +1008,19 @@ static int pm_begin_batch(urf_pm *h) {
   memset(e.flags, 0, sizeof(e.flags));
   memcpy(e.resid, h->last_resid, sizeof(e.resid));
   if (!h->guarded || P < 1) { rollback.armed = false; return 0; }
-  if (!h->flags_recorded) {             // (a second call after a redo finds the pinned words cleared: keep the recorded ones)
-    for (int p = 0; p < P && p < 64; ++p) { h->last_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
+  if (!h->flags_recorded) {             // (a second call -- after a redo, or a retry after a failed begin -- finds the pinned words cleared: keep the recorded ones)
+    memset(h->fast_flags, 0, sizeof(h->fast_flags));
+    for (int p = 0; p < P && p < 64; ++p) { h->fast_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
+    for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
     h->flags_recorded = true;
   }
+  memcpy(h->last_flags, h->fast_flags, sizeof(h->last_flags));
   h->redo_ms = 0.0f;
-  memcpy(e.flags, h->last_flags, sizeof(e.flags));
+  memcpy(e.flags, h->fast_flags, sizeof(e.flags));
   memcpy(e.stage, h->stage_ms, sizeof(e.stage));
   int n = 0;
-  for (int p = 0; p < P; ++p)
-    if (h->h_gflags[p] || h->redo_all) e.idx[n++] = p;
-  for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
+  for (int p = 0; p < P && p < 64; ++p)
+    if (h->fast_flags[p] || h->redo_all) e.idx[n++] = p;
   urf::RedoPool *pool = h->pool;
   if (!h->redo_pairs || !pool) { rollback.armed = false; return 0; }
   if (n == 0) {
@@ -1036,7 +1063,10 @@ static int pm_end_batch(urf_pm *h, int *set, int *P) {
   urf_pm::Begun &e = h->bq[h->bq_head];
   h->redo_ms = 0.0f;
   if (e.n > 0) {
-    if (pm_ensure_launched(h, e)) return -1;
+    if (pm_ensure_launched(h, e)) {
+      if (e.failed) { h->bq_head = (h->bq_head + 1) % urf_pm::kBegun; h->bq_n -= 1; }   // the batch is lost; the handle goes on
+      return -1;
+    }
     URF_HIP(hipEventSynchronize(e.ev_done));
     h->pairs_redone += (unsigned long long)e.n;
     h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e.t0).count();
@@ -1121,8 +1151,7 @@ static int pm_check_resident(urf_pm *h) {
   if (h->h_rs_err[0] == 2) {
     // the streaming kernels' result fails the bound as well: not the launch -- the pair's couplings (not finite, or sums that
     // leave the fp32 range) -- keep the result, say so once
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "liburf_front: the streaming Sinkhorn leaves the same residual: the bound is too tight for these couplings (result kept)\n"); }
+    if (!h->calib_said) { h->calib_said = true; fprintf(stderr, "liburf_front: the streaming Sinkhorn leaves the same residual: the bound is too tight for these couplings (result kept)\n"); }
     memset(h->h_rs_err, 0, 4 * sizeof(int));
     URF_HIP(hipMemsetAsync(h->rs_err, 0, 4 * sizeof(int), h->st));
   }
@@ -1381,8 +1410,7 @@ extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slo
 static const float kGuardSgZCap = 2.5e-3f;
 static int pm_auto_calibrated(urf_pm *h, int P, int rc) {
   if (rc) {   // (a give-up of the resident Sinkhorn, no memory for the scratch copy): the caller's batch does not fail for it -- the next one is measured
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "liburf_front: the automatic guard calibration could not run (%s); it is tried again with the next pairs\n", urf_last_error()); }
+    if (!h->calib_said) { h->calib_said = true; fprintf(stderr, "liburf_front: the automatic guard calibration could not run (%s); it is tried again with the next pairs\n", urf_last_error()); }
     if (++h->calib_failures >= 16) {   // ... but not for ever: every attempt costs a fast and an exact pass
       h->calib_left = 0;
       fprintf(stderr, "liburf_front: the automatic guard calibration failed %d times in a row; the handle keeps the margin %.3g (urf_pm_calibrate_guard remains)\n",

@@ -1180,8 +1180,9 @@ int launch_sinkhorn_resident(const int *counts, const float *C, float *u, float 
     d.cus = prop.multiProcessorCount;
 #ifdef URF_EXPERIMENTS
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
+    // (the padding knob URF_SINKHORN_WIDE_PAD of the experiments build only: the product launches the kernel with no dynamic LDS)
     URF_HIP(hipFuncSetAttribute((const void *)sinkhorn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#endif
     URF_HIP(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
     URF_HIP(hipEventRecord(d.last, st));
   }

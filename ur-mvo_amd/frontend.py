@@ -558,6 +558,10 @@ class FrameStream:
     def in_flight(self):
         return _lib.lib().urf_fe_in_flight(self._h)
 
+    def max_in_flight(self):
+        """batches submit() accepts before one must be collected: min(matchers + 5, 3 matchers + 2)"""
+        return _lib.lib().urf_fe_max_in_flight(self._h)
+
     def frame_resident(self, frame):
         """may the next submit() name global frame `frame` as a reference? (its slot is still in the ring)"""
         return check(_lib.lib().urf_fe_frame_resident(self._h, C.c_long(int(frame))), "urf_fe_frame_resident") == 1
