@@ -170,6 +170,13 @@ def stream_run(U, spb, sgb, dev, device_index, prec, Hh, Ww, batch, steps, repea
            "regions_frames_per_s": [round(steps * batch / r, 2) for r in regions],
            "pairs": sum(x["pairs"] for x in g), "pairs_flagged": sum(x["flagged"] for x in g), "pairs_redone_exact": sum(x["redone"] for x in g),
            "sinkhorn_fallbacks": sum(m.sinkhorn_fallbacks() for m in pms)}
+    if prec == 3:
+        gs = [m.guard_state() for m in pms]
+        out["guard"] = {"margin_in_use": max(g_["margin"] for g_ in gs), "calibrated_difference": max(g_["measured"] for g_ in gs),
+                        "online_largest_difference_on_a_redone_pair": max(g_["online_worst"] for g_ in gs),
+                        "online_pairs_sampled": sum(g_["online_pairs"] for g_ in gs), "margin_raises": sum(g_["margin_raises"] for g_ in gs),
+                        "online_violations": sum(g_["online_violations"] for g_ in gs), "audits": sum(g_["audits"] for g_ in gs),
+                        "audit_mismatches": sum(g_["audit_mismatches"] for g_ in gs), "every_pair_redone": any(g_["redo_all"] for g_ in gs)}
     del pipe, pms, sp, d_fr
     return (out, kept) if keep else out
 
@@ -610,6 +617,33 @@ def main():
                     secondary[name_] = stream_run(U, spb, sgb, dev, local_rank, prec_, 480, 640, 8, 30, 3)
             if PREC != 3:
                 secondary["strict_parity_640x480_batch8"] = stream_run(U, spb, sgb, dev, local_rank, 3, 480, 640, 8, 30, 3)
+            # The strict mode's rate as a function of what the guard flags.  The flag rate is a property of the matcher's WEIGHTS (how
+            # far the graph layers move the descriptors, hence the split-f16 error and the margin the handle calibrates) and of
+            # the data; the headline's seeded weights (synth.sg_weights: gnn_gain 0.5) are one point.  The same loop on weights
+            # with 2x and 3x the residual gain, each against the exact mode on the same weights (index lists must be equal).
+            curve = []
+            for gain in (0.5, 1.0, 1.5):
+                sgb_g = sgb if gain == 0.5 else synth.pack_sg(synth.sg_weights(0, gnn_gain=gain))
+                r_, lists_ = stream_run(U, spb, sgb_g, dev, local_rank, 3, 480, 640, 8, 20, 3, keep=True)
+                x_, xl_ = stream_run(U, spb, sgb_g, dev, local_rank, 0, 480, 640, 8, 10, 1, keep=True)
+                tot_ = same_ = 0
+                for b_ in xl_:
+                    if b_ in lists_ and b_ >= 5:
+                        for a_, e_ in zip(lists_[b_], xl_[b_]):
+                            tot_ += 1
+                            same_ += int(len(a_) == len(e_) and np.array_equal(a_["queryIdx"], e_["queryIdx"]) and np.array_equal(a_["trainIdx"], e_["trainIdx"]))
+                curve.append({"gnn_gain": gain, "frames_per_s": r_["frames_per_s"], "regions_frames_per_s": r_["regions_frames_per_s"],
+                              "pairs": r_["pairs"], "pairs_flagged": r_["pairs_flagged"], "pairs_redone_exact": r_["pairs_redone_exact"],
+                              "flag_rate": round(r_["pairs_flagged"] / max(1, r_["pairs"]), 4), "guard": r_["guard"],
+                              "exact_mode_frames_per_s_same_weights": x_["frames_per_s"],
+                              "pairs_with_the_exact_modes_index_list": f"{same_}/{tot_}"})
+                if same_ != tot_:
+                    print(f"bench.py: STRICT PARITY VIOLATED at gnn_gain {gain}: {tot_ - same_} of {tot_} pairs differ from the exact mode", file=sys.stderr)
+            secondary["strict_parity_vs_flag_rate"] = {
+                "what": "the strict loop (640x480, batch 8, 20 steps x 3 regions) on seeded matcher weights of growing residual gain "
+                        "(synth.sg_weights(0, gnn_gain=g); 0.5 = the headline's): the margin each handle calibrates on its first pairs, "
+                        "the pairs its guard flags, the rate, and the check of every list against the exact mode on the same weights",
+                "curve": curve}
             secondary["native_frame_stream_strict_640x480"] = native_frame_stream_run(U, spb, sgb, local_rank, 3, 480, 640, 8, args.steps, 3,
                                                                                          kept_ref=kept if PREC == 3 else None)
             # (timed regions as long as the headline's: a region ends with a drain of the pipeline, 2 - 3 steps of latency)
@@ -654,7 +688,11 @@ def main():
                        "resolution": args.resolution, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
                        "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": {0: "exact", 1: "fast", 2: "guarded fast", 3: "strict parity"}[PREC],
-                       "weights": "seeded synthetic (reference ships none)",
+                       "weights": {"what": "seeded synthetic (the reference ships none): synth.sp_weights(0), synth.sg_weights(0)",
+                                   "matcher_gnn_gain": 0.5,
+                                   "strict_mode_pairs_flagged_and_redone": f"{sum(h_['pairs_redone_exact'] for h_ in per_rank)}/{sum(h_['pairs'] for h_ in per_rank)}",
+                                   "note": "the strict mode's rate depends on the share of pairs its guard flags, a property of the weights and "
+                                           "the data: secondary.strict_parity_vs_flag_rate holds the rate at other gains"},
                        "streams": {0: "one in-order stream", 1: "2 streams: SP(b+1) beside Sinkhorn(b)",
                                    2: f"{1 + MATCHERS} streams: SuperPoint enqueued {AHEAD} batches ahead, {MATCHERS} matcher handles in turn"}[OVERLAP],
                        "parallelism": f"dp{world}: frame shards + 1 RCCL all-gather of feature slots/step (urf_comm_*, C ABI) + "

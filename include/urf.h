@@ -205,6 +205,13 @@ typedef struct {
    * for it (urf_pm_fetch_ready / _end).  Measured slower still (one more step of latency). */
   int redo_merge;
   int redo_shared_engine;
+  /* online check of the guard's error model (strict parity; appended, 0 = default): every exact redo leaves the exact
+   * log-assignment of a pair the fast pass has also matched; the largest fast-vs-exact difference on the entries the fast
+   * decisions rested on is folded into the handle's margin when the redo is handed out (raised to 1.6 x the difference once it
+   * exceeds margin / 1.6, said on stderr; above 2.5e-3 every pair is redone) -- urf_pm_guard_state() reports it.  audit_period:
+   * one UNFLAGGED pair of every audit_period-th begun batch goes through the exact engine as well (the only sample on pairs the
+   * guard passed: its exact index list must equal the fast one); 0 = 256, < 0 = no audits. */
+  int audit_period;
 } urf_sg_config;
 
 typedef struct { int queryIdx, trainIdx; float distance; } urf_dmatch; /* cv::DMatch fields used at src/point_matching.cc:37 */
@@ -396,7 +403,10 @@ int urf_pm_redo_engine_stats(urf_pm *h, double *out, int n);
 int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const void *const *d_slots1, double *out);
 /* the guard of a precision-2 / -3 handle: out[0] = the margin in use (log domain), out[1] = the largest fast-vs-exact difference
  * the calibrations (automatic or explicit) have measured, out[2] = pairs the automatic calibration still wants to measure,
- * out[3] = 1 when the measured error exceeded the cap and a strict handle redoes every pair in the exact mode (n <= 4 values) */
+ * out[3] = 1 when the measured error exceeded the cap and a strict handle redoes every pair in the exact mode; the online check
+ * (urf_sg_config.audit_period): out[4] = the largest fast-vs-exact difference any redone pair has shown, out[5] = redone pairs
+ * sampled, out[6] = times the margin was raised for it, out[7] = times it exceeded the margin its batch had been guarded with,
+ * out[8] = unflagged pairs audited, out[9] = audited pairs whose exact index list differed from the fast one (n <= 10 values) */
 int urf_pm_guard_state(urf_pm *h, double *out, int n);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
@@ -603,6 +613,11 @@ int urf_probe_mfma_roof(int device, int waves_per_cu, int iters, int mode, float
 /* diagnostics of the linear-layer kernel for tools/gpu_h2fixed.py: 1 = non-temporal stores, 2 = no stores, 4 = one K chunk only
  * (2 and 4 give wrong results: timing only); 0 restores the product behaviour */
 int urf_probe_h2gemm_xflags(int flags);
+/* A/B switches of round 6's small-grid kernels (bit-identical forms of the fast matcher's linear and attention kernels):
+ * urf_probe_h2gemm_deep: 0 = never the deep-ring tile, 1 = the launcher's policy (default), 6 / 3 = that ring depth everywhere;
+ * urf_probe_attn_variant: -1 = the launcher's policy, 0 .. 4 = 1x8, 2x4, 2x8, 1x4, 1x2 (query tiles per wave x waves) */
+int urf_probe_h2gemm_deep(int depth);
+int urf_probe_attn_variant(int variant);
 #endif
 
 #ifdef __cplusplus

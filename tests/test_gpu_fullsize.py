@@ -717,7 +717,8 @@ def test_strict_handle_calibrates_itself_on_other_weights(U, F):
     trained weights have other activation ranges.  A strict handle measures itself on the first pairs it sees
     (urf_sg_config.calibrate_pairs, default 8): with a second weight set whose residual-stream gain is three times the
     default's the split-f16 error grows, the margin follows it, and every list still equals the exact mode's index for
-    index.  With the calibration switched off the same handle keeps the built-in margin (what round 4 shipped)."""
+    index.  With the calibration switched off the same handle keeps the built-in margin (what round 4 shipped) -- until the
+    online check (round 6: the by-product of every exact redo, and an audit of unflagged pairs) corrects it."""
     sgw = U.synth.pack_sg(U.synth.sg_weights(1, gnn_gain=1.5))
     rng = np.random.default_rng(80)
     pairs = []
@@ -748,6 +749,24 @@ def test_strict_handle_calibrates_itself_on_other_weights(U, F):
     redone = st.near_tie_reruns()["redone"]
     assert st.near_tie_reruns()["pairs"] == len(pairs)              # the calibration passes are not counted as pairs
     print(f"calibrated margin {g['margin']:.3g} (measured {g['measured']:.3g} on 8 pairs), {redone} of {len(pairs)} pairs redone")
+    # the online check: every redo's by-product (fast against exact on the entries the fast decisions rested on) is folded into the
+    # margin for the life of the handle -- sampled on exactly the redone pairs, never above the margin its batch was guarded with
+    assert g["online_pairs"] == redone and g["online_violations"] == 0 and g["audits"] == 0
+    assert (g["online_worst"] > 0.0) == (redone > 0) and g["margin"] >= 1.6 * g["online_worst"] - 1e-9
+    # ... and it is what saves a handle whose start-up calibration is off (or saw unrepresentative pairs): with an audit of every
+    # batch's unflagged pair (audit_period 1) every pair goes through the exact engine, the built-in 2.2e-4 is found too small
+    # for these weights on the first pairs and the margin is raised to 1.6 x the largest difference seen, as the calibration
+    # would have; the lists handed out are the exact engine's
+    aud = F.PointMatching(F.SuperGlueConfig(), precision=3, calibrate_pairs=-1, audit_period=1)
+    assert aud.build(sgw) and abs(aud.guard_state()["margin"] - 2.2e-4) < 1e-9
+    for i, (f0, f1) in enumerate(pairs):
+        assert [(q, t) for q, t, _ in aud.MatchingPoints(f0, f1, True)] == [(q, t) for q, t, _ in ex.MatchingPoints(f0, f1, True)], i
+    ga, ra = aud.guard_state(), aud.near_tie_reruns()
+    assert ga["audits"] + ra["redone"] == len(pairs) == ga["online_pairs"] and ra["redone"] == ra["flagged"]
+    assert ga["margin_raises"] >= 1 and ga["online_worst"] > 2.2e-4 / 1.6 and ga["margin"] >= 1.6 * ga["online_worst"] - 1e-9
+    assert ga["online_worst"] >= 0.5 * g["measured"]               # the same quantity the calibration measures, on other pairs
+    print(f"online margin {ga['margin']:.3g} after {ga['margin_raises']} raises (largest difference {ga['online_worst']:.3g}), "
+          f"{ga['audits']} audits, {ga['audit_mismatches']} audited lists differed from the fast ones")
 
 
 def test_strict_handles_share_a_redo_engine_and_merge_consecutive_batches(U, F, sp_blob, sg_blob):
@@ -878,3 +897,35 @@ def test_sinkhorn_stage_vs_float64_on_the_same_couplings(U, O, sg_exact, sg_fast
     Z64 = Cd + u[:, None] + v[None, :] - norm
     err = np.abs(Z - Z64).max()
     assert err < (1e-4 if prec else 1e-3), err
+
+
+# ------------------------------------------------------------------ round 6: the small-grid kernels of the fast matcher
+@pytest.mark.parametrize("n0,n1", [(1000, 1000), (1024, 777), (130, 1000)])
+def test_small_grid_kernels_give_the_bits_of_the_batch_kernels(Uexp, sg_blob, n0, n1):
+    """One pair cannot fill the chip with 128-row tiles and 128-query attention workgroups: the per-call path runs the
+    deep-ring linear tile (h2gemm_deep_tile: 64 rows, six LDS stages, five chunks in flight) and attention on 32-query
+    workgroups.  Both keep every accumulator's operations and their order, so the whole log-assignment matrix must come out
+    bit for bit as with the kernels a batch of eight runs (the switches of the experiments build select them at run time)."""
+    Fx, L = Uexp.frontend, Uexp._lib.lib()
+    rng = np.random.default_rng(n0 + n1)
+    f0 = make_features(rng, n0)
+    f1 = make_features(rng, n1, planted_from=f0, m=min(n0, n1) // 2)
+    from oracle import oracle as O
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
+    sg = Fx.SuperGlue(Fx.SuperGlueConfig(), precision=1)
+    assert sg.build(sg_blob)
+    out = {}
+    try:
+        for name, deep, attn in (("batch kernels", 0, 0), ("policy", 1, -1), ("deep 6 + 1x2", 6, 4), ("deep 3 + 1x4", 3, 3)):
+            L.urf_probe_h2gemm_deep(deep)
+            L.urf_probe_attn_variant(attn)
+            out[name] = sg.infer(nf0, nf1, want_scores=True)
+    finally:
+        L.urf_probe_h2gemm_deep(1)
+        L.urf_probe_attn_variant(-1)
+    ref = out["batch kernels"]
+    assert (ref[0] >= 0).sum() >= min(n0, n1) // 2 - 40
+    for name, o in out.items():
+        for a, b in zip(o, ref):
+            assert np.array_equal(a, b), name
+

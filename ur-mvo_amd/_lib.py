@@ -32,7 +32,7 @@ SYMBOLS = [
 ]
 # exported by the experiments build only (#ifdef URF_EXPERIMENTS in include/urf.h): fault injection, kernel A/B switches, diagnostics
 EXPERIMENT_SYMBOLS = [
-    "urf_probe_h2gemm_variant", "urf_probe_h2gemm_xflags", "urf_probe_sinkhorn_stamps", "urf_probe_sinkhorn_fault",
+    "urf_probe_h2gemm_variant", "urf_probe_h2gemm_xflags", "urf_probe_h2gemm_deep", "urf_probe_attn_variant", "urf_probe_sinkhorn_stamps", "urf_probe_sinkhorn_fault",
     "urf_probe_sinkhorn_backoff", "urf_probe_sinkhorn_corrupt", "urf_probe_mfma_roof",
 ]
 
@@ -50,7 +50,7 @@ class SGConfig(C.Structure):
                 ("precision", C.c_int), ("ransac_threshold_px", C.c_float), ("ransac_confidence", C.c_float),
                 ("redo_flagged_pairs", C.c_int), ("guard_margin", C.c_float), ("outlier_stage", C.c_int),
                 ("sinkhorn_residual_bound", C.c_float), ("calibrate_pairs", C.c_int), ("redo_merge", C.c_int),
-                ("redo_shared_engine", C.c_int)]
+                ("redo_shared_engine", C.c_int), ("audit_period", C.c_int)]
 
 
 class EpiConfig(C.Structure):

@@ -697,6 +697,7 @@ static int launch_attn_h2_t(const _Float16 *qkh, const _Float16 *qkl, const _Flo
   return 0;
 }
 
+int g_attn_small = -1;   // (experiments build, urf_probe_attn_variant: force a variant at run time; -1 = the policy below)
 int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth, const _Float16 *vtl,
                    const int *counts, int cross, _Float16 *oh, _Float16 *ol, int nimg, hipStream_t st) {
   // URF_ATTN_VARIANT (A/B runs): 0 = 1 tile x 8 waves, 1 = 2 tiles x 4 waves, 2 = 2 tiles x 8 waves.
@@ -705,16 +706,23 @@ int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth
   static int forced = -2;
   if (forced == -2) {
     const char *e = urf::exp_env("URF_ATTN_VARIANT");
-    forced = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    forced = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
   }
-  const int variant = forced >= 0 ? forced : (nimg >= 16 ? 2 : 0);
+  // Round 6: one or two pairs (the per-call path): 1 tile x 4 waves (64 queries per workgroup: 128 / 256 workgroups) and, for a
+  // lone pair, 1 tile x 2 waves (32 queries: 256 workgroups) -- the same per-wave arithmetic, the same bits; 3 / 4 = those forms
+  const int variant = forced >= 0 ? forced : (g_attn_small >= 0 ? g_attn_small : (nimg >= 16 ? 2 : (nimg <= 2 ? 4 : (nimg <= 4 ? 3 : 0))));
   if (variant == 1) return launch_attn_h2_t<2, 4>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
   if (variant == 2) return launch_attn_h2_t<2, 8>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
+  if (variant == 3) return launch_attn_h2_t<1, 4>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
+  if (variant == 4) return launch_attn_h2_t<1, 2>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
   return launch_attn_h2_t<1, 8>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
 }
 
 }  // namespace urf
 
+#ifdef URF_EXPERIMENTS
+extern "C" int urf_probe_attn_variant(int v) { urf::g_attn_small = v; return 0; }
+#endif
 #ifdef URF_ATTN_STAMPS
 extern "C" int urf_probe_attn_stamps(long long *out) {   // [2 wave groups][64 chunks][8 stamps]
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_attn_stamps), sizeof(long long) * 2 * 64 * 8) == hipSuccess ? 0 : -1;

@@ -500,7 +500,114 @@ static int launch_h2gemm_t(const H2Args &a, int batch, hipStream_t st) {
 
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: the DEEP-RING tile for launches that cannot fill the chip (one pair on the per-call path of the reference's
+// unpatched caller, src/tracking.cc:338-377; the four-pair batches of BASELINE configs[3]).  There a workgroup has its CU (almost)
+// to itself and the two-stage loop above is a chain of DMA round trips: a chunk's 24 MFMAs per wave take 0.16 us, its LDS-DMA
+// from the previous launch's output (L2 miss: Infinity Cache or HBM) ~1 us, and nothing else is resident to hide it --
+// 1.1 us per chunk measured at one pair (17.6 us for the K = 512 layer).  Here the tile is 128 couts x 64 rows (twice the
+// workgroups) and S stages of 24 KB hold S - 1 chunks in flight: the K loop runs at the DMA's THROUGHPUT, not its latency.
+//   stage = [Ah 128 x 32 | Al 128 x 32 | Bh 64 x 32 | Bl 64 x 32] halfs; 24 DMA pieces of 1 KiB per chunk = 3 per wave, always all
+//   three (rows past the end read the last valid row: their accumulators are never stored), so `s_waitcnt vmcnt(3 (S - 2))`
+//   retires exactly the chunk about to be read (LDS-DMA retires in issue order); the raw s_barrier behind it makes every wave's
+//   pieces visible and says that everybody has consumed the fragments of the stage refilled next (read one chunk ago).
+// Same swizzle, same fragments, same MFMA order per accumulator as h2gemm_glds_tile<TOUT, 1>: bit-identical outputs.
+constexpr int DP_A = 128 * BK, DP_B = 64 * BK, DP_STAGE = 2 * DP_A + 2 * DP_B;   // halfs
+template <bool TOUT, int S>
+__device__ __forceinline__ void h2gemm_deep_tile(const H2Args &a, _Float16 *hsm, int b, int cout_base, int row0) {
+  static_assert(S >= 3 && 3 * (S - 2) <= 63, "ring depth");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int wc = wave >> 2, wr = wave & 3;
+  f32x4 acc[4][2];
+  h2_init_acc<TOUT>(a, acc, cout_base, wc, px, g);
+  // DMA roles: piece q = 3 wave + u of the chunk's 24
+  const _Float16 *src[3], *src2[3];
+  int dst[3];
+  bool isb[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int q = 3 * wave + u;
+    const int plane = q < 8 ? 0 : (q < 16 ? 1 : (q < 20 ? 2 : 3));
+    const int rb = q < 8 ? q : (q < 16 ? q - 8 : (q < 20 ? q - 16 : q - 20));
+    const int drow = rb * 16 + (lane >> 2);
+    const int dkg = (lane & 3) ^ ((-(drow >> 2)) & 3);
+    isb[u] = plane >= 2;
+    dst[u] = (plane == 0 ? 0 : plane == 1 ? DP_A : plane == 2 ? 2 * DP_A : 2 * DP_A + DP_B) + rb * 16 * BK;
+    if (plane < 2) {
+      src[u] = (plane ? a.wl : a.wh) + (size_t)(cout_base + drow) * a.Cin + 8 * dkg;
+      src2[u] = src[u];
+    } else {
+      int srow = row0 + drow;
+      if (srow > a.rows - 1) srow = a.rows - 1;
+      src[u] = (plane == 3 ? a.xl : a.xh) + (size_t)b * a.x_bstride + (size_t)srow * a.ldx + 8 * dkg;
+      src2[u] = a.x2h ? (plane == 3 ? a.x2l : a.x2h) + (size_t)b * a.x2_bstride + (size_t)srow * a.ldx2 + 8 * dkg : src[u];
+    }
+  }
+  auto issue = [&](int ch) {
+    const int c0 = ch * BK;
+    _Float16 *base = hsm + (ch % S) * DP_STAGE;
+    const bool second = a.x2h && c0 >= a.Cin1;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const _Float16 *p = (isb[u] && second) ? src2[u] + (c0 - a.Cin1) : src[u] + c0;
+      __builtin_amdgcn_global_load_lds((gbl_void *)p, (lds_void *)(base + dst[u]), 16, 0, 0);
+    }
+  };
+  const int swz = 8 * (g ^ ((-(px >> 2)) & 3));
+  const int aoff = (wc * 64 + px) * BK + swz;
+  const int boff = 2 * DP_A + (wr * 16 + px) * BK + swz;
+  const int nchunks = a.Cin / BK;
+  constexpr int LOOK = S - 1;
+#pragma unroll
+  for (int c = 0; c < LOOK; ++c) issue(c);   // (the launcher checks nchunks >= 5)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // chunk ch has landed: everything but the LOOK - 1 younger groups (in the tail fewer are pending: wait for all)
+    if (ch + LOOK <= nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (LOOK - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + LOOK < nchunks) issue(ch + LOOK);
+    const _Float16 *st = hsm + (ch % S) * DP_STAGE;
+    f16x8 ah[4], al[4], bh, bl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ah[m] = *(const f16x8 *)(st + aoff + m * 16 * BK);
+      al[m] = *(const f16x8 *)(st + DP_A + aoff + m * 16 * BK);
+    }
+    bh = *(const f16x8 *)(st + boff);
+    bl = *(const f16x8 *)(st + DP_B + boff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (TOUT) {  // D[row = token][col = cout]
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][0], 0, 0, 0);
+      } else {     // D[row = cout][col = token]
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][0], 0, 0, 0);
+      }
+    }
+  }
+  h2_epilogue<TOUT, 1>(a, acc, b, cout_base, row0, wc, wr, px, g);
+}
+
+// MODE 0: token-major outputs, 1: transposed outputs, 2: both in one launch (uniform branch per workgroup); S = ring stages
+// (6: 144 KB, one workgroup per CU -- grids of at most a workgroup per CU; 3: 72 KB, two per CU)
+template <int MODE, int S>
+__global__ void __launch_bounds__(512, 2) h2gemm_deep_kernel(H2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) _Float16 hsm[];
+  const int b = blockIdx.z, cout_base = blockIdx.y * 128, row0 = blockIdx.x * 64;
+  if (a.counts && row0 >= a.counts[b]) return;
+  if (MODE == 0) h2gemm_deep_tile<false, S>(a, hsm, b, cout_base, row0);
+  else if (MODE == 1) h2gemm_deep_tile<true, S>(a, hsm, b, cout_base, row0);
+  else if (cout_base >= a.t_from) h2gemm_deep_tile<true, S>(a, hsm, b, cout_base, row0);
+  else h2gemm_deep_tile<false, S>(a, hsm, b, cout_base, row0);
+}
+
 int g_h2gemm_xflags = 0;
+int g_h2gemm_deep = -1;     // -1: not read yet; 0 never, 1 policy (default), 6 / 3 forced (urf_probe_h2gemm_deep, experiments build)
 int g_h2gemm_variant = -1;  // probe override: 0 = register-staged 128x128, 1 = register-staged 64x128, 2 = LDS-DMA 128x128 (default)
 
 int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
@@ -578,6 +685,42 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
       return 0;
     }
 #endif
+    // launches that cannot fill the chip with the tiles above: the deep-ring tile (64 rows; h2gemm_deep_tile).  Counted in 64-row
+    // tiles of the longest image: up to one workgroup per CU -> six stages (the whole K = 256 loop in flight), up to two -> three.
+    // URF_H2GEMM_DEEP (experiments build): 0 = never, 1 = default policy, 6 / 3 = that depth for every launch
+    if (g_h2gemm_deep < 0) { const char *e = urf::exp_env("URF_H2GEMM_DEEP"); g_h2gemm_deep = e ? atoi(e) : 1; }
+    const int deep = g_h2gemm_deep;
+    URF_CHECK(a.Cin / BK >= 5, "h2gemm: Cin %d below the deep ring's prologue", a.Cin);
+    {
+      const long tiles64 = (long)((a.rows + 63) / 64) * (a.Cout / 128) * batch;
+      const int depth = deep == 6 || deep == 3 ? deep : (deep == 1 ? (tiles64 <= 288 ? 6 : (tiles64 <= 448 ? 3 : 0)) : 0);
+      if (depth) {
+        static DeviceOnce attr_deep;
+        if (attr_deep.need()) {
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<1, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          URF_HIP(hipFuncSetAttribute((const void *)h2gemm_deep_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_deep.mark();
+        }
+        const dim3 g64((a.rows + 63) / 64, a.Cout / 128, batch);
+        const size_t ldsd = sizeof(_Float16) * (size_t)depth * DP_STAGE;
+        const int mode = a.ohT ? (a.t_from > 0 ? 2 : 1) : 0;
+        if (depth == 6) {
+          if (mode == 2) hipLaunchKernelGGL((h2gemm_deep_kernel<2, 6>), g64, dim3(512), ldsd, st, b);
+          else if (mode == 1) hipLaunchKernelGGL((h2gemm_deep_kernel<1, 6>), g64, dim3(512), ldsd, st, b);
+          else hipLaunchKernelGGL((h2gemm_deep_kernel<0, 6>), g64, dim3(512), ldsd, st, b);
+        } else {
+          if (mode == 2) hipLaunchKernelGGL((h2gemm_deep_kernel<2, 3>), g64, dim3(512), ldsd, st, b);
+          else if (mode == 1) hipLaunchKernelGGL((h2gemm_deep_kernel<1, 3>), g64, dim3(512), ldsd, st, b);
+          else hipLaunchKernelGGL((h2gemm_deep_kernel<0, 3>), g64, dim3(512), ldsd, st, b);
+        }
+        URF_HIP(hipGetLastError());
+        return 0;
+      }
+    }
     if (!a.ohT && (((balance & 2) && a.Cout <= 256) || (balance & 4)))
       hipLaunchKernelGGL(h2gemm_glds_half_kernel, dim3((a.rows + 63) / 64, a.Cout / 128, batch), dim3(512), lds, st, b);
     else if (a.ohT && a.t_from > 0) hipLaunchKernelGGL((h2gemm_glds_kernel<2>), grid, dim3(512), lds, st, b);
@@ -616,6 +759,7 @@ using namespace urf;
 #ifdef URF_EXPERIMENTS   // kernel A/B switches: experiments build only (include/urf.h)
 extern "C" int urf_probe_h2gemm_variant(int v) { urf::g_h2gemm_variant = v; return 0; }
 extern "C" int urf_probe_h2gemm_xflags(int f) { urf::g_h2gemm_xflags = f; return 0; }
+extern "C" int urf_probe_h2gemm_deep(int d) { urf::g_h2gemm_deep = d; return 0; }
 #endif
 extern "C" int urf_probe_h2gemm(const float *X, const float *W, const float *bias, int M, int N, int K, float *Y,
                                 int reps, float *ms_out, int device) {

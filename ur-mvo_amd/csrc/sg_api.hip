@@ -42,6 +42,8 @@ int launch_decode(const int *counts, const float *C, const float *Ct, const floa
                   double *ms1, void *matches, float *pts0, float *pts1, int *nmatch, float *Zout, int *gflags, float gz,
                   float *resid_cols, float *resid, float resid_bound, int *err, int P, hipStream_t st);
 int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, float log_floor, int *out, int P, hipStream_t st);
+int launch_guard_online(const int *counts, const int *mi0f, const float *mv0f, const int *mi1f, const float *mv1f, const float *C,
+                        const float *u, const float *v, float log_floor, int *out, int n, hipStream_t st);
 int launch_ransac(const int *nmatch, const float *pts0, const float *pts1, float *ps0, float *ps1, float *pn0,
                   float *pn1, float *T, float *F, float *score, int *ninl, uint32_t seed, int iters, float sigma,
                   double confidence, const int *d_sets, int enable, const void *matches, void *out, int *nout,
@@ -63,6 +65,9 @@ static const float kGuardSgDescNoise = 2.4e-4f;   // the descriptor-noise share 
 // strict parity mode (precision 3): the slots come from the exact SuperPoint, so only the matcher's own error counts
 // (measured maximum 2.0e-4 on the entries a decision can rest on, both bench streams) with 10 % on top
 static const float kGuardSgZStrict = 2.2e-4f;
+// above this measured fast-vs-exact difference the error model itself is not trusted: a strict handle then redoes EVERY pair in the
+// exact mode (at calibration time and in the online check alike)
+static const float kGuardSgZCap = 2.5e-3f;
 // integrity bound of a fast Sinkhorn result (every fast mode): the largest |column marginal - 1| of the plan the decode reads
 // (argmax_kernel, RESID; an invariant of every correct result: the iteration's last update is the column update).  Clean
 // launches stay below 2e-5 on both bench streams (tools/gpu_determinism.py prints the largest value seen);
@@ -196,6 +201,15 @@ struct urf_pm {
     hipEvent_t ev_done = nullptr;    // the redo has delivered
     int *counts = nullptr;           // staging (strict handles): counts / pixel coordinates / encoded keypoints of the flagged pairs,
     float *kxy = nullptr, *x = nullptr;   // copied on THIS handle's stream, so that its next batch never waits for the engine
+    // online check of the error model: the fast pass's row / column best entries of the pairs being redone (staged like the inputs),
+    // the largest fast-vs-exact difference on them per redone pair (pinned; written behind the pass), and the audit of one
+    // UNFLAGGED pair (audit_k = its position in idx[], -1 = none; its fast list kept on the host for the comparison)
+    int *mi0 = nullptr, *mi1 = nullptr;
+    float *mv0 = nullptr, *mv1 = nullptr;
+    float *h_online = nullptr;
+    float margin_at_begin = 0.0f;
+    int audit_k = -1;
+    std::vector<urf_dmatch> audit_list;
     std::chrono::steady_clock::time_point t0;
   } bq[kBegun];
   int bq_head = 0, bq_n = 0;
@@ -206,7 +220,13 @@ struct urf_pm {
   int last_flags[64];              // guard words of the batch handed out by the last fetch / host call
   int fast_flags[64];              // guard words of the batch whose fast pass was enqueued last, recorded by its first begin (a retried begin reads these: the pinned words are cleared once)
   bool flags_recorded = false;
+  bool redo_queued = false;        // the redo of the batch whose fast pass was enqueued last has been queued (or it needed none)
   unsigned long long pairs_flagged = 0;
+  // online margin (strict handles): folded from every redo's by-product, and from an audit of one unflagged pair per audit_period begun batches
+  int *online = nullptr;           // (engine) device words of the pass's pairs
+  float online_worst = 0.0f;
+  unsigned long long online_pairs = 0, online_violations = 0, margin_raises = 0, audits = 0, audit_mismatches = 0, begins = 0;
+  int audit_period = 256;
   bool calib_said = false;         // "the automatic guard calibration could not run" has been said for THIS handle (no process-global state: the reference calls from fresh threads)
   // automatic calibration of the guard's margin (urf_sg_config.calibrate_pairs): pairs still to be measured, the largest difference seen
   int calib_left = 0, calib_failures = 0;
@@ -580,8 +600,14 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     }
     h->pool = pool;
     h->redo = pool->engine;
-    for (int k = 0; k < urf_pm::kBegun; ++k)
+    for (int k = 0; k < urf_pm::kBegun; ++k) {
       if (dalloc(&h->bq[k].counts, NI) || dalloc(&h->bq[k].kxy, NI * NP * 2) || dalloc(&h->bq[k].x, NI * NP * 256)) return -1;
+      if (dalloc(&h->bq[k].mi0, P * NP) || dalloc(&h->bq[k].mi1, P * NP) || dalloc(&h->bq[k].mv0, P * NP) || dalloc(&h->bq[k].mv1, P * NP)) return -1;
+      URF_HIP(hipHostMalloc((void **)&h->bq[k].h_online, 64 * sizeof(float), hipHostMallocDefault));
+      memset(h->bq[k].h_online, 0, 64 * sizeof(float));
+    }
+    if (!pool->engine->online) URF_HIP(hipMalloc((void **)&pool->engine->online, 64 * sizeof(int)));
+    h->audit_period = h->cfg.audit_period > 0 ? h->cfg.audit_period : (h->cfg.audit_period < 0 ? 0 : 256);
     URF_HIP(hipDeviceSynchronize());
   }
   return 0;
@@ -638,7 +664,12 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
                     h->score, h->Fbest, h->best_score, h->inliers, h->cv_scratch, (void *)h->d_slotptrs, h->rs_xin, h->rs_xbc, h->rs_err, h->ninl, h->d_sets,
                     h->g_flags, h->rs_resid, h->rs_resid_cols};
     for (void *p : bufs) (void)hipFree(p);
-    for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipFree(h->bq[k].counts); (void)hipFree(h->bq[k].kxy); (void)hipFree(h->bq[k].x); }
+    for (int k = 0; k < urf_pm::kBegun; ++k) {
+      (void)hipFree(h->bq[k].counts); (void)hipFree(h->bq[k].kxy); (void)hipFree(h->bq[k].x);
+      (void)hipFree(h->bq[k].mi0); (void)hipFree(h->bq[k].mi1); (void)hipFree(h->bq[k].mv0); (void)hipFree(h->bq[k].mv1);
+      if (h->bq[k].h_online) (void)hipHostFree(h->bq[k].h_online);
+    }
+    (void)hipFree(h->online);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
     for (int k = 0; k < urf_pm::kSets; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
     for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipEventDestroy(h->bq[k].ev_in); (void)hipEventDestroy(h->bq[k].ev_done); }
@@ -810,6 +841,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   } else if (sg_linear(h, NI, h->x, 256, 256, nullptr, 0, 0, h->wf, h->bf, 256, h->mdesc, 256, false, nullptr)) return -1;
   h->last_P = P; h->last_Z = want_Z; h->last_ransac = ransac;
   h->flags_recorded = false;
+  h->redo_queued = false;
   // this batch's lists go to the other result set (the previous batch's may still be waiting for its redo / its fetch_end)
   {   // a set that no begun batch holds (at most two do)
     int s2 = (h->cur_set + 1) % urf_pm::kSets;
@@ -957,6 +989,11 @@ static int pool_flush(urf::RedoPool *pool) {
       urf_pm *h = j.owner;
       urf_pm::Begun &e = h->bq[j.entry];
       const int set = e.set;
+      // the by-product of the pass: fast-vs-exact on the entries the fast decisions of these pairs rested on (pm_end_batch folds it)
+      if (launch_guard_online(r->counts + 2 * k0, e.mi0, e.mv0, e.mi1, e.mv1, r->C + (size_t)k0 * (NP + 1) * LDC, r->u + (size_t)k0 * LDC,
+                              r->v + (size_t)k0 * LDC, logf(0.1f), r->online + k0, e.n, st))
+        return -1;
+      URF_HIP(hipMemcpyAsync(e.h_online, r->online + k0, (size_t)e.n * sizeof(float), hipMemcpyDeviceToHost, st));
       for (int k = 0; k < e.n; ++k) {
         const int p = e.idx[k], q = k0 + k;
         URF_HIP(hipMemcpyAsync(h->nf_set[set] + p, r->nfinal + q, sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -1019,8 +1056,27 @@ static int pm_begin_batch(urf_pm *h) {
   memcpy(e.flags, h->fast_flags, sizeof(e.flags));
   memcpy(e.stage, h->stage_ms, sizeof(e.stage));
   int n = 0;
-  for (int p = 0; p < P && p < 64; ++p)
-    if (h->fast_flags[p] || h->redo_all) e.idx[n++] = p;
+  e.audit_k = -1;
+  e.margin_at_begin = h->g_z;
+  h->begins += h->redo_queued ? 0 : 1;
+  // audit: one UNFLAGGED pair of every audit_period-th begun batch goes through the exact engine as well -- the only sample of the
+  // error model on pairs the guard passed (its exact list replaces the fast one; the two index lists must be equal)
+  const int audit_p = (h->strict && h->redo_pairs && h->pool && h->audit_period > 0 && !h->redo_all && h->begins % (unsigned long long)h->audit_period == 0)
+                          ? (int)((h->begins / (unsigned long long)h->audit_period) % (unsigned long long)P) : -1;
+  // (a second begin of the SAME fast batch after its redo has been queued -- the host calls look again once the redo has rewritten
+  // their results -- finds nothing left to do; a retry after a FAILED begin finds the recorded words and queues the redo again)
+  const bool todo = !h->redo_queued;
+  for (int p = 0; p < P && p < 64 && todo; ++p) {
+    const bool audit = p == audit_p && !h->fast_flags[p];
+    if (h->fast_flags[p] || h->redo_all || audit) {
+      if (audit) {
+        e.audit_k = n;
+        const int cnt = h->hn_set[h->cur_set][p];
+        e.audit_list.assign(h->hm_set[h->cur_set] + (size_t)p * NP, h->hm_set[h->cur_set] + (size_t)p * NP + (cnt > 0 && cnt <= NP ? cnt : 0));
+      }
+      e.idx[n++] = p;
+    }
+  }
   urf::RedoPool *pool = h->pool;
   if (!h->redo_pairs || !pool) { rollback.armed = false; return 0; }
   if (n == 0) {
@@ -1028,6 +1084,7 @@ static int pm_begin_batch(urf_pm *h) {
     std::lock_guard<std::mutex> lock(pool->mu);
     if (!pool->queue.empty() && pool_flush(pool)) return -1;
     rollback.armed = false;
+    h->redo_queued = true;
     return 0;
   }
   // the inputs leave this handle's buffers on its OWN stream (idle: the host has waited for the batch's fast pass), into the
@@ -1035,11 +1092,16 @@ static int pm_begin_batch(urf_pm *h) {
   // pass may still be running
   for (int k = 0; k < n; ++k) {
     const int p = e.idx[k];
+    h->audits += k == e.audit_k;
     h->cause_thr += (e.flags[p] & 1) != 0;
     h->cause_run += (e.flags[p] & 2) != 0;
     URF_HIP(hipMemcpyAsync(e.counts + 2 * k, h->counts + 2 * p, 2 * sizeof(int), hipMemcpyDeviceToDevice, h->st));
     URF_HIP(hipMemcpyAsync(e.kxy + (size_t)2 * k * NP * 2, h->kxy + (size_t)2 * p * NP * 2, (size_t)2 * NP * 2 * sizeof(float), hipMemcpyDeviceToDevice, h->st));
     URF_HIP(hipMemcpyAsync(e.x + (size_t)2 * k * NP * 256, h->x + (size_t)2 * p * NP * 256, (size_t)2 * NP * 256 * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.mi0 + (size_t)k * NP, h->mi0 + (size_t)p * NP, NP * sizeof(int), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.mi1 + (size_t)k * NP, h->mi1 + (size_t)p * NP, NP * sizeof(int), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.mv0 + (size_t)k * NP, h->mv0 + (size_t)p * NP, NP * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+    URF_HIP(hipMemcpyAsync(e.mv1 + (size_t)k * NP, h->mv1 + (size_t)p * NP, NP * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   }
   URF_HIP(hipEventRecord(e.ev_in, h->st));
   e.n = n;
@@ -1055,8 +1117,58 @@ static int pm_begin_batch(urf_pm *h) {
     }
   }
   rollback.armed = false;
+  h->redo_queued = true;
   return 1;
 }
+// Online margin.  A finished redo pass has left, per redone pair, the largest |Z_fast - Z_exact| over the entries the fast pass's
+// decisions rested on (guard_online_kernel) -- a free sample of the error model the guard's margin stands for, on exactly the
+// deployment's pairs, for the life of the handle (the calibration at the handle's start is eight pairs).  Folded here:
+//   * d > margin / 1.6 : the head-room of the calibration is used up -- the margin is raised to 1.6 d (and said on stderr); above
+//     the cap the model is not trusted any more and every pair is redone, as at calibration time;
+//   * d > the margin the batch was GUARDED with : the model was violated on this pair (itself redone, hence correct); counted and
+//     said loudly -- an unflagged pair of that batch may have carried the same error.
+// The audit pair (one unflagged pair per audit_period begun batches) is the only sample on pairs the guard PASSED: its exact index
+// list must equal the fast one it replaced.
+static void pm_fold_online(urf_pm *h, urf_pm::Begun &e) {
+  if (!h->strict || !e.h_online) return;
+  float d = 0.0f;
+  for (int k = 0; k < e.n && k < 64; ++k) { const float v = e.h_online[k]; if (!(v <= d)) d = v; }   // (a NaN counts as the worst)
+  h->online_pairs += (unsigned long long)e.n;
+  if (!(d <= h->online_worst)) h->online_worst = d;
+  if (!(d <= e.margin_at_begin)) {
+    h->online_violations += 1;
+    fprintf(stderr, "liburf_front: ONLINE GUARD CHECK: a redone pair's fast-vs-exact difference %.3g on a decisive entry exceeds the margin %.3g its "
+            "batch was guarded with: the error model did not hold there (the pair itself was redone; violation %llu of this handle)\n",
+            (double)d, (double)e.margin_at_begin, h->online_violations);
+  }
+  if (!(d <= h->g_z / 1.6f)) {
+    const float need = 1.6f * d;
+    if (!(need <= h->g_z)) {
+      h->margin_raises += 1;
+      const bool cap = !(d <= kGuardSgZCap) && h->redo_pairs && !h->redo_all;
+      if (h->margin_raises <= 8 || (h->margin_raises & (h->margin_raises - 1)) == 0 || cap)
+        fprintf(stderr, "liburf_front: online guard check: fast-vs-exact difference %.3g on a redone pair is above margin / 1.6: margin %.3g -> %.3g%s\n",
+                (double)d, (double)h->g_z, (double)need, cap ? " -- above the cap the error model is trusted to: every pair will be redone in the exact mode" : "");
+      if (need == need) h->g_z = need;
+      if (cap) h->redo_all = true;
+    }
+  }
+  if (e.audit_k >= 0 && e.audit_k < e.n) {
+    const int p = e.idx[e.audit_k];
+    const int cnt = h->hn_set[e.set][p];
+    const urf_dmatch *got = h->hm_set[e.set] + (size_t)p * NP;
+    bool same = cnt == (int)e.audit_list.size();
+    for (int i = 0; same && i < cnt; ++i) same = got[i].queryIdx == e.audit_list[i].queryIdx && got[i].trainIdx == e.audit_list[i].trainIdx;
+    if (!same) {
+      h->audit_mismatches += 1;
+      fprintf(stderr, "liburf_front: AUDIT: an UNFLAGGED pair's exact index list (%d matches) differs from the fast list the guard had passed (%zu): "
+              "the strict guarantee did not hold for it (mismatch %llu of %llu audits; fast-vs-exact %.3g, margin %.3g)\n",
+              cnt, e.audit_list.size(), h->audit_mismatches, h->audits, (double)e.h_online[e.audit_k], (double)e.margin_at_begin);
+    }
+    e.audit_k = -1;
+  }
+}
+
 // the oldest begun batch: wait for its redo (if one was started) and pop it; *set = its result set, *P its pair count
 static int pm_end_batch(urf_pm *h, int *set, int *P) {
   URF_CHECK(h->bq_n > 0, "no fetch has begun");
@@ -1068,7 +1180,8 @@ static int pm_end_batch(urf_pm *h, int *set, int *P) {
       return -1;
     }
     URF_HIP(hipEventSynchronize(e.ev_done));
-    h->pairs_redone += (unsigned long long)e.n;
+    h->pairs_redone += (unsigned long long)(e.n - (e.audit_k >= 0 ? 1 : 0));
+    pm_fold_online(h, e);
     h->redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e.t0).count();
   }
   memcpy(h->last_flags, e.flags, sizeof(e.flags));
@@ -1343,12 +1456,12 @@ static int pm_calibrate_core(urf_pm *h, int P, float factor, double *out) {
   // (not a batch of the caller's stream: the bookkeeping of the last handed-out batch survives the call)
   const unsigned long long seen = h->pairs_seen;
   const int keep_P = h->last_P;
-  const bool keep_Z = h->last_Z, keep_ransac = h->last_ransac, keep_rec = h->flags_recorded;
+  const bool keep_Z = h->last_Z, keep_ransac = h->last_ransac, keep_rec = h->flags_recorded, keep_queued = h->redo_queued;
   struct Restore {
-    urf_pm *h; int P; bool Z, ransac, rec;
-    ~Restore() { h->last_P = P; h->last_Z = Z; h->last_ransac = ransac; h->flags_recorded = rec;
+    urf_pm *h; int P; bool Z, ransac, rec, queued;
+    ~Restore() { h->last_P = P; h->last_Z = Z; h->last_ransac = ransac; h->flags_recorded = rec; h->redo_queued = queued;
                  for (int p = 0; p < h->maxP && p < 64; ++p) h->h_gflags[p] = 0; }
-  } restore{h, keep_P, keep_Z, keep_ransac, keep_rec};
+  } restore{h, keep_P, keep_Z, keep_ransac, keep_rec, keep_queued};
   if (pm_pipeline(h, P, true, false)) return -1;                      // the fast pass, Z kept
   h->pairs_seen = seen;
   URF_HIP(hipStreamSynchronize(st));
@@ -1407,7 +1520,6 @@ extern "C" int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slo
 // synthetic streams' the built-in constant was measured on.  The maximum over a handful of pairs underestimates the maximum over
 // a stream (1.39e-4 on eight bench pairs against 2.0e-4 over both streams), hence the factor 1.6.  Above kGuardSgZCap the error
 // model itself is not trusted: a strict handle then redoes EVERY pair in the exact mode (correct, at the exact mode's speed).
-static const float kGuardSgZCap = 2.5e-3f;
 static int pm_auto_calibrated(urf_pm *h, int P, int rc) {
   if (rc) {   // (a give-up of the resident Sinkhorn, no memory for the scratch copy): the caller's batch does not fail for it -- the next one is measured
     if (!h->calib_said) { h->calib_said = true; fprintf(stderr, "liburf_front: the automatic guard calibration could not run (%s); it is tried again with the next pairs\n", urf_last_error()); }
@@ -1467,8 +1579,10 @@ extern "C" int urf_pm_redo_engine_stats(urf_pm *h, double *out, int n) {
 
 extern "C" int urf_pm_guard_state(urf_pm *h, double *out, int n) {
   URF_CHECK(h && h->built && out && n >= 1, "urf_pm_guard_state: bad argument");
-  const double v[4] = {(double)h->g_z, (double)h->calib_worst, (double)h->calib_left, h->redo_all ? 1.0 : 0.0};
-  for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
+  const double v[10] = {(double)h->g_z, (double)h->calib_worst, (double)h->calib_left, h->redo_all ? 1.0 : 0.0,
+                        (double)h->online_worst, (double)h->online_pairs, (double)h->margin_raises, (double)h->online_violations,
+                        (double)h->audits, (double)h->audit_mismatches};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
   return 0;
 }
 

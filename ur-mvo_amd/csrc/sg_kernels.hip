@@ -649,6 +649,47 @@ int launch_guard_z_calib(const int *counts, const float *zf, const float *zx, fl
   return 0;
 }
 
+// Online check of the guard's error model (strict parity): every exact redo leaves the exact couplings and potentials of a pair
+// the fast pass has also matched.  For the fast pass's own row / column best entries (mi / mv of its decode; the entries its
+// decisions rested on) the exact log-assignment is recomputed from the engine's buffers; the largest |Z_fast - Z_exact| over the
+// entries either pass holds above log_floor comes back as float bits, one word per redone pair.  One workgroup per pair.
+__global__ void __launch_bounds__(256) guard_online_kernel(const int *counts, const int *mi0f, const float *mv0f, const int *mi1f,
+                                                           const float *mv1f, const float *C, const float *u, const float *v,
+                                                           float log_floor, int *out) {
+  const int p = blockIdx.x, n0 = counts[2 * p], n1 = counts[2 * p + 1];
+  const float norm = -log_c((float)(n0 + n1));
+  const float *Cp = C + (size_t)p * (NP + 1) * LDC, *up = u + (size_t)p * LDC, *vp = v + (size_t)p * LDC;
+  float worst = 0.0f;
+  for (int i = threadIdx.x; i < n0; i += 256) {
+    const int j = mi0f[(size_t)p * NP + i];
+    const float a = mv0f[(size_t)p * NP + i];
+    if (j >= 0 && j < n1) {
+      const float x = ((Cp[(size_t)i * LDC + j] + up[i]) + vp[j]) - norm;
+      if (a > log_floor || x > log_floor) worst = fmaxf(worst, a > x ? a - x : x - a);
+    }
+  }
+  for (int j = threadIdx.x; j < n1; j += 256) {
+    const int i = mi1f[(size_t)p * NP + j];
+    const float a = mv1f[(size_t)p * NP + j];
+    if (i >= 0 && i < n0) {
+      const float x = ((Cp[(size_t)i * LDC + j] + up[i]) + vp[j]) - norm;
+      if (a > log_floor || x > log_floor) worst = fmaxf(worst, a > x ? a - x : x - a);
+    }
+  }
+  __shared__ float part[4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) worst = fmaxf(worst, __shfl_xor(worst, d, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) out[p] = __float_as_int(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+}
+int launch_guard_online(const int *counts, const int *mi0f, const float *mv0f, const int *mi1f, const float *mv1f, const float *C,
+                        const float *u, const float *v, float log_floor, int *out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(guard_online_kernel, dim3(n), dim3(256), 0, st, counts, mi0f, mv0f, mi1f, mv1f, C, u, v, log_floor, out);
+  URF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ launchers
 int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int height, int *counts, float *kin,
                          float *kxy, float *x, hipStream_t st) {

@@ -181,7 +181,8 @@ PM_STAGES = ["prep", "kenc", "gnn", "final+score", "sinkhorn", "decode", "ransac
 class _PM:
     def __init__(self, cfg, max_pairs=1, device=0, sinkhorn_iterations=100, ransac_iterations=200,
                  ransac_sigma=0.0, ransac_seed=0, precision=0, ransac_threshold_px=0.0, ransac_confidence=0.0,
-                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0, sinkhorn_residual_bound=0.0, calibrate_pairs=0, redo_merge=0, redo_shared_engine=0):
+                 redo_flagged_pairs=0, guard_margin=0.0, outlier_stage=0, sinkhorn_residual_bound=0.0, calibrate_pairs=0, redo_merge=0, redo_shared_engine=0,
+                 audit_period=0):
         """outlier stage: all-zero = the reference call's parameters (3 px, confidence 0.99, src/point_matching.cc:50);
         ransac_sigma > 0 states the gate like EpipolarGeometry does, ransac_confidence < 0 makes every hypothesis count.
         precision: 0 exact, 1 fast, 2 guarded fast (flagged pairs reported), 3 strict parity (flagged pairs redone in the
@@ -191,7 +192,7 @@ class _PM:
         self._c = SGConfig(cfg.image_width, cfg.image_height, cfg.matching_threshold, sinkhorn_iterations,
                            max_pairs, device, ransac_iterations, ransac_sigma, ransac_seed, precision,
                            ransac_threshold_px, ransac_confidence, redo_flagged_pairs, guard_margin, outlier_stage,
-                           sinkhorn_residual_bound, calibrate_pairs, redo_merge, redo_shared_engine)
+                           sinkhorn_residual_bound, calibrate_pairs, redo_merge, redo_shared_engine, audit_period)
         self._h = C.c_void_p()
         check(_lib.lib().urf_pm_create(C.byref(self._c), C.byref(self._h)), "urf_pm_create")
 
@@ -244,9 +245,14 @@ class _PM:
 
     def guard_state(self):
         """dict(margin in use, largest calibrated fast-vs-exact difference, pairs the automatic calibration still wants, redo_all)"""
-        v = (C.c_double * 4)()
-        check(_lib.lib().urf_pm_guard_state(self._h, v, 4), "urf_pm_guard_state")
-        return dict(margin=float(v[0]), measured=float(v[1]), pairs_left=int(v[2]), redo_all=bool(v[3]))
+        v = (C.c_double * 10)()
+        check(_lib.lib().urf_pm_guard_state(self._h, v, 10), "urf_pm_guard_state")
+        # online_*: the by-product of every exact redo (largest fast-vs-exact difference seen on a redone pair, pairs sampled,
+        # times the margin was raised for it, times it exceeded the margin its batch was guarded with); audits: unflagged pairs
+        # sent through the exact engine / those whose exact index list differed from the fast one
+        return dict(margin=float(v[0]), measured=float(v[1]), pairs_left=int(v[2]), redo_all=bool(v[3]),
+                    online_worst=float(v[4]), online_pairs=int(v[5]), margin_raises=int(v[6]), online_violations=int(v[7]),
+                    audits=int(v[8]), audit_mismatches=int(v[9]))
 
     def near_tie_flags(self, P=1):
         """guard words of the pairs of the batch handed out last (0 = the pair's match set is the exact pipeline's)"""
