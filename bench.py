@@ -176,7 +176,8 @@ def stream_run(U, spb, sgb, dev, device_index, prec, Hh, Ww, batch, steps, repea
                         "online_largest_difference_on_a_redone_pair": max(g_["online_worst"] for g_ in gs),
                         "online_pairs_sampled": sum(g_["online_pairs"] for g_ in gs), "margin_raises": sum(g_["margin_raises"] for g_ in gs),
                         "online_violations": sum(g_["online_violations"] for g_ in gs), "audits": sum(g_["audits"] for g_ in gs),
-                        "audit_mismatches": sum(g_["audit_mismatches"] for g_ in gs), "every_pair_redone": any(g_["redo_all"] for g_ in gs)}
+                        "audit_mismatches": sum(g_["audit_mismatches"] for g_ in gs), "every_pair_redone": any(g_["redo_all"] for g_ in gs),
+                        "batches_run_in_the_exact_mode_instead": sum(g_["exact_batches"] for g_ in gs)}
     del pipe, pms, sp, d_fr
     return (out, kept) if keep else out
 

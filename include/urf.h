@@ -168,7 +168,10 @@ typedef struct {
   float ransac_confidence;
   /* guard of the fast matcher (precision 2 and 3; appended fields, all-zero = the mode's defaults):
    * redo_flagged_pairs: 0 = the mode's default (2: flagged pairs are reported only; 3: redone in the exact mode),
-   *   1 = redo them, -1 = never redo (precision 2 only; precision 3 without the redo is not strict and is refused).
+   *   1 = redo them, -1 = never redo (precision 2 only; precision 3 without the redo is not strict and is refused),
+   *   2 = redo them and NEVER divert whole batches to the exact mode (a strict handle whose guard flags more than half of the
+   *   last 32 pairs -- or whose measured error is above the cap -- otherwise runs its next 64 batches in the exact mode itself:
+   *   the same lists for less than fast pass + redo; urf_pm_guard_state out[10] counts those batches).
    * guard_margin: the margin on the log-assignment within which a decisive entry counts as near-tied; 0 = the mode's
    *   default (2: 5e-4, 3: 2.2e-4).  urf_pm_calibrate_guard() widens it where a deployment's pairs need it. */
   int redo_flagged_pairs;
@@ -406,7 +409,8 @@ int urf_pm_calibrate_guard(urf_pm *h, int P, const void *const *d_slots0, const 
  * out[3] = 1 when the measured error exceeded the cap and a strict handle redoes every pair in the exact mode; the online check
  * (urf_sg_config.audit_period): out[4] = the largest fast-vs-exact difference any redone pair has shown, out[5] = redone pairs
  * sampled, out[6] = times the margin was raised for it, out[7] = times it exceeded the margin its batch had been guarded with,
- * out[8] = unflagged pairs audited, out[9] = audited pairs whose exact index list differed from the fast one (n <= 10 values) */
+ * out[8] = unflagged pairs audited, out[9] = audited pairs whose exact index list differed from the fast one, out[10] = batches
+ * the handle ran in the exact mode because its guard flagged most pairs (n <= 11 values) */
 int urf_pm_guard_state(urf_pm *h, double *out, int n);
 
 /* ------------------------------------------------ kernel timing (bench) ---- */
@@ -617,6 +621,12 @@ int urf_probe_h2gemm_xflags(int flags);
  * urf_probe_h2gemm_deep: 0 = never the deep-ring tile, 1 = the launcher's policy (default), 6 / 3 = that ring depth everywhere;
  * urf_probe_attn_variant: -1 = the launcher's policy, 0 .. 4 = 1x8, 2x4, 2x8, 1x4, 1x2 (query tiles per wave x waves) */
 int urf_probe_h2gemm_deep(int depth);
+/* the exact linear layer with both operands by LDS-DMA (linear_dma_kernel): 0 = never, 1 = the launcher's policy (default),
+ * 2 / 3 = every eligible launch, with that many stages.  Bit-identical to the register-staged tile. */
+int urf_probe_linear_dma(int v);
+/* the exact attention kernel's workgroup: 4 = 64 queries on 512 threads, 2 = 32 queries on 256 threads, 0 = the launcher's
+ * policy (2 for at most two pairs).  Same bits. */
+int urf_probe_attn_exact_nqt(int v);
 int urf_probe_attn_variant(int variant);
 #endif
 

@@ -361,7 +361,7 @@ def test_a_handle_holds_two_begun_batches_and_hands_them_out_in_order(U, F, sp_b
     frames, ofeats, olists = bench_stream_oracle(H, W)
     sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=H, max_width=W, max_batch=7, precision=0)
     assert sp.build(sp_blob)
-    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=2, precision=3, guard_margin=50.0)
+    pm = F.PointMatching(F.SuperGlueConfig(), max_pairs=2, precision=3, guard_margin=50.0, redo_flagged_pairs=2)
     assert pm.build(sg_blob)
     d = torch.from_numpy(np.stack(frames[:7])).cuda()
     slots = torch.zeros((7, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
@@ -794,7 +794,7 @@ def test_strict_handles_share_a_redo_engine_and_merge_consecutive_batches(U, F, 
     for merge, shared in ((1, 1), (0, 1), (0, 0), (1, 0)):
         hs = []
         for _ in range(2):
-            m = F.PointMatching(F.SuperGlueConfig(), max_pairs=3, precision=3, guard_margin=50.0, calibrate_pairs=-1, redo_merge=merge,
+            m = F.PointMatching(F.SuperGlueConfig(), max_pairs=3, precision=3, guard_margin=50.0, calibrate_pairs=-1, redo_flagged_pairs=2, redo_merge=merge,
                                 redo_shared_engine=shared)
             assert m.build(sg_blob)
             hs.append(m)
@@ -815,7 +815,7 @@ def test_strict_handles_share_a_redo_engine_and_merge_consecutive_batches(U, F, 
     # room for both batches in one pass: max_pairs 6, three pairs each
     hs = []
     for _ in range(2):
-        m = F.PointMatching(F.SuperGlueConfig(), max_pairs=6, precision=3, guard_margin=50.0, calibrate_pairs=-1, redo_merge=1,
+        m = F.PointMatching(F.SuperGlueConfig(), max_pairs=6, precision=3, guard_margin=50.0, calibrate_pairs=-1, redo_flagged_pairs=2, redo_merge=1,
                             redo_shared_engine=1)
         assert m.build(sg_blob)
         hs.append(m)
@@ -928,4 +928,62 @@ def test_small_grid_kernels_give_the_bits_of_the_batch_kernels(Uexp, sg_blob, n0
     for name, o in out.items():
         for a, b in zip(o, ref):
             assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("n0,n1", [(1000, 1000), (1024, 777), (130, 1000), (64, 64)])
+def test_dma_staged_exact_linear_layer_gives_the_bits_of_the_register_staged_one(Uexp, O, sg_blob, n0, n1):
+    """linear_dma_kernel (round 6: 64-row tiles, both operands by LDS-DMA into a ring of stages, swizzled instead of padded)
+    against the register-staged tile of conv_mfma_kernel<1>: every output is the same fma chain, so the exact matcher's whole
+    log-assignment matrix must be bit-identical with the kernel off (0), on by policy (1) and forced with two and three stages
+    -- and equal to the CPU oracle's (the exact mode's contract)."""
+    Fx, L = Uexp.frontend, Uexp._lib.lib()
+    rng = np.random.default_rng(7 * n0 + n1)
+    f0 = make_features(rng, n0)
+    f1 = make_features(rng, n1, planted_from=f0, m=min(n0, n1) // 2)
+    nf0, nf1 = O.sg_normalize(f0, 640, 512), O.sg_normalize(f1, 640, 512)
+    sg = Fx.SuperGlue(Fx.SuperGlueConfig(), precision=0)
+    assert sg.build(sg_blob)
+    out = {}
+    try:
+        for v, nqt in ((0, 4), (1, 0), (2, 2), (3, 4), (0, 2)):     # (nqt: the exact attention kernel on 64- / 32-query workgroups)
+            L.urf_probe_linear_dma(v)
+            L.urf_probe_attn_exact_nqt(nqt)
+            out[(v, nqt)] = sg.infer(nf0, nf1, want_scores=True)
+    finally:
+        L.urf_probe_linear_dma(1)
+        L.urf_probe_attn_exact_nqt(0)
+    want = O.sg_infer(sg_blob, O.SGConfig(*SG_CFG), nf0, nf1)
+    for v, o in out.items():
+        for a, b in zip(o, want):
+            assert np.array_equal(a, b), v
+
+
+def test_a_strict_handle_whose_guard_flags_most_pairs_runs_in_the_exact_mode(U, F, sp_blob, sg_blob):
+    """fast pass + exact redo costs more than the exact pass alone once about half the pairs are redone (bench.py,
+    secondary.strict_parity_vs_flag_rate).  A strict handle that sees more than half of its last 32 pairs flagged therefore runs
+    its next 64 batches in the exact mode itself, then looks at the fast matcher again: the same lists, no fast pass, no redo.
+    Forced here with an absurd margin (every pair flagged); redo_flagged_pairs = 2 keeps the redo path (the other tests of it)."""
+    import torch
+    frames = U.synth.shift_stream(61, 5, 480, 640)
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    slots = torch.zeros((5, U._lib.lib().urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp = F.SuperPoint(F.SuperPointConfig(max_keypoints=1000), max_height=480, max_width=640, max_batch=5, precision=0)
+    assert sp.build(sp_blob)
+    sp.infer_device(d.data_ptr(), 5, 480, 640, slots.data_ptr())
+    sp.sync()
+    s0, s1 = [slots[j].data_ptr() for j in range(4)], [slots[j + 1].data_ptr() for j in range(4)]
+    ex = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, precision=0)
+    st = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, precision=3, guard_margin=50.0, calibrate_pairs=-1)
+    assert ex.build(sg_blob) and st.build(sg_blob)
+    ex.match_device_async(s0, s1, True)
+    want = ex.fetch(4, as_arrays=True)
+    seen = []
+    for b in range(12):                       # 8 batches = 32 pairs decide; the diversion starts with the batch enqueued after that
+        st.match_device_async(s0, s1, True)
+        got = st.fetch(4, as_arrays=True)
+        for a, w in zip(got, want):
+            assert np.array_equal(a["queryIdx"], w["queryIdx"]) and np.array_equal(a["trainIdx"], w["trainIdx"]), b
+        seen.append((st.guard_state()["exact_batches"], st.near_tie_reruns()["redone"]))
+    assert seen[7] == (0, 32) and seen[-1] == (4, 32), seen       # batches 9 .. 12 ran exact: nothing flagged, nothing redone
 

@@ -33,7 +33,7 @@ for P in (1, 2, 3):
         dt = (time.perf_counter() - t) * 1e3
     st = ex.stage_ms()
     print(f"exact handle, {P} pair(s): wall {dt:.2f} ms; " + ", ".join(f"{n} {v:.3f}" for n, v in zip(F.PM_STAGES, st)))
-    sx = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=8, precision=3, guard_margin=50.0)
+    sx = F.PointMatching(F.SuperGlueConfig(image_width=640, image_height=512), max_pairs=8, precision=3, guard_margin=50.0, redo_flagged_pairs=2)
     assert sx.build(sgb)
     for rep in range(3):
         t = time.perf_counter()

@@ -708,9 +708,10 @@ int launch_attn_h2(const _Float16 *qkh, const _Float16 *qkl, const _Float16 *vth
     const char *e = urf::exp_env("URF_ATTN_VARIANT");
     forced = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
   }
-  // Round 6: one or two pairs (the per-call path): 1 tile x 4 waves (64 queries per workgroup: 128 / 256 workgroups) and, for a
-  // lone pair, 1 tile x 2 waves (32 queries: 256 workgroups) -- the same per-wave arithmetic, the same bits; 3 / 4 = those forms
-  const int variant = forced >= 0 ? forced : (g_attn_small >= 0 ? g_attn_small : (nimg >= 16 ? 2 : (nimg <= 2 ? 4 : (nimg <= 4 ? 3 : 0))));
+  // Round 6: one or two pairs (the per-call path) run 3 = 1 tile x 4 waves (64 queries per workgroup: 128 / 256 workgroups instead
+  // of 64 / 128): 0.59 against 0.68 ms for a pair's 18 launches.  4 = 1 tile x 2 waves (32 queries) is measured and NOT used: every
+  // workgroup stages the head's whole K / V^T through its few threads, 2.47 ms.  Same per-wave arithmetic, same bits.
+  const int variant = forced >= 0 ? forced : (g_attn_small >= 0 ? g_attn_small : (nimg >= 16 ? 2 : (nimg <= 4 ? 3 : 0)));
   if (variant == 1) return launch_attn_h2_t<2, 4>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
   if (variant == 2) return launch_attn_h2_t<2, 8>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);
   if (variant == 3) return launch_attn_h2_t<1, 4>(qkh, qkl, vth, vtl, counts, cross, oh, ol, nimg, st);

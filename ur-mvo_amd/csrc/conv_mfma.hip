@@ -556,6 +556,122 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs a) {
   conv_mfma_tile<TAPS, POOL, FUSE1A, MB, WDMA>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the exact linear layer with BOTH operands by LDS-DMA (the redo engine of the strict mode and every other launch
+// that cannot fill the chip: one or two pairs = 2 000 - 4 000 rows).  The register-staged tile above (TAPS == 1) moves a chunk's
+// 128 rows and 64 x 64 weights global -> VGPR -> LDS with one chunk of look-ahead and two barriers per chunk; on a grid of 64 - 192
+// workgroups nothing else is resident to hide that, and a launch whose fma chains need 7 - 14 us of matrix-pipe time takes 20 - 28.
+// Here: 64 rows x 64 channels per workgroup (twice the workgroups), wave w = rows 16 w .. 16 w + 15 x four 16-channel blocks,
+// S stages of [X 64 x 64 | W 64 x 64] floats filled by global_load_lds (eight 1-KiB pieces per wave and chunk: its own four row
+// pieces and four weight pieces), ONE barrier per chunk, `s_waitcnt vmcnt(8 (S - 2))` retires exactly the chunk about to be read.
+// Unpadded stages; bank spread by swizzles applied to the DMA's SOURCE address and to the fragment read: weight row k keeps its
+// four 16-float blocks in the order block ^ (k & 3) (as the WDMA convolution), activation row r keeps its sixteen 4-float
+// blocks in the order block ^ (r & 15) -- lane (px, g) of k-step s reads float g of block s ^ px: 64 distinct banks.
+// Every output is the same chain as in conv_mfma_tile: acc = bias; for chunk; for k-step: acc = fma(w, x, acc) on the fp32 matrix
+// core with A = weights, B = activations.  Bit-identical to the register-staged tile (tests/test_gpu_fullsize.py).
+template <int S>
+__global__ void __launch_bounds__(256, 2) linear_dma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) float smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  constexpr int ST = 2 * 64 * 64;               // floats per stage: X at 0, W at 4096
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, cout_base = blockIdx.y * 64, x0 = blockIdx.x * 64;
+  if (a.counts && x0 >= a.counts[b]) return;    // rows beyond this item's count
+  f32x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = a.bias[cout_base + m * 16 + 4 * g + r];
+
+  // DMA roles.  Activations: piece i = 4 wave + u = tile rows 4 i .. 4 i + 3; lane L: row 4 i + (L >> 4), physical block L & 15
+  const float *xsrc[4], *xsrc2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 4 * (4 * wave + u) + (lane >> 4);
+    int row = x0 + r;
+    if (row > a.W - 1) row = a.W - 1;           // (past the end: any valid row; its outputs are never stored)
+    const int lb = (lane & 15) ^ (r & 15);
+    xsrc[u] = (const float *)a.in + (size_t)b * a.in_bstride + (size_t)row * a.in_ld + a.in_coff + 4 * lb;
+    xsrc2[u] = a.in2 ? a.in2 + (size_t)b * a.in2_bstride + (size_t)row * a.in2_ld + a.in2_coff + 4 * lb : xsrc[u];
+  }
+  // weights: piece i = rows k = 4 i .. 4 i + 3 of the chunk; lane L: row 4 i + (L >> 4), 16-byte slot L & 15 = physical block
+  // (L & 15) >> 2 -> logical block ((L & 15) >> 2) ^ (L >> 4)
+  const int dr = lane >> 4, dsl = lane & 15;
+  const float *wbase = a.w + cout_base + 16 * ((dsl >> 2) ^ dr) + 4 * (dsl & 3);
+  auto issue = [&](int ch) {
+    float *st = smem + (ch % S) * ST;
+    const int c0 = ch * 64;
+    const bool second = a.in2 && c0 >= a.Cin1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *p = second ? xsrc2[u] + (c0 - a.Cin1) : xsrc[u] + c0;
+      __builtin_amdgcn_global_load_lds((gbl_void *)p, (lds_void *)(st + (4 * wave + u) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * wave + u;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(wbase + (size_t)(c0 + 4 * i + dr) * a.Cout), (lds_void *)(st + 4096 + i * 256), 16, 0, 0);
+    }
+  };
+  const int nch = a.Cin / 64;
+  constexpr int LOOK = S - 1;
+  for (int c = 0; c < LOOK && c < nch; ++c) issue(c);
+  const int xoff = (16 * wave + px) * 64 + g;   // + 4 (ks ^ px)
+  const int woff = 4096 + g * 64 + px;          // + 16 (m ^ g) + 256 ks   (row 4 ks + g)
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + LOOK <= nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (LOOK - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // everybody's pieces of chunk ch are in; everybody is done with the stage refilled next
+    if (ch + LOOK < nch) issue(ch + LOOK);
+    const float *st = smem + (ch % S) * ST;
+    const float *xp = st + xoff;
+    const float *apm[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) apm[m] = st + woff + 16 * (m ^ g);
+    float pa[2][4], pb[2];
+#define URF_LDLOAD(set, ks)                                                         \
+  {                                                                                 \
+    pb[set] = xp[4 * ((ks) ^ px)];                                                  \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) pa[set][m] = apm[m][(ks) * 256];  \
+  }
+    URF_LDLOAD(0, 0)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < 16) URF_LDLOAD(cur ^ 1, ks + 1)
+      __builtin_amdgcn_sched_barrier(0);        // the next step's DS reads are issued before this step's MFMAs
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][m], pb[cur], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef URF_LDLOAD
+  }
+  // epilogue: lane = 4 consecutive channels of one row
+  const int row = x0 + 16 * wave + px;
+  if (row >= a.W) return;
+  const float *resb = a.res ? a.res + (size_t)b * a.res_bstride + (size_t)row * a.res_ld + a.res_coff : nullptr;
+  float *op = a.out + (size_t)b * a.out_bstride + (size_t)row * a.out_ld + a.out_coff;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int co = cout_base + m * 16 + 4 * g;
+    f32x4 v = acc[m];
+    if (a.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+    }
+    if (resb) {
+      const f32x4 rv = *(const f32x4 *)(resb + co);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rv[r] + v[r];
+    }
+    *(f32x4 *)(op + co) = v;
+  }
+}
+
+int g_linear_dma = -1;   // -1: not read yet; 0 = never, 1 = the policy of launch_conv (default), 2 / 3 = that many stages for every eligible launch
+
 static size_t conv_lds_bytes(int taps, bool fuse, bool wdma = false) {
   const int PH = taps == 9 ? TH + 2 : TH, PW = taps == 9 ? TW + 2 : TW;
   return sizeof(float) * ((size_t)PH * PW * IN_STRIDE + (wdma ? 2 * 64 * 64 : 64 * W_STRIDE) + (fuse ? 12 * 20 : 0));
@@ -577,6 +693,28 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   // workgroups, a quarter of the chain; one pair alone 4.41 -> 3.87 ms.  Same fma chain per output.  NOT for the redo engine of a
   // strict-parity handle, whose launches run beside three saturated streams: there the four-fold staging of the rows is chip time
   // the other streams lose (1044 against 1066 frames/s), and not for two pairs (3.37 against 3.25 ms alone).
+  // the DMA-staged linear tile (linear_dma_kernel): layers whose K and N are whole 64-blocks, on launches of at most 256 of the
+  // 128-row tiles (one or two pairs: the redo engine of a strict handle, the per-call host API) -- there it replaces the
+  // `narrow` form as well.  URF_LINEAR_DMA (experiments build): 0 never, 1 this policy, 2 / 3 = every eligible launch with that many stages
+  if (g_linear_dma < 0) { const char *e = urf::exp_env("URF_LINEAR_DMA"); g_linear_dma = e ? atoi(e) : 1; }
+  if (taps == 1 && !a.gate && g_linear_dma && (a.Cin % 64) == 0 && (a.Cout % 64) == 0 && (a.in_ld % 4) == 0 && (a.in_coff % 4) == 0 &&
+      (!a.in2 || ((a.Cin1 % 64) == 0 && (a.in2_ld % 4) == 0 && (a.in2_coff % 4) == 0))) {
+    const long tiles128 = (long)((a.W + 127) / 128) * (a.Cout / 64) * batch;
+    const int stages = g_linear_dma >= 2 ? (g_linear_dma >= 3 ? 3 : 2) : (tiles128 <= 256 ? 2 : 0);
+    if (stages) {
+      static DeviceOnce attr_ld;
+      if (attr_ld.need()) {
+        URF_HIP(hipFuncSetAttribute((const void *)linear_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        URF_HIP(hipFuncSetAttribute((const void *)linear_dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_ld.mark();
+      }
+      const dim3 g64((a.W + 63) / 64, a.Cout / 64, batch);
+      if (stages == 3) hipLaunchKernelGGL((linear_dma_kernel<3>), g64, dim3(256), 3 * 32 * 1024, st, a);
+      else hipLaunchKernelGGL((linear_dma_kernel<2>), g64, dim3(256), 2 * 32 * 1024, st, a);
+      URF_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   const bool narrow = taps == 1 && a.narrow && !a.gate && (a.Cout % 16) == 0 && a.Cout >= 64;
   grid.y = (split || narrow) ? (a.Cout + 15) / 16 : (a.Cout + 63) / 64;
   grid.z = batch;
@@ -634,4 +772,8 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
 extern "C" int urf_probe_conv32_stamps(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(urf::g_conv32_stamps), sizeof(long long) * 20) == hipSuccess ? 0 : -1;
 }
+#endif
+
+#ifdef URF_EXPERIMENTS
+extern "C" int urf_probe_linear_dma(int v) { urf::g_linear_dma = v; return 0; }
 #endif

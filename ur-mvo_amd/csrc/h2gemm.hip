@@ -693,7 +693,9 @@ int launch_h2gemm(const H2Args &a, int batch, hipStream_t st) {
     URF_CHECK(a.Cin / BK >= 5, "h2gemm: Cin %d below the deep ring's prologue", a.Cin);
     {
       const long tiles64 = (long)((a.rows + 63) / 64) * (a.Cout / 128) * batch;
-      const int depth = deep == 6 || deep == 3 ? deep : (deep == 1 ? (tiles64 <= 288 ? 6 : (tiles64 <= 448 ? 3 : 0)) : 0);
+      // (only for one or two pairs, where nothing else is resident: measured at four pairs in the 3-stream pipeline -- 1241x376, batch
+      // 4 -- the six-stage form LOSES 4 - 12 %, 823 / 757 against 860 frames/s: a 144-KB workgroup keeps its CU to itself)
+      const int depth = deep == 6 || deep == 3 ? deep : ((deep == 1 && batch <= 4) ? (tiles64 <= 288 ? 6 : (tiles64 <= 448 ? 3 : 0)) : 0);
       if (depth) {
         static DeviceOnce attr_deep;
         if (attr_deep.need()) {

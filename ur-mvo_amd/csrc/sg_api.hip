@@ -68,6 +68,10 @@ static const float kGuardSgZStrict = 2.2e-4f;
 // above this measured fast-vs-exact difference the error model itself is not trusted: a strict handle then redoes EVERY pair in the
 // exact mode (at calibration time and in the online check alike)
 static const float kGuardSgZCap = 2.5e-3f;
+// the flag-rate policy of a strict handle: decided over windows of kFlagWindow pairs of fast batches; above one half the handle runs
+// kExactSpell batches in the exact mode before it looks at the fast matcher again
+static const unsigned kFlagWindow = 32;
+static const int kExactSpell = 64;
 // integrity bound of a fast Sinkhorn result (every fast mode): the largest |column marginal - 1| of the plan the decode reads
 // (argmax_kernel, RESID; an invariant of every correct result: the iteration's last update is the column update).  Clean
 // launches stay below 2e-5 on both bench streams (tools/gpu_determinism.py prints the largest value seen);
@@ -227,6 +231,17 @@ struct urf_pm {
   float online_worst = 0.0f;
   unsigned long long online_pairs = 0, online_violations = 0, margin_raises = 0, audits = 0, audit_mismatches = 0, begins = 0;
   int audit_period = 256;
+  // a strict handle whose guard flags most pairs (or whose error model is beyond its cap: redo_all) gains nothing from the fast pass:
+  // fast pass + exact redo costs more than the exact pass alone once about half the pairs are redone (bench.py,
+  // strict_parity_vs_flag_rate: 519 against 652 frames/s with every pair redone).  The handle then runs its batches in the exact
+  // mode itself -- same lists, no fast pass -- and looks at the fast matcher again after kExactSpell batches.
+  int exact_left = 0;              // batches still to run in the exact mode before the fast matcher is tried again
+  unsigned long long exact_spells = 0;
+  bool exact_policy = true;        // (urf_sg_config.redo_flagged_pairs == 2 switches the diversion off: measurements of the redo path itself)
+  unsigned win_pairs = 0, win_flagged = 0;   // flag statistics of the fast batches since the last decision
+  unsigned long long exact_batches = 0;
+  bool last_fast = false;          // the batch enqueued last ran the fast matcher
+  bool calibrating = false;        // pm_calibrate_core's own fast pass: never diverted
   bool calib_said = false;         // "the automatic guard calibration could not run" has been said for THIS handle (no process-global state: the reference calls from fresh threads)
   // automatic calibration of the guard's margin (urf_sg_config.calibrate_pairs): pairs still to be measured, the largest difference seen
   int calib_left = 0, calib_failures = 0;
@@ -475,6 +490,7 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // environment: they decide what the handle guarantees
     h->g_z = h->cfg.guard_margin > 0.0f ? h->cfg.guard_margin : (h->strict ? kGuardSgZStrict : kGuardSgZ);
     h->redo_pairs = h->cfg.redo_flagged_pairs != 0 ? (h->cfg.redo_flagged_pairs > 0) : (h->strict ? 1 : 0);
+    h->exact_policy = h->cfg.redo_flagged_pairs != 2;
     h->redo_merge = h->cfg.redo_merge > 0 && h->cfg.redo_shared_engine != 0;
     if (const char *e = urf::exp_env("URF_REDO_MERGE")) h->redo_merge = atoi(e) != 0;   // (experiments build: A/B)
     if (const char *e = urf::exp_env("URF_REDO_OFF"); e && atoi(e) != 0) h->redo_pairs = 0;   // what-if timing runs (experiments build): results are NOT strict
@@ -830,11 +846,15 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   mark(PT_KENC);
   if (pm_kenc(h, NI)) return -1;
   mark(PT_GNN);
-  if (h->fast) {
+  const bool divert = h->fast && h->strict && h->redo_pairs && !h->calibrating && (h->redo_all || h->exact_left > 0);
+  const bool fast = h->fast && !divert;
+  if (divert) { h->exact_batches += 1; if (h->exact_left > 0) h->exact_left -= 1; }
+  h->last_fast = fast;
+  if (fast) {
     if (pm_gnn_fast(h, NI, prof)) return -1;
   } else if (pm_gnn_exact(h, NI, prof)) return -1;
   mark(PT_SCORE);
-  if (h->fast) {
+  if (fast) {
     if (h2_linear(h, NI, h->xh, h->xl, 256, 256, nullptr, nullptr, 0, 0, h->hwf, h->bf, 256, h->mdesc, nullptr, nullptr, 256, false,
                   nullptr, false))
       return -1;
@@ -856,7 +876,7 @@ static int pm_pipeline(urf_pm *h, int P, bool want_Z, bool ransac) {
   h->h_matches = h->hm_set[h->cur_set]; h->h_n = h->hn_set[h->cur_set];
   h->pairs_seen += (unsigned long long)P;
   h->batches_seen += 1;
-  return pm_tail(h, P, want_Z, ransac, prof, h->fast);
+  return pm_tail(h, P, want_Z, ransac, prof, fast);
 }
 
 // scores -> Sinkhorn -> decode -> outlier stage, from the projected descriptors h->mdesc (which stay in place until the next
@@ -1047,9 +1067,25 @@ static int pm_begin_batch(urf_pm *h) {
   if (!h->guarded || P < 1) { rollback.armed = false; return 0; }
   if (!h->flags_recorded) {             // (a second call -- after a redo, or a retry after a failed begin -- finds the pinned words cleared: keep the recorded ones)
     memset(h->fast_flags, 0, sizeof(h->fast_flags));
-    for (int p = 0; p < P && p < 64; ++p) { h->fast_flags[p] = h->h_gflags[p]; h->pairs_flagged += h->h_gflags[p] != 0; }
+    unsigned nf = 0;
+    for (int p = 0; p < P && p < 64; ++p) { h->fast_flags[p] = h->h_gflags[p]; nf += h->h_gflags[p] != 0; }
+    h->pairs_flagged += nf;
     for (int p = 0; p < P; ++p) h->h_gflags[p] = 0;
     h->flags_recorded = true;
+    if (h->strict && h->redo_pairs && h->last_fast && h->exact_policy) {
+      h->win_pairs += (unsigned)P; h->win_flagged += nf;
+      if (h->win_pairs >= kFlagWindow) {
+        if (2 * h->win_flagged > h->win_pairs) {
+          if (h->exact_spells == 0 || (h->exact_spells & (h->exact_spells - 1)) == 0)
+            fprintf(stderr, "liburf_front: the guard flagged %u of the last %u pairs: fast pass + exact redo costs more than the exact pass alone -- "
+                    "this strict handle runs its next %d batches in the exact mode (same lists), then tries the fast matcher again (spell %llu)\n",
+                    h->win_flagged, h->win_pairs, kExactSpell, h->exact_spells + 1);
+          h->exact_left = kExactSpell;
+          h->exact_spells += 1;
+        }
+        h->win_pairs = 0; h->win_flagged = 0;
+      }
+    }
   }
   memcpy(h->last_flags, h->fast_flags, sizeof(h->last_flags));
   h->redo_ms = 0.0f;
@@ -1257,7 +1293,7 @@ static int pm_check_resident(urf_pm *h) {
     if (again) what_backoff = true;
   }
   h->rs_on = false;
-  const int rc = pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->fast);
+  const int rc = pm_tail(h, h->last_P, h->last_Z, h->last_ransac, false, h->last_fast);
   if (what == 2 && !what_backoff) h->rs_on = was_on;
   if (rc) return -1;
   URF_HIP(hipStreamSynchronize(h->st));   // (the redone tail has new guard words: pm_guard_redo reads them next)
@@ -1462,7 +1498,10 @@ static int pm_calibrate_core(urf_pm *h, int P, float factor, double *out) {
     ~Restore() { h->last_P = P; h->last_Z = Z; h->last_ransac = ransac; h->flags_recorded = rec; h->redo_queued = queued;
                  for (int p = 0; p < h->maxP && p < 64; ++p) h->h_gflags[p] = 0; }
   } restore{h, keep_P, keep_Z, keep_ransac, keep_rec, keep_queued};
-  if (pm_pipeline(h, P, true, false)) return -1;                      // the fast pass, Z kept
+  h->calibrating = true;
+  const int rc_fast = pm_pipeline(h, P, true, false);                 // the fast pass, Z kept
+  h->calibrating = false;
+  if (rc_fast) return -1;
   h->pairs_seen = seen;
   URF_HIP(hipStreamSynchronize(st));
   if (h->h_rs_err && h->h_rs_err[0] != 0) {                           // the resident Sinkhorn gave up (or failed its integrity bound): nothing to measure against
@@ -1583,6 +1622,7 @@ extern "C" int urf_pm_guard_state(urf_pm *h, double *out, int n) {
                         (double)h->online_worst, (double)h->online_pairs, (double)h->margin_raises, (double)h->online_violations,
                         (double)h->audits, (double)h->audit_mismatches};
   for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+  if (n > 10) out[10] = (double)h->exact_batches;
   return 0;
 }
 

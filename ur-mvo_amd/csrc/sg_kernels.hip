@@ -87,20 +87,26 @@ __device__ __forceinline__ float exp_c_nonpos(float x) {
 // query tile share a SIMD (2 waves/SIMD hide each other's LDS/barrier stalls);
 // their partial results are combined once: l = lA + lB, O = (OA + OB) / l.
 constexpr int KHALF = 512;   // keys per half (8 chunks of 64)
-__global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
+// NQT = query tiles (16 queries each) per workgroup, two waves (key halves) per tile: 4 = the form above (64 queries, 512 threads);
+// 2 (round 6) = 32 queries on 256 threads for launches of one or two pairs, whose 128 - 256 workgroups of the wide form leave half
+// the chip idle (the redo engine of a strict handle, the per-call host API).  A wave's operations do not depend on NQT: same bits.
+template <int NQT>
+__global__ void __launch_bounds__(128 * NQT, 2) attn_kernel(const float *qkv /*[img][NP][768]*/, const int *counts,
                                                       int cross, float *o /*[img][NP][256]*/) {
+  constexpr int NT = 128 * NQT, QB = 16 * NQT;          // threads, queries per workgroup
+  constexpr int RPT = NT / 32, SU = 64 / RPT;           // staging: key rows per pass and half, passes per chunk
   __shared__ __attribute__((aligned(16))) float kv[2][2][64 * VSTR];  // [double buffer][half][chunk]
-  __shared__ float s_max[8][16];
-  __shared__ float s_l[4][16];
+  __shared__ float s_max[2 * NQT][16];
+  __shared__ float s_l[NQT][16];
   int qtile, grp;
-  xcd_group_map(blockIdx.x, NP / 64, (int)gridDim.x / (NP / 64), qtile, grp);   // the 16 query tiles of a head on one XCD
+  xcd_group_map(blockIdx.x, NP / QB, (int)gridDim.x / (NP / QB), qtile, grp);   // the query tiles of a head on one XCD
   const int im = grp >> 2, sm = cross ? (im ^ 1) : im;
   const int head = grp & 3;
   const int nq = counts[im], ns = counts[sm];
-  const int q0 = qtile * 64;
+  const int q0 = qtile * QB;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = wave & 3, kh = wave >> 2;
+  const int qt = wave % NQT, kh = wave / NQT;
   const int px = lane & 15, g = lane >> 4;
   const float *qb = qkv + ((size_t)im * NP) * 768 + head * 64;
   const float *kb = qkv + ((size_t)sm * NP) * 768 + 256 + head * 64;
@@ -109,29 +115,29 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][N
   const int nrounds = (nsA + 63) >> 6;                  // chunks of half A (>= chunks of half B)
   const int kbase_h = kh * KHALF;                       // first key of this wave's half
 
-  // staging: 512 threads, thread -> (half sh, key row sr + 16u, float4 sj)
-  const int sh = tid >> 8, st = tid & 255;
+  // staging: thread -> (half sh, key row sr + RPT u, float4 sj)
+  const int sh = tid / (NT / 2), st = tid % (NT / 2);
   const int sj = st & 15, sr = st >> 4;
-  f32x4 pf[4];
+  f32x4 pf[SU];
   auto issue = [&](const float *base, int ch) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int key = sh * KHALF + ch * 64 + sr + 16 * u;
+    for (int u = 0; u < SU; ++u) {
+      const int key = sh * KHALF + ch * 64 + sr + RPT * u;
       pf[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (key < ns) pf[u] = *(const f32x4 *)(base + (size_t)key * 768 + 4 * sj);
     }
   };
   auto commit_k = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float *dst = kv[buf][sh] + (sr + 16 * u) * KSTR + 4 * sj;
+    for (int u = 0; u < SU; ++u) {
+      float *dst = kv[buf][sh] + (sr + RPT * u) * KSTR + 4 * sj;
       *(float2 *)dst = make_float2(pf[u][0], pf[u][1]);
       *(float2 *)(dst + 2) = make_float2(pf[u][2], pf[u][3]);
     }
   };
   auto commit_v = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *(f32x4 *)(kv[buf][sh] + (sr + 16 * u) * VSTR + 4 * sj) = pf[u];
+    for (int u = 0; u < SU; ++u) *(f32x4 *)(kv[buf][sh] + (sr + RPT * u) * VSTR + 4 * sj) = pf[u];
   };
 
   issue(kb, 0);
@@ -198,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const float *qkv /*[img][N
   if (g == 0) s_max[wave][px] = m;
   commit_v(0);
   __syncthreads();
-  m = fmaxf(m, s_max[wave ^ 4][px]);
+  m = fmaxf(m, s_max[wave < NQT ? wave + NQT : wave - NQT][px]);   // the wave of this query tile's other key half
   // ---------------- phase 2: p = exp_c(s - m) one tile ahead of its O^T += V^T P^T
   const int nsl = ns - kbase_h;  // keys of this half (may be <= 0)
   float part = 0.0f;
@@ -697,8 +703,13 @@ int launch_sg_prep_slots(const float *const *slots, int nimg, int width, int hei
   URF_HIP(hipGetLastError());
   return 0;
 }
+int g_attn_exact_nqt = -1;   // (urf_probe_attn_exact_nqt, experiments build: 2 / 4 = that form for every launch, 0 = the policy)
 int launch_attn(const float *qkv, const int *counts, int cross, float *o, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(attn_kernel, dim3((NP / 64) * 4 * nimg), dim3(512), 0, st, qkv, counts, cross, o);
+  // one or two pairs: 32-query workgroups (twice as many, half the size); URF_ATTN_EXACT_NQT (experiments build) forces 2 or 4
+  if (g_attn_exact_nqt < 0) { const char *e = urf::exp_env("URF_ATTN_EXACT_NQT"); g_attn_exact_nqt = e ? atoi(e) : 0; }
+  const int nqt = g_attn_exact_nqt == 2 || g_attn_exact_nqt == 4 ? g_attn_exact_nqt : (nimg <= 4 ? 2 : 4);
+  if (nqt == 2) hipLaunchKernelGGL(attn_kernel<2>, dim3((NP / 32) * 4 * nimg), dim3(256), 0, st, qkv, counts, cross, o);
+  else hipLaunchKernelGGL(attn_kernel<4>, dim3((NP / 64) * 4 * nimg), dim3(512), 0, st, qkv, counts, cross, o);
   URF_HIP(hipGetLastError());
   return 0;
 }
@@ -759,3 +770,7 @@ int launch_decode(const int *counts, const float *C, const float *Ct, const floa
 }
 
 }  // namespace urf
+
+#ifdef URF_EXPERIMENTS
+extern "C" int urf_probe_attn_exact_nqt(int v) { urf::g_attn_exact_nqt = v; return 0; }
+#endif

@@ -245,14 +245,14 @@ class _PM:
 
     def guard_state(self):
         """dict(margin in use, largest calibrated fast-vs-exact difference, pairs the automatic calibration still wants, redo_all)"""
-        v = (C.c_double * 10)()
-        check(_lib.lib().urf_pm_guard_state(self._h, v, 10), "urf_pm_guard_state")
+        v = (C.c_double * 11)()
+        check(_lib.lib().urf_pm_guard_state(self._h, v, 11), "urf_pm_guard_state")
         # online_*: the by-product of every exact redo (largest fast-vs-exact difference seen on a redone pair, pairs sampled,
         # times the margin was raised for it, times it exceeded the margin its batch was guarded with); audits: unflagged pairs
         # sent through the exact engine / those whose exact index list differed from the fast one
         return dict(margin=float(v[0]), measured=float(v[1]), pairs_left=int(v[2]), redo_all=bool(v[3]),
                     online_worst=float(v[4]), online_pairs=int(v[5]), margin_raises=int(v[6]), online_violations=int(v[7]),
-                    audits=int(v[8]), audit_mismatches=int(v[9]))
+                    audits=int(v[8]), audit_mismatches=int(v[9]), exact_batches=int(v[10]))
 
     def near_tie_flags(self, P=1):
         """guard words of the pairs of the batch handed out last (0 = the pair's match set is the exact pipeline's)"""
