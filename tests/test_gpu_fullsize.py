@@ -333,12 +333,21 @@ def test_the_pipeline_is_reproducible_run_to_run_soak(U, F, sp_blob, sg_blob, pr
     pipe.prologue()
     lists, bad = {}, []
 
+    audited = []
+
     def rec(b, mt, res):
         lists[b] = [r.copy() for r in res]
         if b >= 6:
             for j in range(B):
-                if not np.array_equal(lists[b][j], lists[b - 5][j]):
-                    bad.append((b, j))
+                x, y = lists[b][j], lists[b - 5][j]
+                if not np.array_equal(x, y):
+                    # strict mode, round 6: one UNFLAGGED pair of every 256th begun batch of a handle is audited -- handed out from
+                    # the exact engine instead of the fast pass: the same index list, distances within the fast matcher's 1e-3
+                    if prec == 3 and len(x) == len(y) and np.array_equal(x["queryIdx"], y["queryIdx"]) and \
+                            np.array_equal(x["trainIdx"], y["trainIdx"]) and float(np.abs(x["distance"] - y["distance"]).max()) < 1e-3:
+                        audited.append((b, j))
+                    else:
+                        bad.append((b, j))
         lists.pop(b - 10, None)
 
     for b in range(steps):
@@ -348,6 +357,15 @@ def test_the_pipeline_is_reproducible_run_to_run_soak(U, F, sp_blob, sg_blob, pr
     assert sum(m.sinkhorn_fallbacks() for m in pms) == 0
     if prec == 3:
         assert sum(m.near_tie_reruns()["redone"] for m in pms) >= steps // 5 - 2       # (one flagged pair per period on this stream)
+        gs = [m.guard_state() for m in pms]
+        audits = sum(g["audits"] for g in gs)
+        # 750 begun batches per handle: two audits each unless the pair whose turn it was had been flagged anyway; an audited pair
+        # differs (in its distances only) from its neighbours five batches before and after: at most two tolerated entries per audit
+        assert 1 <= audits <= 6 and len(audited) <= 2 * audits, (audits, audited)
+        assert sum(g["audit_mismatches"] for g in gs) == 0 and sum(g["online_violations"] for g in gs) == 0
+        assert all(g["online_worst"] <= g["margin"] / 1.6 + 1e-9 for g in gs) and sum(g["exact_batches"] for g in gs) == 0
+    else:
+        assert not audited
 
 
 @pytest.mark.gpu
