@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--no-guard-calibration", action="store_true",
                     help="skip the check of the guard's error model before the timed region (counter-collection runs: its "
                          "exact-mode launches would be tallied with the step's)")
+    ap.add_argument("--matcher-gain", type=float, default=0.5,
+                    help="residual gain of the seeded SuperGlue weights (synth.sg_weights(0, gnn_gain)): 0.5 = the headline's; larger gains "
+                         "make the fast matcher's error, the strict handle's margin and the share of flagged pairs grow (what-if runs)")
     ap.add_argument("--resolution", default="640x480", choices=["640x480", "1241x376"],
                     help="frame size WxH: 640x480 (headline, BASELINE configs[2]) or the KITTI-size stream of configs[3]")
     args = ap.parse_args()
@@ -336,7 +339,7 @@ def main():
     U = load_pkg()
     F, synth, D, P = U.frontend, U.synth, U.dist, U.pipeline
     spb = synth.pack_sp(synth.sp_weights(0))
-    sgb = synth.pack_sg(synth.sg_weights(0))
+    sgb = synth.pack_sg(synth.sg_weights(0, gnn_gain=args.matcher_gain))
     PREC = args.precision
     FAST = PREC >= 1                  # the matcher runs on the f16 matrix core
     SP_FAST = PREC in (1, 2)          # ... and so does SuperPoint (strict parity keeps it in exact fp32)
@@ -624,7 +627,7 @@ def main():
             # with 2x and 3x the residual gain, each against the exact mode on the same weights (index lists must be equal).
             curve = []
             for gain in (0.5, 1.0, 1.5):
-                sgb_g = sgb if gain == 0.5 else synth.pack_sg(synth.sg_weights(0, gnn_gain=gain))
+                sgb_g = synth.pack_sg(synth.sg_weights(0, gnn_gain=gain))
                 r_, lists_ = stream_run(U, spb, sgb_g, dev, local_rank, 3, 480, 640, 8, 20, 3, keep=True)
                 x_, xl_ = stream_run(U, spb, sgb_g, dev, local_rank, 0, 480, 640, 8, 10, 1, keep=True)
                 tot_ = same_ = 0
@@ -690,7 +693,7 @@ def main():
                        "max_keypoints": MAX_KP, "keypoints_per_frame": round(n_avg, 1),
                        "sinkhorn_iterations": SINK_ITERS, "ransac_iterations": 200, "precision": {0: "exact", 1: "fast", 2: "guarded fast", 3: "strict parity"}[PREC],
                        "weights": {"what": "seeded synthetic (the reference ships none): synth.sp_weights(0), synth.sg_weights(0)",
-                                   "matcher_gnn_gain": 0.5,
+                                   "matcher_gnn_gain": args.matcher_gain,
                                    "strict_mode_pairs_flagged_and_redone": f"{sum(h_['pairs_redone_exact'] for h_ in per_rank)}/{sum(h_['pairs'] for h_ in per_rank)}",
                                    "note": "the strict mode's rate depends on the share of pairs its guard flags, a property of the weights and "
                                            "the data: secondary.strict_parity_vs_flag_rate holds the rate at other gains"},

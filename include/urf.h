@@ -621,8 +621,8 @@ int urf_probe_h2gemm_xflags(int flags);
  * urf_probe_h2gemm_deep: 0 = never the deep-ring tile, 1 = the launcher's policy (default), 6 / 3 = that ring depth everywhere;
  * urf_probe_attn_variant: -1 = the launcher's policy, 0 .. 4 = 1x8, 2x4, 2x8, 1x4, 1x2 (query tiles per wave x waves) */
 int urf_probe_h2gemm_deep(int depth);
-/* the exact linear layer with both operands by LDS-DMA (linear_dma_kernel): 0 = never, 1 = the launcher's policy (default),
- * 2 / 3 = every eligible launch, with that many stages.  Bit-identical to the register-staged tile. */
+/* the exact linear layer with both operands by LDS-DMA (linear_dma_kernel): 0 = never (the register-staged tile), 1 / 2 = two
+ * stages (default), 3 = three stages.  Bit-identical to the register-staged tile. */
 int urf_probe_linear_dma(int v);
 /* the exact attention kernel's workgroup: 4 = 64 queries on 512 threads, 2 = 32 queries on 256 threads, 0 = the launcher's
  * policy (2 for at most two pairs).  Same bits. */

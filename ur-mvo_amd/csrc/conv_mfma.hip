@@ -693,14 +693,14 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   // workgroups, a quarter of the chain; one pair alone 4.41 -> 3.87 ms.  Same fma chain per output.  NOT for the redo engine of a
   // strict-parity handle, whose launches run beside three saturated streams: there the four-fold staging of the rows is chip time
   // the other streams lose (1044 against 1066 frames/s), and not for two pairs (3.37 against 3.25 ms alone).
-  // the DMA-staged linear tile (linear_dma_kernel): layers whose K and N are whole 64-blocks, on launches of at most 256 of the
-  // 128-row tiles (one or two pairs: the redo engine of a strict handle, the per-call host API) -- there it replaces the
-  // `narrow` form as well.  URF_LINEAR_DMA (experiments build): 0 never, 1 this policy, 2 / 3 = every eligible launch with that many stages
+  // the DMA-staged linear tile (linear_dma_kernel): every layer whose K and N are whole 64-blocks (it replaces the `narrow` form
+  // of the per-pair host API as well).  URF_LINEAR_DMA (experiments build): 0 never, 1 / 2 = two stages (default), 3 = three stages
   if (g_linear_dma < 0) { const char *e = urf::exp_env("URF_LINEAR_DMA"); g_linear_dma = e ? atoi(e) : 1; }
   if (taps == 1 && !a.gate && g_linear_dma && (a.Cin % 64) == 0 && (a.Cout % 64) == 0 && (a.in_ld % 4) == 0 && (a.in_coff % 4) == 0 &&
       (!a.in2 || ((a.Cin1 % 64) == 0 && (a.in2_ld % 4) == 0 && (a.in2_coff % 4) == 0))) {
-    const long tiles128 = (long)((a.W + 127) / 128) * (a.Cout / 64) * batch;
-    const int stages = g_linear_dma >= 2 ? (g_linear_dma >= 3 ? 3 : 2) : (tiles128 <= 256 ? 2 : 0);
+    // (two stages = 64 KB, two workgroups per CU, for every eligible launch: measured +1.2 % in the exact mode at batch 8 and in the
+    // strict mode at a 40 % flag rate, a lone pair's linear layers 1.47 -> 1.13 ms; three stages lose 3.5 % at batch 8)
+    const int stages = g_linear_dma >= 3 ? 3 : 2;
     if (stages) {
       static DeviceOnce attr_ld;
       if (attr_ld.need()) {
