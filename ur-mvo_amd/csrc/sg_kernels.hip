@@ -82,6 +82,33 @@ __device__ __forceinline__ float exp_c_nonpos(float x) {
   return x < -87.33654f ? 0.0f : v;
 }
 
+// Two softmax arguments at a time on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one instruction, two IEEE
+// operations per lane): the same operations on each element as exp_c_nonpos, hence the same bits -- 19 instructions per pair of
+// elements instead of 32.  The exact attention kernel spends 40 % of its time in this polynomial (fp32 VALU work does not hide under
+// the fp32 MFMAs on gfx950: EXPERIMENTS.md section 8, round 5).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_c_nonpos2(f32x2 x) {
+  auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+  auto k2 = [](float c) { return f32x2{c, c}; };
+  const f32x2 n = __builtin_elementwise_rint(x * 1.44269504088896341f);
+  f32x2 r = fma2(n, k2(-0.693359375f), x);
+  r = fma2(n, k2(2.12194440e-4f), r);
+  f32x2 p = k2(1.9875691500e-4f);
+  p = fma2(p, r, k2(1.3981999507e-3f));
+  p = fma2(p, r, k2(8.3334519073e-3f));
+  p = fma2(p, r, k2(4.1665795894e-2f));
+  p = fma2(p, r, k2(1.6666665459e-1f));
+  p = fma2(p, r, k2(5.0000001201e-1f));
+  const f32x2 r2 = r * r;
+  const f32x2 y = fma2(p, r2, r) + 1.0f;
+  f32x2 v;
+  v[0] = __builtin_ldexpf(y[0], (int)n[0]);
+  v[1] = __builtin_ldexpf(y[1], (int)n[1]);
+  v[0] = x[0] < -87.33654f ? 0.0f : v[0];
+  v[1] = x[1] < -87.33654f ? 0.0f : v[1];
+  return v;
+}
+
 // 512-thread workgroup = 64 queries x 1 head: wave w handles query tile (w & 3)
 // against key half (w >> 2): keys [0,512) or [512,1024).  The two waves of a
 // query tile share a SIMD (2 waves/SIMD hide each other's LDS/barrier stalls);
@@ -209,8 +236,11 @@ __global__ void __launch_bounds__(128 * NQT, 2) attn_kernel(const float *qkv /*[
   const int nsl = ns - kbase_h;  // keys of this half (may be <= 0)
   float part = 0.0f;
   if (nsl > 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const float p = exp_c_nonpos(sreg[0][r] - m); sreg[0][r] = p; part = part + p; }
+    {   // (part = ((part + p0) + p1) + p2) + p3: the canonical order, whatever computes the p)
+      const f32x2 a = exp_c_nonpos2(f32x2{sreg[0][0] - m, sreg[0][1] - m}), b = exp_c_nonpos2(f32x2{sreg[0][2] - m, sreg[0][3] - m});
+      sreg[0][0] = a[0]; sreg[0][1] = a[1]; sreg[0][2] = b[0]; sreg[0][3] = b[1];
+      part = part + a[0]; part = part + a[1]; part = part + b[0]; part = part + b[1];
+    }
   }
   f32x4 oacc[4];
 #pragma unroll
@@ -232,11 +262,11 @@ __global__ void __launch_bounds__(128 * NQT, 2) attn_kernel(const float *qkv /*[
         for (int s = 0; s < 16; ++s) {
           const int kt = s >> 2, r = s & 3, T = ch * 4 + kt;
           if (r == 0 && T + 1 < 32 && (T + 1) * 16 < nsl) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float p = exp_c_nonpos(sreg[T + 1 < 32 ? T + 1 : 31][q] - m);
-              sreg[T + 1 < 32 ? T + 1 : 31][q] = p;
-              part = part + p;
+            {
+              f32x4 &sv = sreg[T + 1 < 32 ? T + 1 : 31];
+              const f32x2 a = exp_c_nonpos2(f32x2{sv[0] - m, sv[1] - m}), b = exp_c_nonpos2(f32x2{sv[2] - m, sv[3] - m});
+              sv[0] = a[0]; sv[1] = a[1]; sv[2] = b[0]; sv[3] = b[1];
+              part = part + a[0]; part = part + a[1]; part = part + b[0]; part = part + b[1];
             }
           }
           if (s + 1 < 16) {
@@ -257,11 +287,11 @@ __global__ void __launch_bounds__(128 * NQT, 2) attn_kernel(const float *qkv /*[
         const int T = ch * 4 + kt;
         if (T * 16 < nsl) {
           if (T + 1 < 32 && (T + 1) * 16 < nsl) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = exp_c_nonpos(sreg[T + 1 < 32 ? T + 1 : 31][r] - m);
-              sreg[T + 1 < 32 ? T + 1 : 31][r] = p;
-              part = part + p;
+            {
+              f32x4 &sv = sreg[T + 1 < 32 ? T + 1 : 31];
+              const f32x2 a = exp_c_nonpos2(f32x2{sv[0] - m, sv[1] - m}), b = exp_c_nonpos2(f32x2{sv[2] - m, sv[3] - m});
+              sv[0] = a[0]; sv[1] = a[1]; sv[2] = b[0]; sv[3] = b[1];
+              part = part + a[0]; part = part + a[1]; part = part + b[0]; part = part + b[1];
             }
           }
 #pragma unroll
@@ -404,9 +434,17 @@ __device__ __forceinline__ float sinkhorn_row_lse(const f32x4 (&cur)[5], const f
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
     const int c = 256 * t + 4 * lane;
+    if (FAST) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (c + r < Cn) s = s + (FAST ? __expf(x[t][r] - m) : exp_c_nonpos(x[t][r] - m));
+      for (int r = 0; r < 4; ++r)
+        if (c + r < Cn) s = s + __expf(x[t][r] - m);
+    } else {   // the canonical exponential, two elements per packed instruction (exp_c_nonpos2: the same bits); same order of the sum
+      const f32x2 a = exp_c_nonpos2(f32x2{x[t][0] - m, x[t][1] - m}), b = exp_c_nonpos2(f32x2{x[t][2] - m, x[t][3] - m});
+      if (c + 0 < Cn) s = s + a[0];
+      if (c + 1 < Cn) s = s + a[1];
+      if (c + 2 < Cn) s = s + b[0];
+      if (c + 3 < Cn) s = s + b[1];
+    }
   }
   s = bfly64_sum(s);
   return m + (FAST ? __logf(s) : log_c(s));
