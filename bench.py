@@ -582,6 +582,18 @@ def main():
                                         "gbytes_per_s": round(v[2] / v[0] * 1e3, 1), "bound": roofs(k, *v)[0],
                                         "frac": round(frac_of(k, v), 4), "ms_below_roof": round(float(v[0] * (1 - frac_of(k, v))), 3)}
                                     for k, v in per_step.items()}}
+        if FAST and "h2gemm" in dom:
+            # What paces this family: not the matrix pipe and not HBM but the STAGING of its operands into LDS.
+            # Every workgroup of a launch fetches its weight tile and its activation tile (two f16 planes each = 4 B per element)
+            # for the whole K; with 128 x 128 (128 x 64) tiles that is Cin x 1 KiB (768 B) per workgroup: per GNN layer and step
+            tiles = int(np.ceil(n_avg / 128.0)) * 2 * BATCH
+            fill = 18 * (tiles * 6 * 256 * 256 * 4 + tiles * 4 * 256 * 512 * 4 + 2 * tiles * 2 * 192 * 512 * 4) + 2 * tiles * 2 * 192 * 256 * 4
+            roofline["lds_fill"] = {
+                "gbytes_per_step": round(fill / 1e9, 2), "tbytes_per_s": round(fill / 1e9 / ms, 2),
+                "note": "L2 -> LDS staging bytes of the 55 linear launches of a step (analytic: per workgroup (weight rows + activation rows) x "
+                        "Cin x 4 B), over this family's measured time: the LDS-DMA stream of the chip sustains 6 - 7 TB/s "
+                        "(MI355X_MICROARCH.md: ldsdma-fill, chip 6.4 TB/s), which is where these launches sit -- the split-f16 operands cost "
+                        "4 B per element for 3 MFMAs of 16 cycles, so at 128 x 128 tiles the staging, not the matrix pipe, is the roof"}
         stage_means = {"superpoint": round(float(np.mean(sp_ms)), 3), "matching": round(float(np.mean(pm_ms)), 3),
                        "sinkhorn": round(float(np.mean(sink_ms)), 3), "ransac": round(float(np.mean(ransac_ms)), 3)}
         exact = None
