@@ -193,8 +193,8 @@ typedef struct {
   float sinkhorn_residual_bound;
   /* automatic calibration of the matcher's guard (precision 2, 3; appended): the first calibrate_pairs pairs the handle is given
    * (by any entry: urf_match, urf_sg_infer, urf_match_device_async) are measured BEFORE they are matched -- the fast against the
-   * exact matcher, as urf_pm_calibrate_guard does -- and the margin becomes at least 1.6 x the largest difference seen (the
-   * maximum over a few pairs underestimates a stream's), so that the strict guarantee follows the deployment's own weights
+   * exact matcher, as urf_pm_calibrate_guard does -- and the margin becomes at least 2.5 x the largest difference seen (the
+   * maximum over eight pairs underestimates a stream's by up to 2.3 x, measured), so that the strict guarantee follows the deployment's own weights
    * instead of the synthetic ones the built-in 2.2e-4 was measured on.  0 = the mode's default (3: 8 pairs; 2: none), < 0 =
    * never.  Costs one exact pass per measured batch, once; reported on stderr.  Above 2.5e-3 a strict handle redoes EVERY pair
    * in the exact mode (still the oracle's lists, at the exact mode's speed) and says so. */

@@ -762,7 +762,7 @@ def test_strict_handle_calibrates_itself_on_other_weights(U, F):
         left = g["pairs_left"]
     g = st.guard_state()
     assert g["pairs_left"] == 0
-    assert g["measured"] > 0.0 and g["margin"] >= max(2.2e-4, 1.6 * g["measured"]) - 1e-9 and not g["redo_all"]
+    assert g["measured"] > 0.0 and g["margin"] >= max(2.2e-4, 2.5 * g["measured"]) - 1e-9 and not g["redo_all"]
     assert abs(off.guard_state()["margin"] - 2.2e-4) < 1e-9 and off.guard_state()["measured"] == 0.0
     redone = st.near_tie_reruns()["redone"]
     assert st.near_tie_reruns()["pairs"] == len(pairs)              # the calibration passes are not counted as pairs
@@ -992,7 +992,9 @@ def test_a_strict_handle_whose_guard_flags_most_pairs_runs_in_the_exact_mode(U, 
     sp.sync()
     s0, s1 = [slots[j].data_ptr() for j in range(4)], [slots[j + 1].data_ptr() for j in range(4)]
     ex = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, precision=0)
-    st = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, precision=3, guard_margin=50.0, calibrate_pairs=-1)
+    # (audit_period 1: a diverted batch must not be audited or redone either -- its lists are exact already and its encoded
+    # keypoints, what a redo starts from, were consumed in place: round 6's sweep on other weights found exactly that)
+    st = F.PointMatching(F.SuperGlueConfig(), max_pairs=4, precision=3, guard_margin=50.0, calibrate_pairs=-1, audit_period=1)
     assert ex.build(sg_blob) and st.build(sg_blob)
     ex.match_device_async(s0, s1, True)
     want = ex.fetch(4, as_arrays=True)
@@ -1004,4 +1006,6 @@ def test_a_strict_handle_whose_guard_flags_most_pairs_runs_in_the_exact_mode(U, 
             assert np.array_equal(a["queryIdx"], w["queryIdx"]) and np.array_equal(a["trainIdx"], w["trainIdx"]), b
         seen.append((st.guard_state()["exact_batches"], st.near_tie_reruns()["redone"]))
     assert seen[7] == (0, 32) and seen[-1] == (4, 32), seen       # batches 9 .. 12 ran exact: nothing flagged, nothing redone
+    g = st.guard_state()
+    assert g["audits"] == 0 and g["audit_mismatches"] == 0 and g["online_violations"] == 0 and g["online_pairs"] == 32
 

@@ -22,7 +22,7 @@ wseed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 gain = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
 sgb = synth.pack_sg(synth.sg_weights(wseed, gnn_gain=gain))
 pmx = F.PointMatching(F.SuperGlueConfig(), precision=0)
-pms = F.PointMatching(F.SuperGlueConfig(), precision=3)
+pms = F.PointMatching(F.SuperGlueConfig(), precision=3, audit_period=int(os.environ.get("URF_SWEEP_AUDIT", "0")))   # (0 = every 256th pair)
 assert pmx.build(sgb) and pms.build(sgb)
 bad = flagged = tot = 0
 worst_d = 0.0
@@ -47,6 +47,9 @@ st = pms.near_tie_reruns()
 g = pms.guard_state()
 print(f"weights seed {wseed} gain {gain}: guard margin {g['margin']:.3g} (largest calibrated difference {g['measured']:.3g}, redo_all {g['redo_all']}); "
       f"largest column-marginal residual integrity events {pms.sinkhorn_integrity()['events']}")
+print(f"   online guard check: largest fast-vs-exact difference on a redone pair {g['online_worst']:.3g} over {g['online_pairs']} pairs, {g['margin_raises']} raises, "
+      f"{g['online_violations']} violations; {g['audits']} unflagged pairs audited, {g['audit_mismatches']} with another index list; "
+      f"{g['exact_batches']} pairs run in the exact mode by the handle itself (its guard flagged most of the pairs before them)")
 print(f"{N} pairs, {tot} matches: pairs whose strict list differs from the exact list: {bad}; flagged and redone {flagged} ({st['redone']} by the counter); "
       f"largest distance difference on an unflagged pair {worst_d:.3g}")
 sys.exit(1 if bad else 0)
