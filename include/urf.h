@@ -620,6 +620,9 @@ int urf_probe_h2gemm_xflags(int flags);
 /* A/B switches of round 6's small-grid kernels (bit-identical forms of the fast matcher's linear and attention kernels):
  * urf_probe_h2gemm_deep: 0 = never the deep-ring tile, 1 = the launcher's policy (default), 6 / 3 = that ring depth everywhere;
  * urf_probe_attn_variant: -1 = the launcher's policy, 0 .. 4 = 1x8, 2x4, 2x8, 1x4, 1x2 (query tiles per wave x waves) */
+/* the next `passes` passes of a redo engine fail after they have taken their jobs out of the engine's queue -- what a failing
+ * launch or copy does; the owners' urf_pm_fetch_begin / _end must report it instead of handing out un-redone lists */
+int urf_probe_redo_fault(int passes);
 int urf_probe_h2gemm_deep(int depth);
 /* the exact linear layer with both operands by LDS-DMA (linear_dma_kernel): 0 = never (the register-staged tile), 1 / 2 = two
  * stages (default), 3 = three stages.  Bit-identical to the register-staged tile. */

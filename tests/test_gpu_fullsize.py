@@ -1009,3 +1009,57 @@ def test_a_strict_handle_whose_guard_flags_most_pairs_runs_in_the_exact_mode(U, 
     g = st.guard_state()
     assert g["audits"] == 0 and g["audit_mismatches"] == 0 and g["online_violations"] == 0 and g["online_pairs"] == 32
 
+
+def test_a_failed_redo_pass_is_reported_not_papered_over(Uexp, sp_blob, sg_blob):
+    """ADVICE of round 5: a redo pass that fails after it has taken its jobs out of the engine's queue used to leave them neither
+    queued nor launched -- urf_pm_fetch_end then waited on an event that was never recorded for the batch and handed out the
+    un-redone FAST lists of a strict handle without an error; and a retried urf_pm_fetch_begin found its guard words cleared and
+    redid nothing.  With the fault injected (experiments build): (1) own engine: fetch_begin fails, the retry queues the redo from
+    the recorded guard words, the lists are the exact ones; (2) a shared engine with merged passes: the pass that fails also held
+    the OTHER handle's waiting job -- that handle's fetch_end reports it, and both handles go on with their next batches."""
+    import torch
+    Fx, L = Uexp.frontend, Uexp._lib.lib()
+    frames = Uexp.synth.shift_stream(71, 4, 480, 640)
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    slots = torch.zeros((4, L.urf_slot_bytes() // 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp = Fx.SuperPoint(Fx.SuperPointConfig(max_keypoints=1000), max_height=480, max_width=640, max_batch=4, precision=0)
+    assert sp.build(sp_blob)
+    sp.infer_device(d.data_ptr(), 4, 480, 640, slots.data_ptr())
+    sp.sync()
+    s0, s1 = [slots[j].data_ptr() for j in range(3)], [slots[j + 1].data_ptr() for j in range(3)]
+    ex = Fx.PointMatching(Fx.SuperGlueConfig(), max_pairs=3, precision=0)
+    assert ex.build(sg_blob)
+    ex.match_device_async(s0, s1, True)
+    want = ex.fetch(3)
+    idx = lambda lists: [[(q, t) for q, t, _ in m] for m in lists]   # noqa: E731
+    mk = lambda **kw: Fx.PointMatching(Fx.SuperGlueConfig(), max_pairs=3, precision=3, guard_margin=50.0, calibrate_pairs=-1,   # noqa: E731
+                                       redo_flagged_pairs=2, **kw)
+    try:
+        # (1) an engine of the handle's own
+        a = mk()
+        assert a.build(sg_blob)
+        a.match_device_async(s0, s1, True)
+        L.urf_probe_redo_fault(1)
+        with pytest.raises(RuntimeError, match="injected fault"):
+            a.fetch_begin(3)
+        assert a.fetch_begin(3) == 1                       # the retry: the recorded guard words, the redo queued again
+        assert a.fetch_end(3) == want                      # ... and the lists are the exact engine's, bit for bit
+        assert a.near_tie_reruns()["redone"] == 3
+        # (2) two handles on one engine, merged passes: a's job waits in the pool, b's begin launches both -- and fails
+        a, b = mk(redo_shared_engine=1, redo_merge=1), mk(redo_shared_engine=1, redo_merge=1)
+        assert a.build(sg_blob) and b.build(sg_blob)
+        a.match_device_async(s0, s1, True)
+        assert a.fetch_begin(3) == 1                       # queued, waiting one step for a companion
+        b.match_device_async(s0, s1, True)
+        L.urf_probe_redo_fault(1)
+        with pytest.raises(RuntimeError, match="injected fault"):
+            b.fetch_begin(3)
+        with pytest.raises(RuntimeError, match="could not be enqueued"):
+            a.fetch_end(3)                                 # a's job went down with that pass: an error, not the fast lists
+        assert b.fetch_begin(3) == 1 and idx(b.fetch_end(3)) == idx(want)   # b retries; a's batch is lost, the handle is not
+        a.match_device_async(s0, s1, True)
+        assert idx(a.fetch(3)) == idx(want)
+    finally:
+        L.urf_probe_redo_fault(0)
+

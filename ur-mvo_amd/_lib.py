@@ -32,7 +32,7 @@ SYMBOLS = [
 ]
 # exported by the experiments build only (#ifdef URF_EXPERIMENTS in include/urf.h): fault injection, kernel A/B switches, diagnostics
 EXPERIMENT_SYMBOLS = [
-    "urf_probe_h2gemm_variant", "urf_probe_h2gemm_xflags", "urf_probe_h2gemm_deep", "urf_probe_linear_dma", "urf_probe_attn_exact_nqt", "urf_probe_attn_variant", "urf_probe_sinkhorn_stamps", "urf_probe_sinkhorn_fault",
+    "urf_probe_h2gemm_variant", "urf_probe_h2gemm_xflags", "urf_probe_h2gemm_deep", "urf_probe_redo_fault", "urf_probe_linear_dma", "urf_probe_attn_exact_nqt", "urf_probe_attn_variant", "urf_probe_sinkhorn_stamps", "urf_probe_sinkhorn_fault",
     "urf_probe_sinkhorn_backoff", "urf_probe_sinkhorn_corrupt", "urf_probe_mfma_roof",
 ]
 

@@ -86,7 +86,9 @@ static const float kSinkhornResidBound = 1e-4f;
 static int g_backoff_override = 0;
 // test hook: handles built after this call stay on the streaming Sinkhorn for `batches` batches after a give-up (0 = the default, 64)
 #ifdef URF_EXPERIMENTS
+static std::atomic<int> g_redo_fault{0};   // (urf_probe_redo_fault: the next n redo passes fail after they have taken their jobs)
 extern "C" int urf_probe_sinkhorn_backoff(int batches) { g_backoff_override = batches; return 0; }
+extern "C" int urf_probe_redo_fault(int passes) { g_redo_fault.store(passes < 0 ? 0 : passes); return 0; }
 #endif
 
 struct urf_pm {
@@ -995,6 +997,12 @@ static int pool_flush(urf::RedoPool *pool) {
       std::vector<urf::RedoPool::Job> &pass; bool armed;
       ~MarkFailed() { if (armed) for (const auto &j : pass) { urf_pm::Begun &e = j.owner->bq[j.entry]; if (!e.launched) e.failed = true; } }
     } mark{pass, true};
+#ifdef URF_EXPERIMENTS
+    if (g_redo_fault.load() > 0) {   // fault injection: the pass fails with its jobs already out of the queue (what a failing launch or copy does)
+      g_redo_fault.fetch_sub(1);
+      URF_CHECK(false, "injected fault: the redo pass of %zu job(s) was not enqueued", pass.size());
+    }
+#endif
     int k0 = 0;
     for (const auto &j : pass) {
       urf_pm::Begun &e = j.owner->bq[j.entry];
