@@ -721,7 +721,10 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   // full-frame 3x3 launches with whole 64-channel tiles: the weights by LDS-DMA (URF_CONV_WDMA=0 in an experiments build: through registers)
   static const bool wdma_on = [] { const char *e = urf::exp_env("URF_CONV_WDMA"); return !e || atoi(e) != 0; }();
   const bool wdma = wdma_on && taps == 9 && !a.gate && (a.Cout % 64) == 0 && (fuse1a || (a.Cin % 64) == 0) && (a.Cout % 4) == 0;
-  const size_t lds = conv_lds_bytes(taps, fuse1a, wdma);
+  // URF_CONV_LDS_PAD (experiments build): extra dynamic LDS the kernel never touches -- an occupancy what-if (with 1 KB on top of the
+  // 80 KB only ONE convolution workgroup fits on a CU: what SuperPoint costs at the occupancy it has beside a matcher workgroup)
+  static const long conv_pad = [] { const char *e = urf::exp_env("URF_CONV_LDS_PAD"); return e ? atol(e) : 0L; }();
+  const size_t lds = conv_lds_bytes(taps, fuse1a, wdma) + (size_t)(conv_pad > 0 && conv_pad < 70 * 1024 ? conv_pad : 0);
   static DeviceOnce attr_done;
   if (attr_done.need()) {  // > 64 KiB of dynamic LDS needs the opt-in
     const int mx = 72 * 1024;
@@ -733,7 +736,7 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<1, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-    const int mxd = 80 * 1024;
+    const int mxd = 160 * 1024;
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, true, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
     URF_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<9, false, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxd));
