@@ -724,6 +724,8 @@ int launch_conv(const ConvArgs &a, int taps, bool pool, bool fuse1a, int batch, 
   // URF_CONV_LDS_PAD (experiments build): extra dynamic LDS the kernel never touches -- an occupancy what-if (with 1 KB on top of the
   // 80 KB only ONE convolution workgroup fits on a CU: what SuperPoint costs at the occupancy it has beside a matcher workgroup)
   static const long conv_pad = [] { const char *e = urf::exp_env("URF_CONV_LDS_PAD"); return e ? atol(e) : 0L; }();
+  // (round 6, measured and removed: s_setprio 3 / 1 at the top of the full-frame convolutions -- SuperPoint's stream is the critical
+  // one of the strict pipeline -- 1125 / 1124 against 1131 frames/s at 640x480, 940 against 934 at 1241x376: nothing)
   const size_t lds = conv_lds_bytes(taps, fuse1a, wdma) + (size_t)(conv_pad > 0 && conv_pad < 70 * 1024 ? conv_pad : 0);
   static DeviceOnce attr_done;
   if (attr_done.need()) {  // > 64 KiB of dynamic LDS needs the opt-in
