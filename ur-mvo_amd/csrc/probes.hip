@@ -137,6 +137,11 @@ extern "C" int urf_probe_mfma_f16(const void *A_f16, const void *B_f16, const fl
 }
 
 #ifdef URF_EXPERIMENTS   // roof probe, LDS watcher: diagnostics of the experiments build only (include/urf.h)
+// what-if timing runs of bench.py: URF_H2GEMM_XFLAGS sets the diagnostics word of the fast linear kernels at load time
+// (urf_probe_h2gemm_xflags: 1 = non-temporal stores, 2 = no stores, 4 = ONE K chunk only -- 1/8 .. 1/16 of the operand staging;
+// 2 and 4 give wrong results: with URF_REDO_OFF=1 and --no-exact-check only)
+namespace urf { extern int g_h2gemm_xflags; }
+static const int g_xflags_from_env = [] { const char *e = getenv("URF_H2GEMM_XFLAGS"); if (e) urf::g_h2gemm_xflags = atoi(e); return 0; }();
 // ---------------------------------------------------------------------------------------------------
 // Roof probe: the split-f16 inner loop of h2gemm / h2conv / h2mlp (24 x v_mfma_f32_16x16x32_f16 on 12 operand
 // fragments) with the fragments held in registers -- no LDS, no memory, no barrier.  What the chip sustains on random
