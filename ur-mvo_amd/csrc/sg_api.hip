@@ -249,6 +249,8 @@ struct urf_pm {
   unsigned long long exact_batches = 0;
   bool last_fast = false;          // the batch enqueued last ran the fast matcher
   bool calibrating = false;        // pm_calibrate_core's own fast pass: never diverted
+  float *calib_zf = nullptr;       // calibration scratch: the fast pass's log-assignments of up to maxP pairs, and the reduction word
+  int *calib_acc = nullptr;
   bool calib_said = false;         // "the automatic guard calibration could not run" has been said for THIS handle (no process-global state: the reference calls from fresh threads)
   // automatic calibration of the guard's margin (urf_sg_config.calibrate_pairs): pairs still to be measured, the largest difference seen
   int calib_left = 0, calib_failures = 0;
@@ -506,6 +508,10 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
     // (default: a strict handle measures its first 8 pairs; the guarded mode's margin also depends on the SuperPoint side and is
     // calibrated by the caller, urf_sp_calibrate_guard / urf_pm_calibrate_guard)
     h->calib_left = h->cfg.calibrate_pairs > 0 ? h->cfg.calibrate_pairs : (h->cfg.calibrate_pairs == 0 && h->strict ? 8 : 0);
+    if (h->calib_left > 0) {
+      URF_HIP(hipMalloc((void **)&h->calib_zf, (size_t)P * (NP + 1) * LDC * sizeof(float)));
+      URF_HIP(hipMalloc((void **)&h->calib_acc, sizeof(int)));
+    }
   }
   if (dalloc(&h->rs_err, 4)) return -1;
   URF_HIP(hipHostMalloc((void **)&h->h_rs_err, 4 * sizeof(int), hipHostMallocDefault));
@@ -693,6 +699,7 @@ extern "C" void urf_pm_destroy(urf_pm *h) {
       if (h->bq[k].h_online) (void)hipHostFree(h->bq[k].h_online);
     }
     (void)hipFree(h->online);
+    (void)hipFree(h->calib_zf); (void)hipFree(h->calib_acc);
     if (h->h_gflags) (void)hipHostFree(h->h_gflags);
     for (int k = 0; k < urf_pm::kSets; ++k) { (void)hipHostFree(h->hm_set[k]); (void)hipHostFree(h->hn_set[k]); }
     for (int k = 0; k < urf_pm::kBegun; ++k) { (void)hipEventDestroy(h->bq[k].ev_in); (void)hipEventDestroy(h->bq[k].ev_done); }
@@ -1524,10 +1531,14 @@ static int pm_calibrate_core(urf_pm *h, int P, float factor, double *out) {
     URF_CHECK(false, "urf_pm_calibrate_guard: the chip-resident Sinkhorn launch gave up; call again");
   }
   const size_t zbytes = (size_t)P * (NP + 1) * LDC * sizeof(float);
-  float *zf = nullptr;
-  int *acc = nullptr;
-  URF_HIP(hipMalloc((void **)&zf, zbytes));
-  if (hipMalloc((void **)&acc, sizeof(int)) != hipSuccess) { (void)hipFree(zf); URF_CHECK(false, "urf_pm_calibrate_guard: out of device memory"); }
+  // the scratch copy of the fast log-assignments lives with the handle (allocated by build() of a handle that will calibrate itself,
+  // else by the first explicit calibration): no hipMalloc / hipFree inside a call documented as asynchronous
+  if (!h->calib_zf) {
+    URF_HIP(hipMalloc((void **)&h->calib_zf, (size_t)h->maxP * (NP + 1) * LDC * sizeof(float)));
+    if (hipMalloc((void **)&h->calib_acc, sizeof(int)) != hipSuccess) { (void)hipFree(h->calib_zf); h->calib_zf = nullptr; URF_CHECK(false, "urf_pm_calibrate_guard: out of device memory"); }
+  }
+  float *zf = h->calib_zf;
+  int *acc = h->calib_acc;
   int rc = hipMemcpyAsync(zf, h->Z, zbytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -1;
   // the exact pass from the same encoded keypoints (h->x: the fast layers work on their own planes), in this handle's own
   // buffers (no batch is in flight; the device lists of the last fetched batch are overwritten)
@@ -1539,8 +1550,6 @@ static int pm_calibrate_core(urf_pm *h, int P, float factor, double *out) {
   if (!rc) rc = launch_guard_z_calib(h->counts, zf, h->Z, logf(0.1f), acc, P, st);
   if (!rc) rc = hipMemcpyAsync(&worst, acc, sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess ? 0 : -1;
   if (!rc) rc = hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
-  (void)hipFree(zf);
-  (void)hipFree(acc);
   URF_CHECK(rc == 0, "urf_pm_calibrate_guard: a launch or copy failed");
   const float need = factor * (worst + (h->strict ? 0.0f : kGuardSgDescNoise));   // (strict parity: exact slots, no descriptor noise)
   if (need > h->g_z) h->g_z = need;
@@ -1586,9 +1595,11 @@ static int pm_auto_calibrated(urf_pm *h, int P, int rc) {
   }
   h->calib_failures = 0;
   h->calib_left -= P;
+  // (the cap is looked at after EVERY measurement: a pipelined loop with batches smaller than calibrate_pairs may never get to
+  // measure the rest -- the handle usually holds a begun batch when its next one arrives; the online check takes over from here)
+  if (h->calib_worst > kGuardSgZCap && h->strict && h->redo_pairs) h->redo_all = true;
   if (h->calib_left <= 0) {
     h->calib_left = 0;
-    if (h->calib_worst > kGuardSgZCap && h->strict && h->redo_pairs) h->redo_all = true;
     fprintf(stderr, "liburf_front: matcher guard calibrated on this handle's first pairs: largest fast-vs-exact difference %.3g on a decisive "
             "entry, margin in use %.3g%s\n", (double)h->calib_worst, (double)h->g_z,
             h->redo_all ? " -- above the cap the error model is trusted to: every pair will be redone in the exact mode" : "");
