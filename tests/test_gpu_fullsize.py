@@ -921,8 +921,8 @@ def test_sinkhorn_stage_vs_float64_on_the_same_couplings(U, O, sg_exact, sg_fast
 @pytest.mark.parametrize("n0,n1", [(1000, 1000), (1024, 777), (130, 1000)])
 def test_small_grid_kernels_give_the_bits_of_the_batch_kernels(Uexp, sg_blob, n0, n1):
     """One pair cannot fill the chip with 128-row tiles and 128-query attention workgroups: the per-call path runs the
-    deep-ring linear tile (h2gemm_deep_tile: 64 rows, six LDS stages, five chunks in flight) and attention on 32-query
-    workgroups.  Both keep every accumulator's operations and their order, so the whole log-assignment matrix must come out
+    deep-ring linear tile (h2gemm_deep_tile: 64 rows, six LDS stages, five chunks in flight) and attention on 64-query
+    workgroups (1 tile x 4 waves; the 32-query form, measured slower, is compared as well).  Both keep every accumulator's operations and their order, so the whole log-assignment matrix must come out
     bit for bit as with the kernels a batch of eight runs (the switches of the experiments build select them at run time)."""
     Fx, L = Uexp.frontend, Uexp._lib.lib()
     rng = np.random.default_rng(n0 + n1)
@@ -951,7 +951,7 @@ def test_small_grid_kernels_give_the_bits_of_the_batch_kernels(Uexp, sg_blob, n0
 @pytest.mark.parametrize("n0,n1", [(1000, 1000), (1024, 777), (130, 1000), (64, 64)])
 def test_dma_staged_exact_linear_layer_gives_the_bits_of_the_register_staged_one(Uexp, O, sg_blob, n0, n1):
     """linear_dma_kernel (round 6: 64-row tiles, both operands by LDS-DMA into a ring of stages, swizzled instead of padded)
-    against the register-staged tile of conv_mfma_kernel<1>: every output is the same fma chain, so the exact matcher's whole
+    against the register-staged tile of conv_mfma_kernel<1>, and the exact attention kernel on 32- against 64-query workgroups: every output is the same fma chain, so the exact matcher's whole
     log-assignment matrix must be bit-identical with the kernel off (0), on by policy (1) and forced with two and three stages
     -- and equal to the CPU oracle's (the exact mode's contract)."""
     Fx, L = Uexp.frontend, Uexp._lib.lib()
