@@ -636,6 +636,10 @@ extern "C" int urf_pm_build(urf_pm *h, const float *blob, size_t n_floats) {
       memset(h->bq[k].h_online, 0, 64 * sizeof(float));
     }
     if (!pool->engine->online) URF_HIP(hipMalloc((void **)&pool->engine->online, 64 * sizeof(int)));
+    // the engine's stream does its first work NOW: a HIP stream's hardware queue is set up by its first submission, and those
+    // milliseconds would otherwise land on the first flagged pair of the handle (measured: 10.4 against 5.5 ms for a per-call match)
+    URF_HIP(hipMemsetAsync(pool->engine->online, 0, 64 * sizeof(int), pool->engine->st));
+    URF_HIP(hipStreamSynchronize(pool->engine->st));
     h->audit_period = h->cfg.audit_period > 0 ? h->cfg.audit_period : (h->cfg.audit_period < 0 ? 0 : 256);
     URF_HIP(hipDeviceSynchronize());
   }
